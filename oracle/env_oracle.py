@@ -1,0 +1,203 @@
+"""PyTorch-CPU restatement of the env-side hot path (obs / reward / reset / GAE).
+
+ORACLE / TEST INFRASTRUCTURE -- never imported by ``pulse_amd``.
+
+Shapes: N envs, J=24 SMPL bodies, Jt tracked bodies, T future samples.
+``rb`` is Isaac's rigid-body record (N, J, 13): pos 0:3, rot xyzw 3:7,
+lin vel 7:10, ang vel 10:13 (phc/env/tasks/humanoid.py:215-222).
+
+Pinned by tests/golden/env_*.npz (outputs of the reference's own jit functions,
+AST-loaded by oracle/refload.py and run in the build container).
+"""
+import torch
+
+from . import rotations as R
+
+
+def split_rb(rb):
+    return rb[..., 0:3], rb[..., 3:7], rb[..., 7:10], rb[..., 10:13]
+
+
+def self_obs_smpl_max(body_pos, body_rot, body_vel, body_ang_vel,
+                      local_root_obs=True, root_height_obs=True):
+    """compute_humanoid_observations_smpl_max, phc/env/tasks/humanoid.py:1675-1731
+    (upright start, no shape / limb-weight params) -> (N, 1 + 15 J - 3)."""
+    n, j, _ = body_pos.shape
+    root_pos = body_pos[:, 0, :]
+    root_rot = body_rot[:, 0, :]
+    h_inv = R.heading_q_inv(root_rot)
+    h_inv_flat = h_inv.unsqueeze(-2).repeat((1, j, 1)).reshape(n * j, 4)
+
+    rel = (body_pos - root_pos.unsqueeze(-2)).reshape(n * j, 3)
+    loc_pos = R.qrot(h_inv_flat, rel).reshape(n, j * 3)[..., 3:]
+
+    loc_rot = R.qmul(h_inv_flat, body_rot.reshape(n * j, 4))
+    rot6 = R.q_to_tan_norm(loc_rot).reshape(n, j * 6)
+    if not local_root_obs:
+        rot6[..., 0:6] = R.q_to_tan_norm(root_rot)
+
+    loc_vel = R.qrot(h_inv_flat, body_vel.reshape(n * j, 3)).reshape(n, j * 3)
+    loc_ang = R.qrot(h_inv_flat, body_ang_vel.reshape(n * j, 3)).reshape(n, j * 3)
+
+    parts = []
+    if root_height_obs:
+        parts.append(root_pos[:, 2:3])
+    parts += [loc_pos, rot6, loc_vel, loc_ang]
+    return torch.cat(parts, dim=-1)
+
+
+def im_obs_v6(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+              ref_pos, ref_rot, ref_vel, ref_ang_vel, time_steps=1):
+    """compute_imitation_observations_v6, phc/env/tasks/humanoid_im.py:1328-1378
+    (upright start).  cur (N,Jt,.), ref (N*T,Jt,.) -> (N, 24*Jt*T)."""
+    b, j, _ = body_pos.shape
+    t = time_steps
+    h_inv = R.heading_q_inv(root_rot)
+    h = R.heading_q(root_rot)
+    h_inv_e = h_inv.unsqueeze(-2).repeat((1, j, 1)).repeat_interleave(t, 0).view(-1, 4)
+    h_e = h.unsqueeze(-2).repeat((1, j, 1)).repeat_interleave(t, 0).view(-1, 4)
+
+    d_pos = ref_pos.view(b, t, j, 3) - body_pos.view(b, 1, j, 3)
+    d_pos_loc = R.qrot(h_inv_e, d_pos.view(-1, 3))
+
+    cur_rot_e = body_rot[:, None].repeat_interleave(t, 1)
+    d_rot = R.qmul(ref_rot.view(b, t, j, 4), R.qconj(cur_rot_e))
+    d_rot_loc = R.qmul(R.qmul(h_inv_e, d_rot.view(-1, 4)), h_e)
+
+    d_vel = ref_vel.view(b, t, j, 3) - body_vel.view(b, 1, j, 3)
+    d_vel_loc = R.qrot(h_inv_e, d_vel.view(-1, 3))
+    d_ang = ref_ang_vel.view(b, t, j, 3) - body_ang_vel.view(b, 1, j, 3)
+    d_ang_loc = R.qrot(h_inv_e, d_ang.view(-1, 3))
+
+    ref_rel = ref_pos.view(b, t, j, 3) - root_pos.view(b, 1, 1, 3)
+    ref_rel_loc = R.qrot(h_inv_e, ref_rel.view(-1, 3))
+    ref_rot_loc6 = R.q_to_tan_norm(R.qmul(h_inv_e, ref_rot.view(-1, 4)))
+
+    blocks = [d_pos_loc.view(b, t, -1), R.q_to_tan_norm(d_rot_loc).view(b, t, -1),
+              d_vel_loc.view(b, t, -1), d_ang_loc.view(b, t, -1),
+              ref_rel_loc.view(b, t, -1), ref_rot_loc6.view(b, t, -1)]
+    return torch.cat(blocks, dim=-1).view(b, -1)
+
+
+def im_obs_v7(root_pos, root_rot, body_pos, body_vel, ref_pos, ref_vel, time_steps=1):
+    """compute_imitation_observations_v7, phc/env/tasks/humanoid_im.py:1381-1413
+    -> (N, 9*Jt*T)."""
+    b, j, _ = body_pos.shape
+    t = time_steps
+    h_inv_e = R.heading_q_inv(root_rot).unsqueeze(-2).repeat((1, j, 1)).repeat_interleave(t, 0).view(-1, 4)
+    d_pos = R.qrot(h_inv_e, (ref_pos.view(b, t, j, 3) - body_pos.view(b, 1, j, 3)).view(-1, 3))
+    d_vel = R.qrot(h_inv_e, (ref_vel.view(b, t, j, 3) - body_vel.view(b, 1, j, 3)).view(-1, 3))
+    rel = R.qrot(h_inv_e, (ref_pos.view(b, t, j, 3) - root_pos.view(b, 1, 1, 3)).view(-1, 3))
+    return torch.cat([d_pos.view(b, t, -1), d_vel.view(b, t, -1), rel.view(b, t, -1)], dim=-1).view(b, -1)
+
+
+DEFAULT_REWARD_SPECS = {  # phc/env/tasks/humanoid_im.py:55
+    "k_pos": 100.0, "k_rot": 10.0, "k_vel": 0.1, "k_ang_vel": 0.1,
+    "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1,
+}
+DEFAULT_POWER_COEF = 0.0005  # phc/env/tasks/humanoid_im.py:92
+
+
+def im_reward(body_pos, body_rot, body_vel, body_ang_vel,
+              ref_pos, ref_rot, ref_vel, ref_ang_vel, specs=None):
+    """compute_imitation_reward, phc/env/tasks/humanoid_im.py:1543-1574."""
+    s = DEFAULT_REWARD_SPECS if specs is None else specs
+    e_pos = ((ref_pos - body_pos) ** 2).mean(dim=-1).mean(dim=-1)
+    r_pos = torch.exp(-s["k_pos"] * e_pos)
+    ang = R.q_to_angle_axis(R.qmul(ref_rot, R.qconj(body_rot)))[0]
+    r_rot = torch.exp(-s["k_rot"] * (ang ** 2).mean(dim=-1))
+    e_vel = ((ref_vel - body_vel) ** 2).mean(dim=-1).mean(dim=-1)
+    r_vel = torch.exp(-s["k_vel"] * e_vel)
+    e_ang = ((ref_ang_vel - body_ang_vel) ** 2).mean(dim=-1).mean(dim=-1)
+    r_ang = torch.exp(-s["k_ang_vel"] * e_ang)
+    rew = s["w_pos"] * r_pos + s["w_rot"] * r_rot + s["w_vel"] * r_vel + s["w_ang_vel"] * r_ang
+    return rew, torch.stack([r_pos, r_rot, r_vel, r_ang], dim=-1)
+
+
+def power_term(dof_force, dof_vel, progress, coef=DEFAULT_POWER_COEF):
+    """power reward, phc/env/tasks/humanoid_im.py:908-917."""
+    p = -coef * torch.abs(torch.multiply(dof_force, dof_vel)).sum(dim=-1)
+    p[progress <= 3] = 0
+    return p
+
+
+def im_reward_full(rb, ref_pos, ref_rot, ref_vel, ref_ang_vel, dof_force, dof_vel, progress,
+                   specs=None, power_coef=DEFAULT_POWER_COEF, power_reward=True):
+    """HumanoidIm._compute_reward with _full_body_reward, humanoid_im.py:853-919."""
+    bp, br, bv, ba = split_rb(rb)
+    rew, raw = im_reward(bp, br, bv, ba, ref_pos, ref_rot, ref_vel, ref_ang_vel, specs)
+    if power_reward:
+        p = power_term(dof_force, dof_vel, progress, power_coef)
+        rew = rew + p
+        raw = torch.cat([raw, p[:, None]], dim=-1)
+    return rew, raw
+
+
+def im_reset(reset_buf, progress, body_pos, ref_pos, pass_time, term_dist,
+             enable_early_termination=True, disable_collision=False, use_mean=False):
+    """compute_humanoid_im_reset, phc/env/tasks/humanoid_im.py:1600-1628.
+    body_pos/ref_pos (N,Jr,3) already restricted to the reset bodies;
+    term_dist (1,Jr) or (N,Jr).  Returns (reset, terminated) int64."""
+    terminated = torch.zeros_like(reset_buf)
+    if enable_early_termination:
+        dist = torch.norm(body_pos - ref_pos, dim=-1)
+        if use_mean:
+            fallen = torch.any(dist.mean(dim=-1, keepdim=True) > term_dist[0], dim=-1)
+        else:
+            fallen = torch.any(dist > term_dist, dim=-1)
+        fallen = fallen * (progress > 1)
+        if disable_collision:
+            fallen[:] = False
+        terminated = torch.where(fallen, torch.ones_like(reset_buf), terminated)
+    reset = torch.where(pass_time, torch.ones_like(reset_buf), terminated)
+    return reset, terminated
+
+
+def gae(fdones, values, rewards, next_values, gamma, tau):
+    """CommonAgent.discount_values, phc/learning/common_agent.py:493-505.
+    All (T,N,1) except fdones (T,N)."""
+    last = 0
+    advs = torch.zeros_like(rewards)
+    for t in reversed(range(rewards.shape[0])):
+        nd = (1.0 - fdones[t]).unsqueeze(1)
+        delta = rewards[t] + gamma * next_values[t] - values[t]
+        last = delta + gamma * tau * nd * last
+        advs[t] = last
+    return advs
+
+
+def post_physics(rb, ref_now, ref_next, dof_force, dof_vel, progress, pass_time,
+                 reset_body_ids, track_body_ids, term_dist, cycle_counter=None, obs_v=6,
+                 specs=None, power_coef=DEFAULT_POWER_COEF, power_reward=True, use_mean=False):
+    """One HumanoidIm.post_physics_step after ``progress += 1`` and the sim refresh:
+    reward -> reset -> next observation, in the reference's order
+    (phc/env/tasks/humanoid.py:1315-1331, humanoid_im.py:677-706, 853-919, 1119-1192).
+
+    ref_now / ref_next: dicts with pos (N,J,3) rot (N,J,4) vel ang (N,J,3) at
+    motion time t (reward/reset) and t+1 (task obs).  Returns dict with obs (N,934
+    for v6 full body), rew, raw, reset, terminate.
+    """
+    bp, br, bv, ba = split_rb(rb)
+    rew, raw = im_reward_full(rb, ref_now["pos"], ref_now["rot"], ref_now["vel"], ref_now["ang"],
+                              dof_force, dof_vel, progress, specs, power_coef, power_reward)
+    n = rb.shape[0]
+    reset0 = torch.zeros(n, dtype=torch.int64)
+    reset, term = im_reset(reset0, progress, bp[:, reset_body_ids].clone(),
+                           ref_now["pos"][:, reset_body_ids].clone(), pass_time,
+                           term_dist[..., reset_body_ids], use_mean=use_mean)
+    if cycle_counter is not None:
+        rec = torch.logical_and(~pass_time, cycle_counter > 0)
+        reset[rec] = 0
+        term[rec] = 0
+    so = self_obs_smpl_max(bp, br, bv, ba)
+    tb = track_body_ids
+    if obs_v == 6:
+        to = im_obs_v6(bp[:, 0], br[:, 0], bp[:, tb], br[:, tb], bv[:, tb], ba[:, tb],
+                       ref_next["pos"][:, tb], ref_next["rot"][:, tb], ref_next["vel"][:, tb],
+                       ref_next["ang"][:, tb], 1)
+    elif obs_v == 7:
+        to = im_obs_v7(bp[:, 0], br[:, 0], bp[:, tb], bv[:, tb], ref_next["pos"][:, tb],
+                       ref_next["vel"][:, tb], 1)
+    else:
+        raise NotImplementedError(obs_v)
+    return {"obs": torch.cat([so, to], dim=-1), "rew": rew, "raw": raw, "reset": reset, "terminate": term}

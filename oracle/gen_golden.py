@@ -1,0 +1,236 @@
+"""Generate tests/golden/*.npz from the REAL reference functions.
+
+ORACLE / TEST INFRASTRUCTURE.  Runs only in the build container (needs
+/root/reference, read-only).  The reference's TorchScript functions are loaded
+by oracle/refload.py (unmodified text, executed eagerly on PyTorch CPU, fp32)
+and evaluated on seeded synthetic inputs from pulse_amd/synthetic.py; inputs and
+outputs are stored side by side so the fixtures are self-contained.
+
+    python -m oracle.gen_golden            # rewrites tests/golden/*.npz
+
+Fixtures (all small, < 1 MB each):
+  rotations.npz   every quaternion / exp-map / 6-D op on the path + edge cases
+  env_im.npz      self-obs, task-obs v6 / v7, imitation reward (+power), im-reset
+  agent_math.npz  GAE discount_values, PPO actor/critic/bound losses, _calc_advs
+  rms.npz         RunningMeanStd forward sequences (fp64 state), kl_multi
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import refload  # noqa: E402
+from pulse_amd import synthetic as syn  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def gen_rotations():
+    tu = refload.torch_utils()
+    g = syn.make_generator(777)
+    m = 257
+    q = torch.randn(m, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    p = torch.randn(m, 4, generator=g)
+    p = p / p.norm(dim=-1, keepdim=True)
+    v = torch.randn(m, 3, generator=g)
+    e = torch.randn(m, 3, generator=g) * torch.rand(m, 1, generator=g) * 3.0
+    t = torch.rand(m, 1, generator=g)
+    # edge cases
+    q[0] = torch.tensor([0.0, 0.0, 0.0, 1.0])            # identity: sin_theta == 0
+    q[1] = torch.tensor([0.0, 0.0, 0.0, -1.0])           # w = -1
+    q[2] = torch.tensor([1.0, 0.0, 0.0, 0.0])            # pi rotation
+    q[3] = torch.tensor([0.0, 0.0, 1e-6, 1.0])           # below the 1e-5 mask
+    q[3] = q[3] / q[3].norm()
+    q[4] = torch.tensor([0.0, 0.0, 0.0, 1.0000001])      # |w| > 1 -> NaN inside, masked
+    p[5] = q[5]                                          # slerp of identical quats
+    p[6] = -q[6]                                         # antipodal
+    p[7] = q[7] + 1e-4 * torch.randn(4, generator=g)     # nearly identical -> lerp fallback
+    p[7] = p[7] / p[7].norm()
+    e[0] = 0.0                                           # zero exp-map -> 0/0 masked
+    e[1] = torch.tensor([0.0, 0.0, 1e-6])
+    e[2] = torch.tensor([0.0, 3.5, 0.0])                 # angle > pi wraps
+    ang, ax = tu.quat_to_angle_axis(q)
+    out = {
+        "q": q, "p": p, "v": v, "e": e, "t": t,
+        "quat_mul": tu.quat_mul(q, p),
+        "quat_conjugate": tu.quat_conjugate(q),
+        "my_quat_rotate": tu.my_quat_rotate(q, v),
+        "quat_to_angle": ang, "quat_to_axis": ax,
+        "quat_to_exp_map": tu.quat_to_exp_map(q),
+        "quat_to_tan_norm": tu.quat_to_tan_norm(q),
+        "exp_map_to_quat": tu.exp_map_to_quat(e),
+        "slerp": tu.slerp(q, p, t),
+        "calc_heading": tu.calc_heading(q),
+        "calc_heading_quat": tu.calc_heading_quat(q),
+        "calc_heading_quat_inv": tu.calc_heading_quat_inv(q),
+        "normalize_angle": tu.normalize_angle(e[:, 0] * 3.0),
+    }
+    # secondary statement of the isaacgym algebra: poselib (16-multiply product)
+    r3d = refload.importable_modules()["rotation3d"]
+    out["poselib_quat_mul"] = r3d.quat_mul(q, p)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "rotations.npz"), **_np(out))
+
+
+def gen_env_im(n=67):
+    fn = refload.env_functions()
+    g = syn.make_generator(1234)
+    d = syn.env_step_inputs(g, n)
+    rb = d["rb"]
+    bp, br, bv, ba = rb[..., 0:3], rb[..., 3:7], rb[..., 7:10], rb[..., 10:13]
+    rn, rx = d["ref_now"], d["ref_next"]
+    empty = torch.zeros(n, 0)
+    self_obs = fn["compute_humanoid_observations_smpl_max"](bp, br, bv, ba, empty, empty, True, True, True, False, False)
+    self_obs_global_root = fn["compute_humanoid_observations_smpl_max"](bp, br, bv, ba, empty, empty, False, True, True, False, False)
+    task_v6 = fn["compute_imitation_observations_v6"](bp[:, 0], br[:, 0], bp, br, bv, ba,
+                                                      rx["pos"], rx["rot"], rx["vel"], rx["ang"], 1, True)
+    tb = syn.VR_TRACK_BODY_IDS
+    task_v7 = fn["compute_imitation_observations_v7"](bp[:, 0], br[:, 0], bp[:, tb], bv[:, tb],
+                                                      rx["pos"][:, tb], rx["vel"][:, tb], 1, True)
+    task_v6_vr = fn["compute_imitation_observations_v6"](bp[:, 0], br[:, 0], bp[:, tb], br[:, tb], bv[:, tb], ba[:, tb],
+                                                         rx["pos"][:, tb], rx["rot"][:, tb], rx["vel"][:, tb], rx["ang"][:, tb], 1, True)
+    specs = {"k_pos": 100.0, "k_rot": 10.0, "k_vel": 0.1, "k_ang_vel": 0.1,
+             "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1}
+    rew, raw = fn["compute_imitation_reward"](bp[:, 0], br[:, 0], bp, br, bv, ba,
+                                              rn["pos"], rn["rot"], rn["vel"], rn["ang"], specs)
+    # power term exactly as HumanoidIm._compute_reward does it (humanoid_im.py:908-917)
+    power = torch.abs(torch.multiply(d["dof_force"], d["dof_vel"])).sum(dim=-1)
+    power_reward = -0.0005 * power
+    power_reward[d["progress"] <= 3] = 0
+    rew_total = rew + power_reward
+    raw_total = torch.cat([raw, power_reward[:, None]], dim=-1)
+    # reset exactly as HumanoidIm._compute_reset's else-branch (humanoid_im.py:1176-1186)
+    rid = syn.RESET_BODY_IDS
+    term_dist = torch.full((1, 24), 0.25)
+    reset_buf = torch.zeros(n, dtype=torch.int64)
+    contact = torch.zeros(n, 24, 3)
+    reset, terminate = fn["compute_humanoid_im_reset"](reset_buf, d["progress"], contact, torch.tensor([7, 3, 8, 4]),
+                                                       bp[:, rid].clone(), rn["pos"][:, rid].clone(), d["pass_time"],
+                                                       True, term_dist[..., rid], False, False)
+    reset_mean, terminate_mean = fn["compute_humanoid_im_reset"](reset_buf, d["progress"], contact, torch.tensor([7, 3, 8, 4]),
+                                                                 bp[:, rid].clone(), rn["pos"][:, rid].clone(), d["pass_time"],
+                                                                 True, term_dist[..., rid], False, True)
+    out = {
+        "rb": rb, "dof_force": d["dof_force"], "dof_vel": d["dof_vel"], "progress": d["progress"],
+        "pass_time": d["pass_time"],
+        "ref_now_pos": rn["pos"], "ref_now_rot": rn["rot"], "ref_now_vel": rn["vel"], "ref_now_ang": rn["ang"],
+        "ref_next_pos": rx["pos"], "ref_next_rot": rx["rot"], "ref_next_vel": rx["vel"], "ref_next_ang": rx["ang"],
+        "self_obs": self_obs, "self_obs_global_root": self_obs_global_root,
+        "task_obs_v6": task_v6, "task_obs_v7_vr": task_v7, "task_obs_v6_vr": task_v6_vr,
+        "reward_im": rew, "reward_raw_im": raw, "reward": rew_total, "reward_raw": raw_total,
+        "reset": reset, "terminate": terminate, "reset_mean": reset_mean, "terminate_mean": terminate_mean,
+    }
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "env_im.npz"), **_np(out))
+
+
+def gen_agent_math():
+    m = refload.agent_methods()
+    g = syn.make_generator(4321)
+    out = {}
+    for tag, (t, n) in {"a": (16, 64), "b": (32, 67)}.items():
+        rewards, values, next_values, dones = syn.rollout_scalars(g, t, n, done_p=0.05)
+        if tag == "b":
+            dones[:, 3] = 1      # all-done column
+            dones[-1, :] = 1     # every env ends on the last step
+        me = refload.stub_self(horizon_length=t, gamma=0.99, tau=0.95)
+        advs = m["discount_values"](me, dones.float(), values, rewards, next_values)
+        out.update({f"gae_{tag}_rewards": rewards, f"gae_{tag}_values": values,
+                    f"gae_{tag}_next_values": next_values, f"gae_{tag}_dones": dones,
+                    f"gae_{tag}_advs": advs})
+    b, a = 515, 69
+    old_nlp = torch.randn(b, generator=g) * 0.5 + 60
+    nlp = old_nlp + 0.3 * torch.randn(b, generator=g)
+    adv = torch.randn(b, generator=g)
+    me = refload.stub_self(bounds_loss_coef=10.0, normalize_advantage=True)
+    ai = m["_actor_loss"](me, old_nlp, nlp, adv, 0.2)
+    vp = torch.randn(b, 1, generator=g)
+    val = vp + 0.4 * torch.randn(b, 1, generator=g)
+    ret = torch.randn(b, 1, generator=g)
+    c_noclip = m["_critic_loss"](me, vp, val, 0.2, ret, False)["critic_loss"]
+    c_clip = m["_critic_loss"](me, vp, val, 0.2, ret, True)["critic_loss"]
+    mu = 1.2 * torch.randn(b, a, generator=g)
+    bl = m["bound_loss"](me, mu)
+    returns = torch.randn(b, 1, generator=g)
+    values = torch.randn(b, 1, generator=g)
+    advs_n = m["_calc_advs"](me, {"returns": returns, "values": values})
+    out.update({"loss_old_neglogp": old_nlp, "loss_neglogp": nlp, "loss_adv": adv,
+                "actor_loss": ai["actor_loss"], "actor_clipped": ai["actor_clipped"],
+                "loss_old_values": vp, "loss_values": val, "loss_returns": ret,
+                "critic_loss": c_noclip, "critic_loss_clipped": c_clip,
+                "loss_mu": mu, "bound_loss": bl,
+                "advs_returns": returns, "advs_values": values, "advs_normalized": advs_n})
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "agent_math.npz"), **_np(out))
+
+
+def gen_rms():
+    mods = refload.importable_modules()
+    RMS = mods["running_mean_std"].RunningMeanStd
+    g = syn.make_generator(99)
+    f = 37
+    rms = RMS((f,))
+    rms.train()
+    out = {}
+    scale = 1.0 + 4.0 * torch.rand(f, generator=g)
+    shift = 3.0 * torch.randn(f, generator=g)
+    for i, b in enumerate([64, 33, 128]):
+        x = torch.randn(b, f, generator=g) * scale + shift
+        y = rms(x)
+        out[f"x{i}"] = x
+        out[f"y{i}"] = y
+        out[f"mean{i}"] = rms.running_mean.clone()
+        out[f"var{i}"] = rms.running_var.clone()
+        out[f"count{i}"] = rms.count.clone()
+    rms.eval()
+    x = torch.randn(16, f, generator=g) * scale + shift
+    out["x_eval"] = x
+    out["y_eval"] = rms(x)
+    out["y_unnorm"] = rms(torch.randn(16, f, generator=g) * 3.0, unnorm=True)
+    out["x_unnorm_in"] = torch.zeros(0)
+    # re-create the unnorm input deterministically for the consumer
+    g2 = syn.make_generator(100)
+    z = torch.randn(16, f, generator=g2) * 3.0
+    out["z_unnorm_in"] = z
+    out["z_unnorm_out"] = rms(z, unnorm=True)
+    # frozen copy must not update
+    rms.train()
+    rms.freeze()
+    before = rms.running_mean.clone()
+    _ = rms(x)
+    assert torch.equal(before, rms.running_mean)
+    kl = mods["loss_functions"].kl_multi
+    qm, qv, pm, pv = (torch.randn(50, 32, generator=g) for _ in range(4))
+    out.update({"kl_qm": qm, "kl_qv": qv, "kl_pm": pm, "kl_pv": pv, "kl_multi": kl(qm, qv, pm, pv)})
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "rms.npz"), **_np(out))
+
+
+def main():
+    assert refload.available(), "reference tree not found; goldens can only be generated in the build container"
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    gen_rotations()
+    gen_env_im()
+    gen_agent_math()
+    gen_rms()
+    for f in sorted(os.listdir(GOLDEN_DIR)):
+        print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,397 @@
+// Fused HumanoidIm post-physics step for gfx950: imitation reward -> reset -> next observation.
+//
+// Replaces, in one launch, the reference's chain of TorchScript functions
+//   compute_imitation_reward            phc/env/tasks/humanoid_im.py:1543-1574 (+ power term :908-917)
+//   compute_humanoid_im_reset           phc/env/tasks/humanoid_im.py:1600-1628 (+ recovery mask :1188-1190)
+//   compute_humanoid_observations_smpl_max   phc/env/tasks/humanoid.py:1675-1731
+//   compute_imitation_observations_v6 / _v7  phc/env/tasks/humanoid_im.py:1328-1413
+// (each of which is O(30-70) elementwise launches in the reference's GPU pipeline).
+//
+// Mapping (MI355X-first, HBM/launch bound: ~8 KB algorithmic traffic per env-step):
+//   * one 32-lane half-wave per environment, lane b <-> body b (24 of 32 lanes active);
+//     ENVS_PER_BLOCK environments per workgroup, so N=4096 gives 1024 workgroups (>> 256 CUs);
+//   * the env's 13-float AoS rigid-body records and both reference frames (t and t+1) are
+//     staged into LDS with coalesced 16-byte loads, then read back at a 13-float lane stride
+//     (odd stride -> conflict-free ds_read_b32);
+//   * per-env reductions (4 reward errors, power, any-body-fell) are 32-lane butterfly shuffles;
+//   * the 934-float observation row is assembled in LDS and written with full-line 16-byte
+//     stores straight into the caller's row pitch (e.g. a 960-float GEMM-ready pitch, pad zeroed).
+// Compiled with -ffp-contract=off so products/sums round exactly like the eager reference.
+#include "common.h"
+#include "rot_math.h"
+
+namespace pulse {
+
+constexpr int kLanesPerEnv = 32;
+
+struct ObsLayout {
+    int self_w;      // width of the self observation
+    int off_pos, off_rot, off_vel, off_ang;
+    int task_w;      // width of the task observation
+    int per_t;       // task obs floats per future sample
+};
+
+__host__ __device__ inline ObsLayout make_layout(int J, int root_height_obs, int obs_version, int Jt, int T) {
+    ObsLayout L;
+    const int h0 = root_height_obs ? 1 : 0;
+    L.off_pos = h0;
+    L.off_rot = h0 + 3 * (J - 1);
+    L.off_vel = L.off_rot + 6 * J;
+    L.off_ang = L.off_vel + 3 * J;
+    L.self_w = L.off_ang + 3 * J;
+    L.per_t = (obs_version == 7 ? 9 : 24) * Jt;
+    L.task_w = L.per_t * T;
+    return L;
+}
+
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, kLanesPerEnv);
+    return v;
+}
+__device__ __forceinline__ int group_or(int v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v |= __shfl_xor(v, o, kLanesPerEnv);
+    return v;
+}
+
+// cooperative copy of n floats global -> LDS by the 32 lanes of one env group
+__device__ __forceinline__ void stage(float* __restrict__ dst, const float* __restrict__ src, int n, int lane, bool vec_ok) {
+    if (vec_ok) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const int n4 = n >> 2;
+        for (int i = lane; i < n4; i += kLanesPerEnv) d4[i] = s4[i];
+        for (int i = (n4 << 2) + lane; i < n; i += kLanesPerEnv) dst[i] = src[i];
+    } else {
+        for (int i = lane; i < n; i += kLanesPerEnv) dst[i] = src[i];
+    }
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int E>
+__global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_im_step_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int J = a.num_bodies;
+    const int J13 = J * 13;
+    const int T = a.time_steps;
+    const int nd = a.num_dof;
+    const int J13p = (J13 + 3) & ~3;          // keep every LDS segment 16-byte aligned
+    const int ndp = (nd + 3) & ~3;
+    const int colsp = (a.obs_cols + 3) & ~3;
+    // LDS carve-up (floats); every base a multiple of 4 floats
+    float* s_rb = smem;                        // [E][J13p]
+    float* s_rn = s_rb + E * J13p;             // [E][J13p]   ref at t   : pos|rot|vel|ang
+    float* s_rx = s_rn + E * J13p;             // [E][T][J13p] ref at t+1
+    float* s_df = s_rx + E * T * J13p;         // [E][ndp]
+    float* s_dv = s_df + E * ndp;              // [E][ndp]
+    float* s_obs = s_dv + E * ndp;             // [E][colsp]
+
+    const int tid = threadIdx.x;
+    const int slot = tid / kLanesPerEnv;
+    const int lane = tid % kLanesPerEnv;
+    const int count = a.env_ids ? a.num_ids : a.num_envs;
+    const int idx = blockIdx.x * E + slot;
+    bool valid = idx < count;
+    int64_t e = 0;
+    if (valid) {
+        e = a.env_ids ? a.env_ids[idx] : (int64_t)idx;
+        if (a.env_mask && a.env_mask[e] == 0) valid = false;
+    }
+
+    const bool do_self = a.what & PULSE_IM_SELF_OBS;
+    const bool do_task = a.what & PULSE_IM_TASK_OBS;
+    const bool do_rew = a.what & PULSE_IM_REWARD;
+    const bool do_rst = a.what & PULSE_IM_RESET;
+    const bool need_now = do_rew || do_rst;
+    const ObsLayout L = make_layout(J, a.root_height_obs, a.obs_version, a.num_track, T);
+
+    float* rb_e = s_rb + slot * J13p;
+    float* rn_e = s_rn + slot * J13p;
+    float* rx_e = s_rx + slot * T * J13p;
+    float* df_e = s_df + slot * ndp;
+    float* dv_e = s_dv + slot * ndp;
+    float* obs_e = s_obs + slot * colsp;
+
+    // ---------------- stage inputs (global -> LDS, coalesced) ----------------
+    if (valid) {
+        const float* g_rb = a.rb + e * a.rb_env_stride;
+        stage(rb_e, g_rb, J13, lane, aligned16(g_rb));
+        if (need_now) {
+            // ref_now_* rows are J*3 / J*4 floats per env; 16-byte aligned whenever J % 4 == 0
+            const float* p = a.ref_now_pos + e * (J * 3);
+            const float* q = a.ref_now_rot + e * (J * 4);
+            const float* v = a.ref_now_vel + e * (J * 3);
+            const float* w = a.ref_now_ang + e * (J * 3);
+            stage(rn_e, p, J * 3, lane, aligned16(p));
+            stage(rn_e + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
+            stage(rn_e + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
+            stage(rn_e + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
+        }
+        if (do_task) {
+            for (int t = 0; t < T; ++t) {
+                const int64_t r = e * T + t;
+                float* d = rx_e + t * J13p;
+                const float* p = a.ref_next_pos + r * (J * 3);
+                const float* v = a.ref_next_vel + r * (J * 3);
+                stage(d, p, J * 3, lane, aligned16(p));
+                stage(d + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
+                if (a.obs_version != 7) {
+                    const float* q = a.ref_next_rot + r * (J * 4);
+                    const float* w = a.ref_next_ang + r * (J * 3);
+                    stage(d + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
+                    stage(d + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
+                }
+            }
+        }
+        if (do_rew && a.specs.power_reward) {
+            const float* f = a.dof_force + e * nd;
+            const float* v = a.dof_vel + e * nd;
+            stage(df_e, f, nd, lane, aligned16(f));
+            stage(dv_e, v, nd, lane, aligned16(v));
+        }
+        // zero the padding columns of the observation row
+        if (do_self || do_task) {
+            const int obs_w = L.self_w + L.task_w;
+            for (int c = obs_w + lane; c < colsp; c += kLanesPerEnv) obs_e[c] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- per-(env, body) math ----------------
+    if (valid) {
+        const V3 root_p{rb_e[0], rb_e[1], rb_e[2]};
+        const Q4 root_q{rb_e[3], rb_e[4], rb_e[5], rb_e[6]};
+        const Q4 hinv = heading_quat(root_q, true);   // calc_heading_quat_inv
+        const Q4 hfwd = heading_quat(root_q, false);  // calc_heading_quat
+
+        if (do_self) {
+            if (lane < J) {
+                const float* r = rb_e + 13 * lane;
+                const V3 p{r[0], r[1], r[2]};
+                const Q4 q{r[3], r[4], r[5], r[6]};
+                const V3 v{r[7], r[8], r[9]};
+                const V3 w{r[10], r[11], r[12]};
+                if (lane >= 1) {
+                    const V3 lp = qrot(hinv, V3{p.x - root_p.x, p.y - root_p.y, p.z - root_p.z});
+                    float* o = obs_e + L.off_pos + 3 * (lane - 1);
+                    o[0] = lp.x; o[1] = lp.y; o[2] = lp.z;
+                } else if (a.root_height_obs) {
+                    obs_e[0] = root_p.z;
+                }
+                float tn[6];
+                if (lane == 0 && !a.local_root_obs) q_to_tan_norm(root_q, tn);   // humanoid.py:1707-1709
+                else q_to_tan_norm(qmul(hinv, q), tn);
+                float* o = obs_e + L.off_rot + 6 * lane;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = tn[k];
+                const V3 lv = qrot(hinv, v);
+                o = obs_e + L.off_vel + 3 * lane;
+                o[0] = lv.x; o[1] = lv.y; o[2] = lv.z;
+                const V3 lw = qrot(hinv, w);
+                o = obs_e + L.off_ang + 3 * lane;
+                o[0] = lw.x; o[1] = lw.y; o[2] = lw.z;
+            }
+        }
+
+        if (do_task && lane < a.num_track) {
+            const int Jt = a.num_track;
+            const int tb = a.track_ids[lane];
+            const float* r = rb_e + 13 * tb;
+            const V3 p{r[0], r[1], r[2]};
+            const Q4 q{r[3], r[4], r[5], r[6]};
+            const V3 v{r[7], r[8], r[9]};
+            const V3 w{r[10], r[11], r[12]};
+            for (int t = 0; t < T; ++t) {
+                const float* x = rx_e + t * J13p;
+                const V3 pr{x[3 * tb], x[3 * tb + 1], x[3 * tb + 2]};
+                const V3 vr{x[J * 7 + 3 * tb], x[J * 7 + 3 * tb + 1], x[J * 7 + 3 * tb + 2]};
+                float* ob = obs_e + L.self_w + t * L.per_t;
+                const V3 d1 = qrot(hinv, V3{pr.x - p.x, pr.y - p.y, pr.z - p.z});
+                const V3 d3 = qrot(hinv, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z});
+                const V3 d5 = qrot(hinv, V3{pr.x - root_p.x, pr.y - root_p.y, pr.z - root_p.z});
+                if (a.obs_version == 7) {
+                    float* o = ob + 3 * lane;            o[0] = d1.x; o[1] = d1.y; o[2] = d1.z;
+                    o = ob + 3 * Jt + 3 * lane;          o[0] = d3.x; o[1] = d3.y; o[2] = d3.z;
+                    o = ob + 6 * Jt + 3 * lane;          o[0] = d5.x; o[1] = d5.y; o[2] = d5.z;
+                } else {
+                    const Q4 qr{x[J * 3 + 4 * tb], x[J * 3 + 4 * tb + 1], x[J * 3 + 4 * tb + 2], x[J * 3 + 4 * tb + 3]};
+                    const V3 wr{x[J * 10 + 3 * tb], x[J * 10 + 3 * tb + 1], x[J * 10 + 3 * tb + 2]};
+                    float* o = ob + 3 * lane;            o[0] = d1.x; o[1] = d1.y; o[2] = d1.z;
+                    float tn[6];
+                    q_to_tan_norm(qmul(qmul(hinv, qmul(qr, qconj(q))), hfwd), tn);   // change of basis
+                    o = ob + 3 * Jt + 6 * lane;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o[k] = tn[k];
+                    o = ob + 9 * Jt + 3 * lane;          o[0] = d3.x; o[1] = d3.y; o[2] = d3.z;
+                    const V3 d4 = qrot(hinv, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z});
+                    o = ob + 12 * Jt + 3 * lane;         o[0] = d4.x; o[1] = d4.y; o[2] = d4.z;
+                    o = ob + 15 * Jt + 3 * lane;         o[0] = d5.x; o[1] = d5.y; o[2] = d5.z;
+                    q_to_tan_norm(qmul(hinv, qr), tn);
+                    o = ob + 18 * Jt + 6 * lane;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o[k] = tn[k];
+                }
+            }
+        }
+
+        if (do_rew) {
+            // bodies entering the reward: all J (full-body) or the tracked subset (humanoid_im.py:886-899)
+            const int nb = a.full_body_reward ? J : a.num_track;
+            float e_pos = 0.f, e_rot = 0.f, e_vel = 0.f, e_ang = 0.f;
+            if (lane < nb) {
+                const int b = a.full_body_reward ? lane : a.track_ids[lane];
+                const float* r = rb_e + 13 * b;
+                const float* x = rn_e;
+                float dx = x[3 * b] - r[0], dy = x[3 * b + 1] - r[1], dz = x[3 * b + 2] - r[2];
+                e_pos = (dx * dx + dy * dy + dz * dz) / 3.0f;
+                const Q4 q{r[3], r[4], r[5], r[6]};
+                const Q4 qr{x[J * 3 + 4 * b], x[J * 3 + 4 * b + 1], x[J * 3 + 4 * b + 2], x[J * 3 + 4 * b + 3]};
+                const float ang = q_to_angle_axis(qmul(qr, qconj(q)), nullptr);
+                e_rot = ang * ang;
+                dx = x[J * 7 + 3 * b] - r[7]; dy = x[J * 7 + 3 * b + 1] - r[8]; dz = x[J * 7 + 3 * b + 2] - r[9];
+                e_vel = (dx * dx + dy * dy + dz * dz) / 3.0f;
+                dx = x[J * 10 + 3 * b] - r[10]; dy = x[J * 10 + 3 * b + 1] - r[11]; dz = x[J * 10 + 3 * b + 2] - r[12];
+                e_ang = (dx * dx + dy * dy + dz * dz) / 3.0f;
+            }
+            e_pos = group_sum(e_pos); e_rot = group_sum(e_rot);
+            e_vel = group_sum(e_vel); e_ang = group_sum(e_ang);
+            float pw = 0.f;
+            if (a.specs.power_reward) {
+                for (int d = lane; d < nd; d += kLanesPerEnv) pw += fabsf(df_e[d] * dv_e[d]);
+                pw = group_sum(pw);
+            }
+            if (lane == 0) {
+                const float fn = (float)nb;
+                const float r_pos = expf(-a.specs.k_pos * (e_pos / fn));
+                const float r_rot = expf(-a.specs.k_rot * (e_rot / fn));
+                const float r_vel = expf(-a.specs.k_vel * (e_vel / fn));
+                const float r_ang = expf(-a.specs.k_ang_vel * (e_ang / fn));
+                float rew = a.specs.w_pos * r_pos + a.specs.w_rot * r_rot + a.specs.w_vel * r_vel + a.specs.w_ang_vel * r_ang;
+                const int rw = a.specs.power_reward ? 5 : 4;
+                float* raw = a.rew_raw + e * rw;
+                raw[0] = r_pos; raw[1] = r_rot; raw[2] = r_vel; raw[3] = r_ang;
+                if (a.specs.power_reward) {
+                    float p = -a.specs.power_coef * pw;
+                    if (a.progress[e] <= 3) p = 0.0f;     // first frames are not charged (humanoid_im.py:914)
+                    rew += p;
+                    raw[4] = p;
+                }
+                a.rew[e] = rew;
+            }
+        }
+
+        if (do_rst) {
+            float dist = 0.f;
+            int fell = 0;
+            if (lane < a.num_reset) {
+                const int b = a.reset_ids[lane];
+                const float* r = rb_e + 13 * b;
+                const float dx = r[0] - rn_e[3 * b], dy = r[1] - rn_e[3 * b + 1], dz = r[2] - rn_e[3 * b + 2];
+                dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                fell = dist > a.term_dist[b];
+            }
+            int fallen;
+            if (a.reset_use_mean) {
+                const float m = group_sum(dist) / (float)a.num_reset;
+                fallen = m > a.term_dist[a.reset_ids[0]];
+            } else {
+                fallen = group_or(fell);
+            }
+            if (lane == 0) {
+                const bool pt = a.pass_time[e] != 0;
+                int64_t term = (fallen && a.progress[e] > 1) ? 1 : 0;
+                int64_t rst = pt ? 1 : term;
+                if (a.cycle_counter && !pt && a.cycle_counter[e] > 0) { rst = 0; term = 0; }
+                a.reset[e] = rst;
+                a.terminate[e] = term;
+            }
+        }
+    }
+    if (!(do_self || do_task)) return;
+    __syncthreads();
+
+    // ---------------- write the observation row (LDS -> global, 16-byte stores) ----------------
+    if (valid) {
+        const int c0 = do_self ? 0 : L.self_w;
+        const int c1 = do_task ? a.obs_cols : L.self_w;
+        float* g = a.obs + e * a.obs_stride;
+        if (c0 == 0 && (c1 & 3) == 0 && aligned16(g)) {
+            const float4* s4 = reinterpret_cast<const float4*>(obs_e);
+            float4* g4 = reinterpret_cast<float4*>(g);
+            for (int i = lane; i < (c1 >> 2); i += kLanesPerEnv) g4[i] = s4[i];
+        } else {
+            for (int c = c0 + lane; c < c1; c += kLanesPerEnv) g[c] = obs_e[c];
+        }
+    }
+}
+
+}  // namespace pulse
+
+using namespace pulse;
+
+extern "C" {
+
+int pulse_sizeof_im_step_args(void) { return (int)sizeof(pulse_im_step_args); }
+int pulse_self_obs_width(int num_bodies, int root_height_obs) {
+    return make_layout(num_bodies, root_height_obs, 6, 0, 1).self_w;
+}
+int pulse_task_obs_width(int obs_version, int num_track, int time_steps) {
+    return make_layout(1, 0, obs_version, num_track, time_steps).task_w;
+}
+
+int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
+    PULSE_REQUIRE(args != nullptr, "pulse_im_step: null args");
+    const pulse_im_step_args& a = *args;
+    PULSE_REQUIRE(a.num_envs >= 0, "pulse_im_step: negative num_envs");
+    const int count = a.env_ids ? a.num_ids : a.num_envs;
+    if (count == 0 || a.what == 0) return PULSE_OK;
+    PULSE_REQUIRE(a.rb != nullptr, "pulse_im_step: null rb");
+    PULSE_REQUIRE(a.num_bodies >= 1 && a.num_bodies <= kLanesPerEnv, "pulse_im_step: num_bodies %d not in [1,32]", a.num_bodies);
+    PULSE_REQUIRE(a.rb_env_stride >= (int64_t)a.num_bodies * 13, "pulse_im_step: rb_env_stride too small");
+    PULSE_REQUIRE(a.time_steps >= 1, "pulse_im_step: time_steps < 1");
+    const bool do_obs = a.what & (PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS);
+    const ObsLayout L = make_layout(a.num_bodies, a.root_height_obs, a.obs_version, a.num_track, a.time_steps);
+    if (do_obs) {
+        PULSE_REQUIRE(a.obs != nullptr, "pulse_im_step: null obs");
+        PULSE_REQUIRE(a.obs_cols >= L.self_w + ((a.what & PULSE_IM_TASK_OBS) ? L.task_w : 0),
+                      "pulse_im_step: obs_cols %d < observation width %d", a.obs_cols, L.self_w + L.task_w);
+        PULSE_REQUIRE(a.obs_stride >= a.obs_cols, "pulse_im_step: obs_stride < obs_cols");
+    }
+    if (a.what & PULSE_IM_TASK_OBS) {
+        PULSE_REQUIRE(a.obs_version == 6 || a.obs_version == 7, "pulse_im_step: obs_version %d unsupported (6|7)", a.obs_version);
+        PULSE_REQUIRE(a.track_ids != nullptr && a.num_track >= 1 && a.num_track <= a.num_bodies, "pulse_im_step: bad track ids");
+        PULSE_REQUIRE(a.ref_next_pos && a.ref_next_vel, "pulse_im_step: null ref_next");
+        PULSE_REQUIRE(a.obs_version == 7 || (a.ref_next_rot && a.ref_next_ang), "pulse_im_step: null ref_next rot/ang");
+    }
+    if (a.what & (PULSE_IM_REWARD | PULSE_IM_RESET)) {
+        PULSE_REQUIRE(a.ref_now_pos && a.ref_now_rot && a.ref_now_vel && a.ref_now_ang, "pulse_im_step: null ref_now");
+        PULSE_REQUIRE(a.progress != nullptr, "pulse_im_step: null progress");
+    }
+    if (a.what & PULSE_IM_REWARD) {
+        PULSE_REQUIRE(a.rew && a.rew_raw, "pulse_im_step: null reward outputs");
+        PULSE_REQUIRE(a.full_body_reward || (a.track_ids && a.num_track >= 1), "pulse_im_step: subset reward needs track ids");
+        if (a.specs.power_reward)
+            PULSE_REQUIRE(a.dof_force && a.dof_vel && a.num_dof >= 1, "pulse_im_step: power reward needs dof force/vel");
+    }
+    if (a.what & PULSE_IM_RESET) {
+        PULSE_REQUIRE(a.reset && a.terminate && a.pass_time && a.term_dist, "pulse_im_step: null reset inputs/outputs");
+        PULSE_REQUIRE(a.reset_ids && a.num_reset >= 1 && a.num_reset <= kLanesPerEnv, "pulse_im_step: bad reset ids");
+    }
+    constexpr int E = 4;
+    const int J13p = (a.num_bodies * 13 + 3) & ~3;
+    const int ndp = (a.num_dof + 3) & ~3;
+    const int colsp = do_obs ? ((a.obs_cols + 3) & ~3) : 0;
+    const size_t lds = sizeof(float) * (size_t)E * ((2 + a.time_steps) * J13p + 2 * ndp + colsp);
+    PULSE_REQUIRE(lds <= 160 * 1024, "pulse_im_step: LDS request %zu > 160 KiB", lds);
+    const unsigned grid = (unsigned)((count + E - 1) / E);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(im_step_kernel<E>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_im_step: cannot raise LDS limit: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(im_step_kernel<E>, dim3(grid), dim3(E * kLanesPerEnv), lds, as_stream(s), a);
+    return check_launch("pulse_im_step");
+}
+}

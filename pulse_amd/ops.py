@@ -1,0 +1,406 @@
+"""Tensor-level wrappers over the C ABI, named after the reference functions they replace.
+
+Every function takes ``torch`` tensors that already live on the GPU, checks
+dtype / layout, and enqueues the HIP kernel on torch's CURRENT stream through
+``libpulse_hip.so`` (PyTorch is only the allocator / stream provider here).
+There is no fallback: CPU tensors are rejected and a missing library raises.
+
+Reference mapping (paths relative to the reference root):
+  quat_mul, quat_conjugate                 isaacgym.torch_utils (3P)
+  my_quat_rotate ... calc_heading_quat_inv phc/utils/torch_utils.py:45-240
+  compute_humanoid_observations_smpl_max   phc/env/tasks/humanoid.py:1675-1731
+  compute_imitation_observations_v6 / _v7  phc/env/tasks/humanoid_im.py:1328-1413
+  compute_imitation_reward                 phc/env/tasks/humanoid_im.py:1543-1574
+  compute_humanoid_im_reset                phc/env/tasks/humanoid_im.py:1600-1628
+  discount_values                          phc/learning/common_agent.py:493-505
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS, ImStepArgs, RewardSpecs
+
+DEFAULT_REWARD_SPECS = {"k_pos": 100.0, "k_rot": 10.0, "k_vel": 0.1, "k_ang_vel": 0.1,
+                        "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: tensor must live on the GPU (pulse_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _c(t, name, dtype=torch.float32):
+    t = _dev(t, name, dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# --------------------------------------------------------------------------- #
+# rotation algebra
+# --------------------------------------------------------------------------- #
+def _rows(t, width, name):
+    if t.shape[-1] != width:
+        raise ValueError(f"{name}: last dim must be {width}, got {tuple(t.shape)}")
+    return t.numel() // width
+
+
+def quat_mul(a, b):
+    a, b = _c(a, "a"), _c(b, "b")
+    if a.shape != b.shape:
+        raise AssertionError("quat_mul: shape mismatch")  # the reference asserts equal shapes
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().pulse_quat_mul(_ptr(a), _ptr(b), _ptr(out), _rows(a, 4, "a"), _stream()), "pulse_quat_mul")
+    return out
+
+
+def quat_conjugate(a):
+    a = _c(a, "a")
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().pulse_quat_conjugate(_ptr(a), _ptr(out), _rows(a, 4, "a"), _stream()), "pulse_quat_conjugate")
+    return out
+
+
+def my_quat_rotate(q, v):
+    q, v = _c(q, "q"), _c(v, "v")
+    m = _rows(q, 4, "q")
+    if _rows(v, 3, "v") != m:
+        raise ValueError("my_quat_rotate: q and v row counts differ")
+    out = torch.empty_like(v)
+    _lib.check(_lib.load().pulse_quat_rotate(_ptr(q), _ptr(v), _ptr(out), m, _stream()), "pulse_quat_rotate")
+    return out
+
+
+def quat_to_angle_axis(q):
+    q = _c(q, "q")
+    m = _rows(q, 4, "q")
+    angle = torch.empty(q.shape[:-1], dtype=torch.float32, device=q.device)
+    axis = torch.empty(q.shape[:-1] + (3,), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().pulse_quat_to_angle_axis(_ptr(q), _ptr(angle), _ptr(axis), m, _stream()), "pulse_quat_to_angle_axis")
+    return angle, axis
+
+
+def quat_to_exp_map(q):
+    q = _c(q, "q")
+    out = torch.empty(q.shape[:-1] + (3,), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().pulse_quat_to_exp_map(_ptr(q), _ptr(out), _rows(q, 4, "q"), _stream()), "pulse_quat_to_exp_map")
+    return out
+
+
+def quat_to_tan_norm(q):
+    q = _c(q, "q")
+    out = torch.empty(q.shape[:-1] + (6,), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().pulse_quat_to_tan_norm(_ptr(q), _ptr(out), _rows(q, 4, "q"), _stream()), "pulse_quat_to_tan_norm")
+    return out
+
+
+def exp_map_to_quat(e):
+    e = _c(e, "exp_map")
+    out = torch.empty(e.shape[:-1] + (4,), dtype=torch.float32, device=e.device)
+    _lib.check(_lib.load().pulse_exp_map_to_quat(_ptr(e), _ptr(out), _rows(e, 3, "exp_map"), _stream()), "pulse_exp_map_to_quat")
+    return out
+
+
+def slerp(q0, q1, t):
+    q0, q1 = _c(q0, "q0"), _c(q1, "q1")
+    m = _rows(q0, 4, "q0")
+    t = _c(t, "t").reshape(-1)
+    if q1.shape != q0.shape or t.numel() != m:
+        raise ValueError("slerp: shape mismatch")
+    out = torch.empty_like(q0)
+    _lib.check(_lib.load().pulse_slerp(_ptr(q0), _ptr(q1), _ptr(t), _ptr(out), m, _stream()), "pulse_slerp")
+    return out
+
+
+def calc_heading(q):
+    q = _c(q, "q")
+    out = torch.empty(q.shape[:-1], dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().pulse_calc_heading(_ptr(q), _ptr(out), _rows(q, 4, "q"), _stream()), "pulse_calc_heading")
+    return out
+
+
+def calc_heading_quat(q):
+    q = _c(q, "q")
+    out = torch.empty_like(q)
+    _lib.check(_lib.load().pulse_calc_heading_quat(_ptr(q), _ptr(out), _rows(q, 4, "q"), 0, _stream()), "pulse_calc_heading_quat")
+    return out
+
+
+def calc_heading_quat_inv(q):
+    q = _c(q, "q")
+    out = torch.empty_like(q)
+    _lib.check(_lib.load().pulse_calc_heading_quat(_ptr(q), _ptr(out), _rows(q, 4, "q"), 1, _stream()), "pulse_calc_heading_quat")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# fused HumanoidIm post-physics step
+# --------------------------------------------------------------------------- #
+def _specs_struct(specs=None, power_coef=0.0005, power_reward=True):
+    s = dict(DEFAULT_REWARD_SPECS)
+    if specs:
+        s.update(specs)
+    return RewardSpecs(s["k_pos"], s["k_rot"], s["k_vel"], s["k_ang_vel"], s["w_pos"], s["w_rot"], s["w_vel"],
+                       s["w_ang_vel"], float(power_coef), 1 if power_reward else 0)
+
+
+def _ids32(ids, device):
+    if isinstance(ids, torch.Tensor):
+        return ids.to(device=device, dtype=torch.int32).contiguous()
+    return torch.tensor(list(ids), dtype=torch.int32, device=device)
+
+
+def pack_rb(body_pos, body_rot, body_vel, body_ang_vel):
+    """Return an (N, J, 13) AoS tensor for the four body tensors.
+
+    When they are the reference-style VIEWS of one Isaac rigid-body buffer
+    (phc/env/tasks/humanoid.py:219-222) the buffer itself is returned (zero copy);
+    otherwise (gathered copies) the records are re-packed.
+    """
+    p = _dev(body_pos, "body_pos")
+    n, j = p.shape[0], p.shape[1]
+    ts = (body_pos, body_rot, body_vel, body_ang_vel)
+    offs = (0, 3, 7, 10)
+    try:
+        same = all(t.untyped_storage().data_ptr() == p.untyped_storage().data_ptr() for t in ts)
+    except Exception:
+        same = False
+    if same and all(t.stride()[-1] == 1 and t.stride()[-2] == 13 for t in ts):
+        base_off = p.storage_offset()
+        if all(t.storage_offset() - base_off == o for t, o in zip(ts, offs)) and all(t.stride() == p.stride() for t in ts):
+            return torch.as_strided(p, (n, j, 13), (p.stride()[0], 13, 1), base_off)
+    return torch.cat([_dev(t, "body tensor") for t in ts], dim=-1).contiguous()
+
+
+def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=None, dof_vel=None,
+            progress=None, pass_time=None, cycle_counter=None, track_ids=None, reset_ids=None, term_dist=None,
+            reset_use_mean=False, full_body_reward=True, obs_version=6, local_root_obs=True,
+            root_height_obs=True, specs=None, power_coef=0.0005, power_reward=True,
+            env_ids=None, env_mask=None, obs=None, obs_cols=None, rew=None, rew_raw=None, reset=None,
+            terminate=None):
+    """Low-level entry: one launch of pulse_im_step.  ``rb`` is (N, J, 13) with unit inner strides
+    (the env stride may be larger).  ref_* are dicts with keys pos/rot/vel/ang.  Outputs that are
+    not supplied are allocated.  Returns dict(obs, rew, rew_raw, reset, terminate)."""
+    lib = _lib.load()
+    rb = _dev(rb, "rb")
+    if rb.dim() != 3 or rb.shape[-1] != 13 or rb.stride()[-1] != 1 or rb.stride()[-2] != 13:
+        raise ValueError("rb must be (N, J, 13) with contiguous body records")
+    n, j = rb.shape[0], rb.shape[1]
+    dev = rb.device
+    a = ImStepArgs()
+    keep = []  # keep temporaries alive until the call returns
+
+    def P(t, name, dtype=torch.float32):
+        if t is None:
+            return None
+        t = _c(t, name, dtype)
+        keep.append(t)
+        return t.data_ptr()
+
+    a.rb, a.rb_env_stride, a.num_envs, a.num_bodies = rb.data_ptr(), rb.stride()[0], n, j
+    if env_ids is not None:
+        env_ids = _c(env_ids, "env_ids", torch.int64)
+        keep.append(env_ids)
+        a.env_ids, a.num_ids = env_ids.data_ptr(), env_ids.numel()
+    if env_mask is not None:
+        m = env_mask
+        if m.dtype == torch.bool:
+            m = m.view(torch.uint8)
+        a.env_mask = P(m, "env_mask", torch.uint8)
+    if ref_now is not None:
+        a.ref_now_pos, a.ref_now_rot = P(ref_now["pos"], "ref_now.pos"), P(ref_now["rot"], "ref_now.rot")
+        a.ref_now_vel, a.ref_now_ang = P(ref_now["vel"], "ref_now.vel"), P(ref_now["ang"], "ref_now.ang")
+    if ref_next is not None:
+        a.ref_next_pos, a.ref_next_vel = P(ref_next["pos"], "ref_next.pos"), P(ref_next["vel"], "ref_next.vel")
+        a.ref_next_rot, a.ref_next_ang = P(ref_next.get("rot"), "ref_next.rot"), P(ref_next.get("ang"), "ref_next.ang")
+    a.time_steps = time_steps
+    a.dof_force, a.dof_vel = P(dof_force, "dof_force"), P(dof_vel, "dof_vel")
+    a.num_dof = dof_force.shape[-1] if dof_force is not None else 0
+    a.progress = P(progress, "progress", torch.int64)
+    if pass_time is not None:
+        pt = pass_time.view(torch.uint8) if pass_time.dtype == torch.bool else pass_time
+        a.pass_time = P(pt, "pass_time", torch.uint8)
+    a.cycle_counter = P(cycle_counter, "cycle_counter", torch.int64)
+    if track_ids is not None:
+        t = _ids32(track_ids, dev)
+        keep.append(t)
+        a.track_ids, a.num_track = t.data_ptr(), t.numel()
+    if reset_ids is not None:
+        t = _ids32(reset_ids, dev)
+        keep.append(t)
+        a.reset_ids, a.num_reset = t.data_ptr(), t.numel()
+    a.term_dist = P(term_dist, "term_dist")
+    a.reset_use_mean, a.full_body_reward = int(reset_use_mean), int(full_body_reward)
+    a.what, a.obs_version = what, obs_version
+    a.local_root_obs, a.root_height_obs = int(local_root_obs), int(root_height_obs)
+    a.specs = _specs_struct(specs, power_coef, power_reward)
+
+    out = {}
+    if what & (PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS):
+        sw = lib.pulse_self_obs_width(j, int(root_height_obs))
+        tw = lib.pulse_task_obs_width(obs_version, a.num_track, time_steps) if what & PULSE_IM_TASK_OBS else 0
+        width = sw + tw
+        if obs is None:
+            obs = torch.empty(n, width if obs_cols is None else obs_cols, dtype=torch.float32, device=dev)
+        _dev(obs, "obs")
+        if obs.stride()[-1] != 1:
+            raise ValueError("obs rows must be contiguous")
+        a.obs, a.obs_stride = obs.data_ptr(), obs.stride()[0]
+        a.obs_cols = width if obs_cols is None else obs_cols
+        out["obs"] = obs
+    if what & PULSE_IM_REWARD:
+        rw = 5 if power_reward else 4
+        rew = torch.empty(n, dtype=torch.float32, device=dev) if rew is None else _dev(rew, "rew")
+        rew_raw = torch.empty(n, rw, dtype=torch.float32, device=dev) if rew_raw is None else _dev(rew_raw, "rew_raw")
+        if not (rew.is_contiguous() and rew_raw.is_contiguous() and rew_raw.shape[-1] == rw):
+            raise ValueError("rew / rew_raw must be contiguous, rew_raw (N, 4|5)")
+        a.rew, a.rew_raw = rew.data_ptr(), rew_raw.data_ptr()
+        out["rew"], out["rew_raw"] = rew, rew_raw
+    if what & PULSE_IM_RESET:
+        reset = torch.empty(n, dtype=torch.int64, device=dev) if reset is None else _dev(reset, "reset", torch.int64)
+        terminate = torch.empty(n, dtype=torch.int64, device=dev) if terminate is None else _dev(terminate, "terminate", torch.int64)
+        a.reset, a.terminate = reset.data_ptr(), terminate.data_ptr()
+        out["reset"], out["terminate"] = reset, terminate
+    _lib.check(lib.pulse_im_step(ctypes.byref(a), _stream()), "pulse_im_step")
+    return out
+
+
+def compute_humanoid_observations_smpl_max(body_pos, body_rot, body_vel, body_ang_vel, smpl_params=None,
+                                           limb_weight_params=None, local_root_obs=True, root_height_obs=True,
+                                           upright=True, has_smpl_params=False, has_limb_weight_params=False):
+    """phc/env/tasks/humanoid.py:1675-1731 (upright start, no shape / limb obs)."""
+    if not upright or has_smpl_params or has_limb_weight_params:
+        raise NotImplementedError("only upright=True without shape / limb-weight observations is supported")
+    rb = pack_rb(body_pos, body_rot, body_vel, body_ang_vel)
+    return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=local_root_obs, root_height_obs=root_height_obs)["obs"]
+
+
+def _split_task_only(full, self_w):
+    return full[:, self_w:]
+
+
+def compute_imitation_observations_v6(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+                                      ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps, upright=True):
+    """phc/env/tasks/humanoid_im.py:1328-1378.  body_* are the tracked subset (B, Jt, .); the root
+    is passed separately exactly as in the reference."""
+    if not upright:
+        raise NotImplementedError("upright=False (remove_base_rot) is not supported")
+    return _task_obs(6, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+                     ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps)
+
+
+def compute_imitation_observations_v7(root_pos, root_rot, body_pos, body_vel, ref_body_pos, ref_body_vel, time_steps, upright=True):
+    """phc/env/tasks/humanoid_im.py:1381-1413."""
+    if not upright:
+        raise NotImplementedError("upright=False (remove_base_rot) is not supported")
+    z4 = torch.zeros(body_pos.shape[:-1] + (4,), dtype=torch.float32, device=body_pos.device)
+    z4[..., 3] = 1.0
+    z3 = torch.zeros_like(body_pos)
+    return _task_obs(7, root_pos, root_rot, body_pos, z4, body_vel, z3, ref_body_pos, None, ref_body_vel, None, time_steps)
+
+
+def _task_obs(version, root_pos, root_rot, bp, br, bv, ba, rp, rr, rv, ra, time_steps):
+    # The kernel indexes bodies through a track list and reads the root from body 0, so build
+    # a (B, 1 + Jt, 13) record array: slot 0 = root, slots 1.. = the tracked subset.
+    b, jt = bp.shape[0], bp.shape[1]
+    dev = bp.device
+    root = torch.zeros(b, 1, 13, dtype=torch.float32, device=dev)
+    root[:, 0, 0:3] = root_pos
+    root[:, 0, 3:7] = root_rot
+    rb = torch.cat([root, torch.cat([bp, br, bv, ba], dim=-1)], dim=1).contiguous()
+    j = 1 + jt
+
+    def pad(x, w):  # (B*T, Jt, w) -> (B*T, 1+Jt, w)
+        x = x.reshape(b * time_steps, jt, w)
+        return torch.cat([torch.zeros(b * time_steps, 1, w, dtype=torch.float32, device=dev), x], dim=1).contiguous()
+
+    ref_next = {"pos": pad(rp, 3), "vel": pad(rv, 3)}
+    if version != 7:
+        ref_next["rot"], ref_next["ang"] = pad(rr, 4), pad(ra, 3)
+    lib = _lib.load()
+    sw = lib.pulse_self_obs_width(j, 1)
+    tw = lib.pulse_task_obs_width(version, jt, time_steps)
+    full = torch.empty(b, sw + tw, dtype=torch.float32, device=dev)
+    im_step(rb, what=PULSE_IM_TASK_OBS, ref_next=ref_next, time_steps=time_steps, obs_version=version,
+            track_ids=list(range(1, j)), obs=full)
+    return full[:, sw:]
+
+
+def compute_imitation_reward(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+                             ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, rwd_specs):
+    """phc/env/tasks/humanoid_im.py:1543-1574 -> (reward (N,), reward_raw (N,4))."""
+    rb = pack_rb(body_pos, body_rot, body_vel, body_ang_vel)
+    n = rb.shape[0]
+    dev = rb.device
+    ref = {"pos": ref_body_pos, "rot": ref_body_rot, "vel": ref_body_vel, "ang": ref_body_ang_vel}
+    out = im_step(rb, what=PULSE_IM_REWARD, ref_now=ref, specs=rwd_specs, power_reward=False,
+                  progress=torch.zeros(n, dtype=torch.int64, device=dev))
+    return out["rew"], out["rew_raw"]
+
+
+def compute_humanoid_im_reset(reset_buf, progress_buf, contact_buf, contact_body_ids, rigid_body_pos, ref_body_pos,
+                              pass_time, enable_early_termination, termination_distance, disableCollision, use_mean):
+    """phc/env/tasks/humanoid_im.py:1600-1628.  rigid_body_pos / ref_body_pos are already restricted
+    to the reset bodies (N, Jr, 3); termination_distance is (Jr,) or (1, Jr)."""
+    n, jr = rigid_body_pos.shape[0], rigid_body_pos.shape[1]
+    dev = rigid_body_pos.device
+    if (not enable_early_termination) or disableCollision:
+        term = torch.zeros_like(reset_buf)
+        return torch.where(pass_time, torch.ones_like(reset_buf), term), term
+    rb = torch.zeros(n, jr, 13, dtype=torch.float32, device=dev)
+    rb[..., 0:3] = rigid_body_pos
+    rb[..., 6] = 1.0
+    z3 = torch.zeros(n, jr, 3, dtype=torch.float32, device=dev)
+    z4 = torch.zeros(n, jr, 4, dtype=torch.float32, device=dev)
+    ref = {"pos": ref_body_pos, "rot": z4, "vel": z3, "ang": z3}
+    td = termination_distance.reshape(-1).to(torch.float32)
+    if td.numel() == 1:
+        td = td.expand(jr)
+    out = im_step(rb, what=PULSE_IM_RESET, ref_now=ref, progress=progress_buf, pass_time=pass_time,
+                  reset_ids=list(range(jr)), term_dist=td.contiguous(), reset_use_mean=use_mean)
+    return out["reset"], out["terminate"]
+
+
+# --------------------------------------------------------------------------- #
+# GAE
+# --------------------------------------------------------------------------- #
+def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma, tau, return_returns=False):
+    """CommonAgent.discount_values, phc/learning/common_agent.py:493-505.
+
+    Tensors are (T, N, 1) [dones (T, N), uint8 or float] in ANY strides that all agree
+    (the reference's time-major layout or this framework's env-major buffers viewed time-major).
+    """
+    r = _dev(mb_rewards, "mb_rewards")
+    t, n = r.shape[0], r.shape[1]
+    v, nv = _dev(mb_values, "mb_values"), _dev(mb_next_values, "mb_next_values")
+    d = mb_fdones
+    if d.dtype != torch.uint8:
+        d = (d != 0).to(torch.uint8)
+    _dev(d, "mb_fdones", torch.uint8)
+    st, sn = r.stride()[0], r.stride()[1]
+    for x, name in ((v, "values"), (nv, "next_values")):
+        if (x.stride()[0], x.stride()[1]) != (st, sn) or x.shape[:2] != r.shape[:2]:
+            raise ValueError(f"discount_values: {name} layout differs from rewards")
+    if (d.stride()[0], d.stride()[1]) != (st, sn):
+        # bring dones to the rewards' layout (uint8, tiny)
+        d2 = torch.empty_strided((t, n), (st, sn), dtype=torch.uint8, device=r.device)
+        d2.copy_(d.reshape(t, n))
+        d = d2
+    advs = torch.empty_strided(r.shape, r.stride(), dtype=torch.float32, device=r.device)
+    rets = torch.empty_strided(r.shape, r.stride(), dtype=torch.float32, device=r.device) if return_returns else None
+    gt = float(gamma) * float(tau)  # Python evaluates gamma * tau in double first
+    _lib.check(_lib.load().pulse_gae(_ptr(r), _ptr(v), _ptr(nv), _ptr(d), t, n, st, sn, float(gamma), gt,
+                                     _ptr(advs), _ptr(rets), _stream()), "pulse_gae")
+    return (advs, rets) if return_returns else advs

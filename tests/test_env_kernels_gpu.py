@@ -1,0 +1,275 @@
+"""GPU parity: rotation ops, fused HumanoidIm step and GAE through the C ABI vs the CPU oracle
+and the committed golden vectors (outputs of the real reference functions).
+
+Tolerances: float32 observations / rewards / advantages within 1e-5 (north_star); integer
+outputs (reset / terminate, env and body indexing) bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import env_oracle as E
+from oracle import rotations as R
+from pulse_amd import ops, synthetic as syn
+from pulse_amd._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+ALL = PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS | PULSE_IM_REWARD | PULSE_IM_RESET
+
+
+def close(a, b, atol=ATOL, rtol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, equal_nan=True)
+
+
+# ------------------------------------------------------------------ rotations
+def test_rotation_ops_vs_golden(golden, dev):
+    g = golden("rotations.npz")
+    q, p, v, e, t = (g.t(k, dev) for k in "qpvet")
+    close(ops.quat_mul(q, p), g.np("quat_mul"), 2e-6)
+    close(ops.quat_conjugate(q), g.np("quat_conjugate"), 0)
+    close(ops.my_quat_rotate(q, v), g.np("my_quat_rotate"), 5e-6)
+    ang, ax = ops.quat_to_angle_axis(q)
+    # rows 3,4: |sin(theta/2)| at / below the 1e-5 mask, a knife-edge the test keeps out of `ang`
+    keep = np.ones(len(g.np("quat_to_angle")), bool)
+    keep[3] = False
+    close(ang[torch.from_numpy(keep).to(dev)], g.np("quat_to_angle")[keep], 5e-6)
+    close(ax[torch.from_numpy(keep).to(dev)], g.np("quat_to_axis")[keep], 5e-6)
+    close(ops.quat_to_exp_map(q)[torch.from_numpy(keep).to(dev)], g.np("quat_to_exp_map")[keep], 1e-5)
+    close(ops.quat_to_tan_norm(q), g.np("quat_to_tan_norm"), 5e-6)
+    close(ops.exp_map_to_quat(e), g.np("exp_map_to_quat"), 5e-6)
+    close(ops.slerp(q, p, t), g.np("slerp"), 5e-6)
+    close(ops.calc_heading(q), g.np("calc_heading"), 5e-6)
+    close(ops.calc_heading_quat(q), g.np("calc_heading_quat"), 5e-6)
+    close(ops.calc_heading_quat_inv(q), g.np("calc_heading_quat_inv"), 5e-6)
+
+
+def test_rotation_masked_branches(dev):
+    # identity / |w|>1 -> angle 0, axis z ; zero exp-map -> identity quaternion
+    q = torch.tensor([[0, 0, 0, 1.0], [0, 0, 0, 1.0000001], [0, 0, 0, -1.0]], device=dev)
+    ang, ax = ops.quat_to_angle_axis(q)
+    assert torch.equal(ang.cpu(), torch.zeros(3))
+    assert torch.equal(ax.cpu(), torch.tensor([[0, 0, 1.0]] * 3))
+    z = ops.exp_map_to_quat(torch.zeros(2, 3, device=dev))
+    assert torch.equal(z.cpu(), torch.tensor([[0, 0, 0, 1.0]] * 2))
+
+
+def test_rotation_properties_large(dev):
+    # size-independent properties at 4096*24 rows: rotate-by-inverse round trip, unit norms,
+    # exp-map round trip, slerp end points
+    m = 4096 * 24
+    gq = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.randn(m, 4, generator=gq)
+    q = (q / q.norm(dim=-1, keepdim=True)).to(dev)
+    v = torch.randn(m, 3, generator=gq).to(dev)
+    back = ops.my_quat_rotate(ops.quat_conjugate(q), ops.my_quat_rotate(q, v))   # poselib test_rotation.py:25-30
+    assert (back - v).abs().max().item() < 2e-5
+    tn = ops.quat_to_tan_norm(q)
+    assert (tn[:, :3].norm(dim=-1) - 1).abs().max().item() < 1e-5
+    assert (tn[:, :3] * tn[:, 3:]).sum(-1).abs().max().item() < 1e-5
+    q2 = ops.exp_map_to_quat(ops.quat_to_exp_map(q))
+    dot = (q2 * q).sum(-1).abs()
+    assert (dot - 1).abs().max().item() < 1e-4   # 2*acos near w=+-1 is ill-conditioned: ~sqrt(eps) in angle
+    p = torch.roll(q, 1, 0)
+    assert (ops.slerp(q, p, torch.zeros(m, device=dev)) - q).abs().max().item() < 1e-5
+    hq, hqi = ops.calc_heading_quat(q), ops.calc_heading_quat_inv(q)
+    ident = ops.quat_mul(hq, hqi)
+    assert (ident - torch.tensor([0, 0, 0, 1.0], device=dev)).abs().max().item() < 1e-6
+
+
+def test_empty_inputs(dev):
+    assert ops.quat_mul(torch.zeros(0, 4, device=dev), torch.zeros(0, 4, device=dev)).shape == (0, 4)
+    assert ops.quat_to_tan_norm(torch.zeros(0, 4, device=dev)).shape == (0, 6)
+
+
+def test_cpu_tensors_rejected():
+    with pytest.raises(ValueError):
+        ops.quat_mul(torch.zeros(2, 4), torch.zeros(2, 4))
+
+
+# ------------------------------------------------------------------ fused env step
+def _golden_env(g, dev):
+    rb = g.t("rb", dev)
+    rn = {k: g.t("ref_now_" + k, dev) for k in ("pos", "rot", "vel", "ang")}
+    rx = {k: g.t("ref_next_" + k, dev) for k in ("pos", "rot", "vel", "ang")}
+    return rb, rn, rx
+
+
+def _run_full(d, dev, **kw):
+    to = lambda x: x.to(dev)
+    return ops.im_step(to(d["rb"]), what=ALL, ref_now={k: to(v) for k, v in d["ref_now"].items()},
+                       ref_next={k: to(v) for k, v in d["ref_next"].items()}, dof_force=to(d["dof_force"]),
+                       dof_vel=to(d["dof_vel"]), progress=to(d["progress"]), pass_time=to(d["pass_time"]),
+                       track_ids=list(range(24)), reset_ids=syn.RESET_BODY_IDS,
+                       term_dist=torch.full((24,), 0.25, device=dev), **kw)
+
+
+def test_fused_step_vs_golden(golden, dev):
+    g = golden("env_im.npz")
+    rb, rn, rx = _golden_env(g, dev)
+    out = ops.im_step(rb, what=ALL, ref_now=rn, ref_next=rx, dof_force=g.t("dof_force", dev), dof_vel=g.t("dof_vel", dev),
+                      progress=g.t("progress", dev), pass_time=g.t("pass_time", dev), track_ids=list(range(24)),
+                      reset_ids=syn.RESET_BODY_IDS, term_dist=torch.full((24,), 0.25, device=dev))
+    assert out["obs"].shape == (67, 934)
+    close(out["obs"][:, :358], g.np("self_obs"))
+    close(out["obs"][:, 358:], g.np("task_obs_v6"))
+    close(out["rew"], g.np("reward"))
+    close(out["rew_raw"], g.np("reward_raw"))
+    assert np.array_equal(out["reset"].cpu().numpy(), g.np("reset"))          # int64, bit exact
+    assert np.array_equal(out["terminate"].cpu().numpy(), g.np("terminate"))
+    assert out["reset"].dtype == torch.int64
+
+
+def test_padded_pitch_and_zero_fill(golden, dev):
+    g = golden("env_im.npz")
+    rb, rn, rx = _golden_env(g, dev)
+    obs = torch.full((67, 1024), 7.0, device=dev)                             # pitch 1024, write 960 cols
+    ops.im_step(rb, what=PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, ref_next=rx, track_ids=list(range(24)), obs=obs, obs_cols=960)
+    close(obs[:, :358], g.np("self_obs"))
+    close(obs[:, 358:934], g.np("task_obs_v6"))
+    assert torch.equal(obs[:, 934:960].cpu(), torch.zeros(67, 26))            # pad zeroed (GEMM-ready)
+    assert torch.equal(obs[:, 960:].cpu(), torch.full((67, 64), 7.0))         # beyond obs_cols untouched
+
+
+def test_variants_vs_golden(golden, dev):
+    g = golden("env_im.npz")
+    rb, rn, rx = _golden_env(g, dev)
+    tb = syn.VR_TRACK_BODY_IDS
+    o7 = ops.im_step(rb, what=PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, ref_next=rx, track_ids=tb, obs_version=7)["obs"]
+    assert o7.shape == (67, 358 + 27)
+    close(o7[:, 358:], g.np("task_obs_v7_vr"))
+    o6 = ops.im_step(rb, what=PULSE_IM_TASK_OBS | PULSE_IM_SELF_OBS, ref_next=rx, track_ids=tb, obs_version=6, local_root_obs=False)["obs"]
+    close(o6[:, 358:], g.np("task_obs_v6_vr"))
+    close(o6[:, :358], g.np("self_obs_global_root"))
+    out = ops.im_step(rb, what=PULSE_IM_RESET, ref_now=rn, progress=g.t("progress", dev), pass_time=g.t("pass_time", dev),
+                      reset_ids=syn.RESET_BODY_IDS, term_dist=torch.full((24,), 0.25, device=dev), reset_use_mean=True)
+    assert np.array_equal(out["reset"].cpu().numpy(), g.np("reset_mean"))
+    assert np.array_equal(out["terminate"].cpu().numpy(), g.np("terminate_mean"))
+    out = ops.im_step(rb, what=PULSE_IM_REWARD, ref_now=rn, power_reward=False, progress=g.t("progress", dev))
+    close(out["rew"], g.np("reward_im"))
+    close(out["rew_raw"], g.np("reward_raw_im"))
+
+
+def test_reference_signature_wrappers(golden, dev):
+    """The drop-in functions keep the reference's names / argument order."""
+    g = golden("env_im.npz")
+    rb, rn, rx = _golden_env(g, dev)
+    bp, br, bv, ba = rb[..., 0:3], rb[..., 3:7], rb[..., 7:10], rb[..., 10:13]   # views, as humanoid.py:219-222
+    assert ops.pack_rb(bp, br, bv, ba).data_ptr() == rb.data_ptr()            # zero-copy path taken
+    close(ops.compute_humanoid_observations_smpl_max(bp, br, bv, ba, None, None, True, True, True, False, False), g.np("self_obs"))
+    close(ops.compute_imitation_observations_v6(bp[:, 0], br[:, 0], bp, br, bv, ba, rx["pos"], rx["rot"], rx["vel"], rx["ang"], 1, True),
+          g.np("task_obs_v6"))
+    tb = syn.VR_TRACK_BODY_IDS
+    close(ops.compute_imitation_observations_v7(bp[:, 0], br[:, 0], bp[:, tb], bv[:, tb], rx["pos"][:, tb], rx["vel"][:, tb], 1, True),
+          g.np("task_obs_v7_vr"))
+    specs = dict(E.DEFAULT_REWARD_SPECS)
+    rew, raw = ops.compute_imitation_reward(bp[:, 0], br[:, 0], bp, br, bv, ba, rn["pos"], rn["rot"], rn["vel"], rn["ang"], specs)
+    close(rew, g.np("reward_im"))
+    close(raw, g.np("reward_raw_im"))
+    rid = syn.RESET_BODY_IDS
+    reset, term = ops.compute_humanoid_im_reset(torch.zeros(67, dtype=torch.int64, device=dev), g.t("progress", dev), None, None,
+                                                bp[:, rid].clone(), rn["pos"][:, rid].clone(), g.t("pass_time", dev), True,
+                                                torch.full((1, 20), 0.25, device=dev), False, False)
+    assert np.array_equal(reset.cpu().numpy(), g.np("reset")) and np.array_equal(term.cpu().numpy(), g.np("terminate"))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 64, 130, 4096])
+def test_fused_step_vs_oracle_sizes(dev, n):
+    gsyn = syn.make_generator(1234 + n)
+    d = syn.env_step_inputs(gsyn, n)
+    out = _run_full(d, dev)
+    ref = E.post_physics(d["rb"], d["ref_now"], d["ref_next"], d["dof_force"], d["dof_vel"], d["progress"], d["pass_time"],
+                         syn.RESET_BODY_IDS, list(range(24)), torch.full((1, 24), 0.25))
+    close(out["obs"], ref["obs"])
+    close(out["rew"], ref["rew"])
+    close(out["rew_raw"], ref["raw"])
+    assert torch.equal(out["reset"].cpu(), ref["reset"]) and torch.equal(out["terminate"].cpu(), ref["terminate"])
+
+
+def test_env_ids_mask_and_indexing(dev):
+    """Partial recompute (reset path): only the selected rows change, row e holds env e (bit-exact indexing)."""
+    n = 257
+    d = syn.env_step_inputs(syn.make_generator(9), n)
+    full = _run_full(d, dev)
+    ids = torch.tensor([256, 0, 13, 77, 200], dtype=torch.int64, device=dev)
+    obs = torch.full((n, 934), -3.0, device=dev)
+    to = lambda x: x.to(dev)
+    ops.im_step(to(d["rb"]), what=PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, ref_next={k: to(v) for k, v in d["ref_next"].items()},
+                track_ids=list(range(24)), env_ids=ids, obs=obs)
+    sel = torch.zeros(n, dtype=torch.bool)
+    sel[ids.cpu()] = True
+    assert torch.equal(obs[sel.to(dev)], full["obs"][sel.to(dev)])             # same kernel, same bits
+    assert torch.equal(obs[~sel.to(dev)].cpu(), torch.full((n - 5, 934), -3.0))
+    mask = (torch.arange(n) % 3 == 0)
+    obs2 = torch.full((n, 934), -3.0, device=dev)
+    ops.im_step(to(d["rb"]), what=PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, ref_next={k: to(v) for k, v in d["ref_next"].items()},
+                track_ids=list(range(24)), env_mask=mask.to(dev), obs=obs2)
+    assert torch.equal(obs2[mask.to(dev)], full["obs"][mask.to(dev)])
+    assert torch.equal(obs2[~mask.to(dev)].cpu(), torch.full((int((~mask).sum()), 934), -3.0))
+    # env stride larger than J*13 (Isaac buffers with extra bodies per env)
+    wide = torch.zeros(n, 30, 13, device=dev)
+    wide[:, :24] = to(d["rb"])
+    o3 = ops.im_step(wide[:, :24], what=PULSE_IM_SELF_OBS)["obs"]
+    assert torch.equal(o3, full["obs"][:, :358])
+
+
+def test_future_tracks(dev):
+    """time_steps = 3 (fut_tracks): per-sample blocks, env-major / time-minor reference rows."""
+    n, T = 19, 3
+    g = syn.make_generator(31)
+    rb = syn.rigid_body_state(g, n)
+    frames = [syn.reference_frame(g, rb) for _ in range(T)]
+    rx = {k: torch.stack([f[k] for f in frames], dim=1).reshape(n * T, 24, -1).contiguous() for k in ("pos", "rot", "vel", "ang")}
+    bp, br, bv, ba = E.split_rb(rb)
+    ref = E.im_obs_v6(bp[:, 0], br[:, 0], bp, br, bv, ba, rx["pos"], rx["rot"], rx["vel"], rx["ang"], T)
+    out = ops.im_step(rb.to(dev), what=PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, ref_next={k: v.to(dev) for k, v in rx.items()},
+                      time_steps=T, track_ids=list(range(24)))["obs"]
+    assert out.shape == (n, 358 + 3 * 576)
+    close(out[:, 358:], ref)
+
+
+def test_recovery_mask_and_empty(dev):
+    n = 40
+    d = syn.env_step_inputs(syn.make_generator(77), n)
+    d["ref_now"]["pos"][:, 13] += 1.0                      # everybody falls
+    cyc = torch.zeros(n, dtype=torch.int64)
+    cyc[::2] = 5
+    out = _run_full(d, dev, cycle_counter=cyc.to(dev))
+    ref = E.post_physics(d["rb"], d["ref_now"], d["ref_next"], d["dof_force"], d["dof_vel"], d["progress"], d["pass_time"],
+                         syn.RESET_BODY_IDS, list(range(24)), torch.full((1, 24), 0.25), cycle_counter=cyc)
+    assert torch.equal(out["reset"].cpu(), ref["reset"]) and torch.equal(out["terminate"].cpu(), ref["terminate"])
+    assert ref["terminate"].sum() > 0
+    e = ops.im_step(torch.zeros(0, 24, 13, device=dev), what=PULSE_IM_SELF_OBS)
+    assert e["obs"].shape == (0, 358)
+
+
+# ------------------------------------------------------------------ GAE
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_gae_vs_golden(golden, dev, tag):
+    g = golden("agent_math.npz")
+    r, v, nv, d = (g.t(f"gae_{tag}_{k}", dev) for k in ("rewards", "values", "next_values", "dones"))
+    adv, ret = ops.discount_values(d, v, r, nv, 0.99, 0.95, return_returns=True)
+    close(adv, g.np(f"gae_{tag}_advs"))
+    close(ret, g.np(f"gae_{tag}_advs") + g.np(f"gae_{tag}_values"))
+    # float dones as the reference passes them
+    close(ops.discount_values(d.float(), v, r, nv, 0.99, 0.95), g.np(f"gae_{tag}_advs"))
+
+
+def test_gae_env_major_layout_and_properties(dev):
+    t, n = 32, 4096
+    r, v, nv, d = syn.rollout_scalars(syn.make_generator(3), t, n)
+    ref = E.gae(d.float(), v, r, nv, 0.99, 0.95)
+    # env-major physical storage viewed time-major (this framework's experience buffer)
+    em = lambda x: x.to(dev).transpose(0, 1).contiguous().transpose(0, 1)
+    adv = ops.discount_values(em(d), em(v), em(r), em(nv), 0.99, 0.95)
+    assert adv.stride() == em(r).stride()
+    close(adv, ref)
+    # linearity in (rewards, values, next_values): GAE(2x) == 2 GAE(x)
+    adv2 = ops.discount_values(em(d), em(2 * v), em(2 * r), em(2 * nv), 0.99, 0.95)
+    close(adv2, 2 * ref, atol=2e-5)
+    # all-done: advantage collapses to the one-step delta
+    ones = torch.ones(t, n, dtype=torch.uint8, device=dev)
+    adv3 = ops.discount_values(ones, v.to(dev), r.to(dev), nv.to(dev), 0.99, 0.95)
+    close(adv3, r + 0.99 * nv - v)

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 1
+#define PULSE_ABI_VERSION 2
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -163,6 +163,118 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s);
 int pulse_gae(const float* rewards, const float* values, const float* next_values, const uint8_t* dones,
               int32_t horizon, int32_t num_envs, int64_t stride_t, int64_t stride_n,
               float gamma, float gamma_tau, float* advs, float* returns, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
+ * 4. FP32 MFMA GEMM with fused epilogues: every nn.Linear forward / backward of
+ *    the actor, critic and VAE MLPs (phc/learning/network_builder.py:105-124,245-261;
+ *    amp_network_builder.py:127-148,206-211; amp_network_z_builder.py:469-580).
+ *    C[m][n] = sum_k A(m,k) * B(n,k), v_mfma_f32_32x32x2_f32 (exact fp32).
+ * ------------------------------------------------------------------------- */
+#define PULSE_GEMM_RED_CONTIG 0 /* operand stored [out][k]: reduction index contiguous */
+#define PULSE_GEMM_OUT_CONTIG 1 /* operand stored [k][out]: output index contiguous   */
+#define PULSE_ACT_NONE 0
+#define PULSE_ACT_RELU 1
+#define PULSE_ACT_SILU 2
+#define PULSE_EPI_BIAS_ACT  0 /* C = act(acc + bias[n]); silu may also store the pre-activation in C2 */
+#define PULSE_EPI_RELU_GRAD 1 /* C = acc * (aux > 0)           (aux = forward activation)  */
+#define PULSE_EPI_SILU_GRAD 2 /* C = acc * silu'(aux)          (aux = forward pre-activation) */
+
+typedef struct pulse_gemm_desc {
+    const float* A; const float* B; float* C;
+    float* C2;            /* optional second output (pre-activation), EPI_BIAS_ACT + SILU */
+    const float* bias;    /* optional (N) */
+    const float* aux;     /* gradient epilogues: (M, N) with pitch ldaux */
+    int32_t M, N, K;      /* output M x N, reduction K */
+    int32_t lda, ldb, ldc, ldc2, ldaux; /* pitches in floats; lda/ldb multiples of 4 */
+    int32_t a_layout, b_layout;         /* PULSE_GEMM_*_CONTIG; (OUT, RED) is unsupported */
+    int32_t batch;        /* independent problems; operand z uses pointer + z * stride_* */
+    int64_t stride_a, stride_b, stride_c, stride_c2, stride_bias, stride_aux;
+    int32_t split_k;      /* >1: slab s of the reduction goes to C + s*split_stride (no epilogue) */
+    int64_t split_stride;
+    int32_t activation;   /* PULSE_ACT_* */
+    int32_t epilogue;     /* PULSE_EPI_* */
+} pulse_gemm_desc;
+
+int pulse_sizeof_gemm_desc(void);
+int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
+/* out[i] = scale * sum_s slabs[s*slab_stride + i]  (deterministic split-K / partial-sum reduction) */
+int pulse_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count, float* out,
+                       float scale, pulse_stream_t s);
+/* partial[c*ld_partial + n] = sum of rows of chunk c of x (m x n, pitch ld): bias-gradient partials */
+int pulse_colsum_partial(const float* x, int32_t m, int32_t n, int32_t ld, int32_t num_chunks, float* partial,
+                         int64_t ld_partial, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
+ * 5. Learner-side elementwise / reduction kernels (PPO update).
+ * ------------------------------------------------------------------------- */
+/* RunningMeanStd.forward, phc/utils/running_mean_std.py:69-109.
+ *   mode 0: y = clamp((x - mean) / sqrt(var + eps), -clip, clip);  mode 1 (unnorm): y = sqrt(var+eps)*clamp(x)+mean.
+ *   x rows may be gathered: row i of y comes from x row row_idx[i] (NULL = identity) -- this is the
+ *   AMPDataset minibatch gather (phc/learning/amp_datasets.py:81-94) fused with the normaliser.
+ *   Columns [cols, y_cols) of y are zero-filled (GEMM-ready pitch).  If moment_partials != NULL the
+ *   per-column batch sums / sums of squares (fp64) of the RAW rows are written to
+ *   moment_partials[block][2][cols] for pulse_rms_update (the "update after normalise" of :98-107).
+ *   mean / var are the module's fp64 buffers. */
+int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols,
+                        const double* mean, const double* var, float eps, float clip, int32_t mode,
+                        float* y, int64_t y_stride, int32_t y_cols,
+                        double* moment_partials, int32_t num_blocks, pulse_stream_t s);
+/* _update_mean_var_count_from_moments, running_mean_std.py:56-67 (unbiased batch variance).
+ * count_old is tracked by the host (it only ever grows by the batch size). */
+int pulse_rms_update(double* mean, double* var, double* count_out, const double* moment_partials, int32_t num_blocks,
+                     int32_t cols, double count_old, double batch_count, pulse_stream_t s);
+
+/* rl_games ModelA2CContinuousLogStd eval branch (3P) + value un-normalisation
+ * (phc/learning/common_agent.py:262-288): action = mu + exp(logstd)*noise, neglogp, sigma rows,
+ * value = sqrt(var+eps)*clamp(value_raw,+-5)+mean.  Row pitches are explicit so outputs land directly in
+ * the experience buffer slot. */
+int pulse_policy_sample(const float* mu, int64_t mu_stride, const float* logstd, const float* noise, int64_t noise_stride,
+                        const float* value_raw, int64_t value_stride, const double* value_mean, const double* value_var,
+                        int32_t rows, int32_t num_actions, float* actions, int64_t actions_stride, float* sigmas,
+                        int64_t sigmas_stride, float* neglogp, int64_t neglogp_stride, float* values, int64_t values_out_stride,
+                        pulse_stream_t s);
+
+typedef struct pulse_ppo_loss_args {
+    /* network outputs for the minibatch (row i) */
+    const float* mu; int64_t mu_stride;
+    const float* value; int64_t value_stride;
+    const float* logstd;               /* (A) */
+    /* dataset tensors, row idx[i] (NULL idx = identity): AMPDataset._get_item gather fused in */
+    const int64_t* idx;
+    const float* actions; int64_t actions_stride;
+    const float* old_mu; int64_t old_mu_stride;
+    const float* old_logstd;           /* (A): old sigma is the same state-independent parameter */
+    const float* old_neglogp;          /* (B) */
+    const float* advantages;           /* (B) */
+    const float* old_values;           /* (B) */
+    const float* returns;              /* (B) */
+    int32_t rows, num_actions;
+    float e_clip, critic_coef, bounds_loss_coef; int32_t clip_value; int32_t has_bounds_loss;
+    /* outputs */
+    float* dmu; int64_t dmu_stride;    /* d loss / d mu      (rows, A) */
+    float* dvalue; int64_t dvalue_stride; /* d loss / d value (rows) */
+    float* partials;                   /* (num_blocks, 8): sums of a_loss, c_loss, b_loss, clipped, kl, 0,0,0 */
+    int32_t num_blocks;
+} pulse_ppo_loss_args;
+/* CommonAgent.calc_gradients loss section + analytic gradients w.r.t. the network outputs:
+ * _actor_loss / _critic_loss / bound_loss (phc/learning/common_agent.py:512-520,564-587),
+ * neglogp + policy_kl (rl_games 3P).  loss = a + critic_coef*c + bounds_coef*b (entropy term is constant). */
+int pulse_sizeof_ppo_loss_args(void);
+int pulse_ppo_loss(const pulse_ppo_loss_args* args, pulse_stream_t s);
+
+/* _calc_advs, common_agent.py:589-599: adv = returns - values; (adv - mean)/(std_unbiased + 1e-8). Two launches. */
+int pulse_advantage_moments(const float* returns, const float* values, int64_t count, float* adv, double* partials,
+                            int32_t num_blocks, pulse_stream_t s);
+int pulse_advantage_normalize(float* adv, int64_t count, const double* partials, int32_t num_blocks, pulse_stream_t s);
+
+/* nn.utils.clip_grad_norm_ + torch.optim.Adam.step fused over a flat parameter buffer
+ * (common_agent.py:472-478; Adam(eps=1e-8) :66).  sqnorm_partials: per-block sums of squares of the
+ * gradient (from pulse_sqnorm_partial); clip coefficient = min(1, max_norm / (norm + 1e-6)); max_norm <= 0
+ * disables clipping.  step is the 1-based Adam step count. */
+int pulse_sqnorm_partial(const float* x, int64_t count, float* partials, int32_t num_blocks, pulse_stream_t s);
+int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                    const float* sqnorm_partials, int32_t num_partials, float* grad_norm_out, pulse_stream_t s);
 
 #ifdef __cplusplus
 }

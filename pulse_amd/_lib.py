@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -47,7 +47,36 @@ class ImStepArgs(Structure):
     ]
 
 
+class GemmDesc(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p), ("aux", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldc2", c_int32), ("ldaux", c_int32),
+        ("a_layout", c_int32), ("b_layout", c_int32), ("batch", c_int32),
+        ("stride_a", c_int64), ("stride_b", c_int64), ("stride_c", c_int64), ("stride_c2", c_int64),
+        ("stride_bias", c_int64), ("stride_aux", c_int64),
+        ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
+    ]
+
+
+class PpoLossArgs(Structure):
+    _fields_ = [
+        ("mu", c_void_p), ("mu_stride", c_int64), ("value", c_void_p), ("value_stride", c_int64), ("logstd", c_void_p),
+        ("idx", c_void_p), ("actions", c_void_p), ("actions_stride", c_int64), ("old_mu", c_void_p), ("old_mu_stride", c_int64),
+        ("old_logstd", c_void_p), ("old_neglogp", c_void_p), ("advantages", c_void_p), ("old_values", c_void_p), ("returns", c_void_p),
+        ("rows", c_int32), ("num_actions", c_int32),
+        ("e_clip", c_float), ("critic_coef", c_float), ("bounds_loss_coef", c_float), ("clip_value", c_int32), ("has_bounds_loss", c_int32),
+        ("dmu", c_void_p), ("dmu_stride", c_int64), ("dvalue", c_void_p), ("dvalue_stride", c_int64),
+        ("partials", c_void_p), ("num_blocks", c_int32),
+    ]
+
+
+GEMM_RED_CONTIG, GEMM_OUT_CONTIG = 0, 1
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD = 0, 1, 2
+
 P = c_void_p  # every device pointer crosses the ABI as void*
+c_double = ctypes.c_double
 
 # name -> (restype, argtypes); must list EVERY symbol of include/pulse_hip.h
 SIGNATURES = {
@@ -68,6 +97,19 @@ SIGNATURES = {
     "pulse_task_obs_width": (c_int, [c_int, c_int, c_int]),
     "pulse_im_step": (c_int, [POINTER(ImStepArgs), P]),
     "pulse_gae": (c_int, [P, P, P, P, c_int32, c_int32, c_int64, c_int64, c_float, c_float, P, P, P]),
+    "pulse_sizeof_gemm_desc": (c_int, []),
+    "pulse_gemm_f32": (c_int, [POINTER(GemmDesc), P]),
+    "pulse_reduce_slabs": (c_int, [P, c_int32, c_int64, c_int64, P, c_float, P]),
+    "pulse_colsum_partial": (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, c_int64, P]),
+    "pulse_rms_normalize": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, c_int32, P, c_int64, c_int32, P, c_int32, P]),
+    "pulse_rms_update": (c_int, [P, P, P, P, c_int32, c_int32, c_double, c_double, P]),
+    "pulse_policy_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int32, c_int32, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
+    "pulse_sizeof_ppo_loss_args": (c_int, []),
+    "pulse_ppo_loss": (c_int, [POINTER(PpoLossArgs), P]),
+    "pulse_advantage_moments": (c_int, [P, P, c_int64, P, P, c_int32, P]),
+    "pulse_advantage_normalize": (c_int, [P, c_int64, P, c_int32, P]),
+    "pulse_sqnorm_partial": (c_int, [P, c_int64, P, c_int32, P]),
+    "pulse_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_float, P, c_int32, P, P]),
 }
 
 _lib = None

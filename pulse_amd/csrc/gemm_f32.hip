@@ -1,0 +1,344 @@
+// FP32 MFMA GEMM for the actor / critic / VAE MLPs (forward, dX and dW passes) on gfx950.
+//
+// Replaces every nn.Linear call (+ its autograd backward) on the PPO update path:
+//   phc/learning/network_builder.py:105-124,245-261 (actor_mlp / critic_mlp / mu / value),
+//   phc/learning/amp_network_builder.py:127-148,206-211 (eval_actor / eval_critic),
+//   phc/learning/amp_network_z_builder.py:469-580 (PULSE VAE encoder / prior / decoder MLPs).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 inputs, f32 accumulate, bit-identical to an fmaf chain,
+// 64 FLOP/clk/SIMD (157 TFLOP/s chip peak; gfx950 has no TF32/xf32 path).  The reference trains in
+// fp32 (mixed_precision: False, learning/im.yaml:50), so fp32 is kept end to end.
+//
+// One kernel, three operand-layout instantiations, C[m][n] = sum_k A(m,k) * B(n,k):
+//   <KC,KC>  forward   Y = X W^T      X [M][K],  W [N][K]      (both reduction-contiguous)
+//   <KC,MC>  dX        dX = dY W      dY [M][N], W [N][K]      (B stored [red][out])
+//   <MC,MC>  dW        dW = dY^T X    dY [M][N], X [M][K]      (both stored [red][out], split-K over M)
+// Tiling: 128x128x32 block tile, 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32 (64 accumulator
+// VGPRs).  Operands are staged global -> registers -> LDS with 16-byte loads, double-buffered in LDS
+// (one barrier per k-tile, next tile's global loads in flight during the 64 MFMAs of the current one).
+// LDS images: reduction-contiguous operands as [out][k] with a 36-float pitch (conflict-free
+// ds_read_b128: 16-lane groups land on 16 distinct 16-byte slots); [red][out] operands as [k][out]
+// read with ds_read_b32 (32 consecutive floats per half-wave).  Because k is a pure reduction index
+// the two wave halves take k-offsets {0..3} and {4..7} of every 8-k step, for A and B alike, which is
+// what lets a single ds_read_b128 feed four consecutive MFMAs.
+// 256 CUs / 8 XCDs: the 1-D grid is remapped so each XCD owns a contiguous band of m-tiles (A panels
+// stay in that XCD's L2; the small weight matrix is shared by all).
+#include "common.h"
+
+namespace pulse {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int PITCH_KC = BK + 4;    // [out][k] image
+constexpr int PITCH_MC = BM + 4;    // [k][out] image
+constexpr int TILE_FLOATS = BM * PITCH_KC;  // 4608 >= BK * PITCH_MC (4224)
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux;
+    int M, N, K;
+    int lda, ldb, ldc, ldc2, ldaux;
+    long long sA, sB, sC, sC2, sBias, sAux;   // batch strides (floats)
+    int batch, splitk, kchunk;
+    long long sSplit;                          // C slab stride per k-split (floats)
+    int act;                                   // 0 none, 1 relu, 2 silu (EPI 0 only)
+    int epi;                                   // 0 bias+act, 1 relu-grad mask, 2 silu-grad
+    int tiles_m, tiles_n;
+};
+
+// ---- global -> register staging -------------------------------------------------------------
+template <bool KC>
+__device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ P, int ld, int out0, int ext,
+                                          int k0, int kend, int tid) {
+    if constexpr (KC) {
+        const int kq = (tid & 7) * 4;
+        const int k = k0 + kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = out0 + (tid >> 3) + 32 * i;
+            row = row < ext ? row : ext - 1;              // clamp: rows beyond the extent are never stored
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend) {
+                v = *reinterpret_cast<const float4*>(P + (long long)row * ld + k);
+                if (k + 3 >= kend) {                       // reduction tail: zero the lanes past K
+                    if (k + 1 >= kend) v.y = 0.f;
+                    if (k + 2 >= kend) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            r[i] = v;
+        }
+    } else {
+        const int m = out0 + (tid & 31) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (tid >> 5) + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend && m < ext) v = *reinterpret_cast<const float4*>(P + (long long)k * ld + m);
+            r[i] = v;
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int tid) {
+    if constexpr (KC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * PITCH_KC + (tid & 7) * 4) = r[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * PITCH_MC + (tid & 31) * 4) = r[i];
+    }
+}
+
+// fragment for one 32-wide tile: the 4 k-values this lane feeds to 4 consecutive MFMAs
+template <bool KC>
+__device__ __forceinline__ float4 load_frag(const float* __restrict__ s, int out_in_tile, int kk, int half) {
+    if constexpr (KC) {
+        return *reinterpret_cast<const float4*>(s + out_in_tile * PITCH_KC + kk + 4 * half);
+    } else {
+        const float* p = s + (kk + 4 * half) * PITCH_MC + out_in_tile;
+        return make_float4(p[0], p[PITCH_MC], p[2 * PITCH_MC], p[3 * PITCH_MC]);
+    }
+}
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // stage s: A image at smem + s*2*TILE_FLOATS, B image right after it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    // XCD-aware bijective remap: block b runs on XCD b % 8; give each XCD a contiguous range of tiles
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = ntile >> 3, rr = ntile & 7;
+    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.y;
+    const int bz = z / g.splitk, sp = z - bz * g.splitk;
+    const int kbeg = sp * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    const float* A = g.A + bz * g.sA;
+    const float* B = g.B + bz * g.sB;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    if (nkt > 0) {
+        load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
+        load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
+        store_tile<AKC>(smem, ra, tid);
+        store_tile<BKC>(smem + TILE_FLOATS, rb, tid);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nkt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nkt) {
+            load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg + (t + 1) * BK, kend, tid);
+            load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kend, tid);
+        }
+        const float* a_s = smem + cur * 2 * TILE_FLOATS;
+        const float* b_s = a_s + TILE_FLOATS;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            float4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = load_frag<AKC>(a_s, wm * 64 + i * 32 + l31, kk, half);
+                fb[i] = load_frag<BKC>(b_s, wn * 64 + i * 32 + l31, kk, half);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nkt) {
+            store_tile<AKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS, ra, tid);
+            store_tile<BKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS + TILE_FLOATS, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* C = g.C + bz * g.sC + sp * g.sSplit;
+    float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
+    const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
+    const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                if (g.epi == 0) {
+                    v += bv;
+                    if (g.act == 1) {
+                        v = fmaxf(v, 0.f);
+                    } else if (g.act == 2) {
+                        if (C2) C2[(long long)row * g.ldc2 + col] = v;   // keep the pre-activation for backward
+                        v = v / (1.f + __expf(-v));
+                    }
+                } else if (g.epi == 1) {
+                    v = aux[(long long)row * g.ldaux + col] > 0.f ? v : 0.f;
+                } else {
+                    const float zz = aux[(long long)row * g.ldaux + col];
+                    const float sg = 1.f / (1.f + __expf(-zz));
+                    v *= sg * (1.f + zz * (1.f - sg));
+                }
+                C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---- deterministic reduction of split-K slabs (and of column-sum partials) ---------------------
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
+                                                          long long count, float* __restrict__ out, float scale) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < count; i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < count) {
+            float4 s = *reinterpret_cast<const float4*>(slabs + i);
+            for (int k = 1; k < nslab; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(slabs + k * slab_stride + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+            *reinterpret_cast<float4*>(out + i) = s;
+        } else {
+            for (long long e = i; e < count; ++e) {
+                float s = slabs[e];
+                for (int k = 1; k < nslab; ++k) s += slabs[k * slab_stride + e];
+                out[e] = s * scale;
+            }
+        }
+    }
+}
+
+// ---- column sums (bias gradients): partial[chunk][n] = sum over the chunk's rows of X[m][n] ------
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ X, int M, int N, int ld, int rows_per_chunk,
+                                                            float* __restrict__ partial, long long ldp) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(M, r0 + rows_per_chunk);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + rl; r < r1; r += 4) s += X[(long long)r * ld + c];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) partial[(long long)blockIdx.y * ldp + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+}  // namespace pulse
+
+using namespace pulse;
+
+extern "C" {
+
+int pulse_sizeof_gemm_desc(void) { return (int)sizeof(pulse_gemm_desc); }
+
+int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
+    PULSE_REQUIRE(d != nullptr, "pulse_gemm_f32: null descriptor");
+    PULSE_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "pulse_gemm_f32: negative size");
+    if (d->M == 0 || d->N == 0 || d->batch == 0) return PULSE_OK;
+    PULSE_REQUIRE(d->A && d->B && d->C, "pulse_gemm_f32: null operand");
+    PULSE_REQUIRE(d->batch >= 1 && d->split_k >= 1, "pulse_gemm_f32: batch / split_k must be >= 1");
+    PULSE_REQUIRE((d->lda % 4) == 0 && (d->ldb % 4) == 0, "pulse_gemm_f32: lda / ldb must be multiples of 4 floats");
+    PULSE_REQUIRE((reinterpret_cast<uintptr_t>(d->A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->B) & 15) == 0,
+                  "pulse_gemm_f32: A / B must be 16-byte aligned");
+    PULSE_REQUIRE((d->stride_a % 4) == 0 && (d->stride_b % 4) == 0, "pulse_gemm_f32: batch strides must be multiples of 4 floats");
+    const bool akc = d->a_layout == PULSE_GEMM_RED_CONTIG, bkc = d->b_layout == PULSE_GEMM_RED_CONTIG;
+    PULSE_REQUIRE(!(!akc && bkc), "pulse_gemm_f32: layout combination (A out-contiguous, B reduction-contiguous) unsupported");
+    // pitches must cover the float4 reads: reduction-contiguous rows up to roundup4(K), others up to roundup4(extent)
+    const int k4 = (d->K + 3) & ~3;
+    PULSE_REQUIRE(akc ? d->lda >= k4 : d->lda >= ((d->M + 3) & ~3), "pulse_gemm_f32: lda too small");
+    PULSE_REQUIRE(bkc ? d->ldb >= k4 : d->ldb >= ((d->N + 3) & ~3), "pulse_gemm_f32: ldb too small");
+    PULSE_REQUIRE(d->ldc >= d->N, "pulse_gemm_f32: ldc too small");
+    PULSE_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2 && d->activation >= 0 && d->activation <= 2, "pulse_gemm_f32: bad epilogue / activation");
+    PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr, "pulse_gemm_f32: gradient epilogue needs aux");
+    PULSE_REQUIRE(d->split_k == 1 || (d->epilogue == 0 && d->activation == 0 && d->bias == nullptr),
+                  "pulse_gemm_f32: split-K slabs carry no epilogue");
+
+    GemmArgs g;
+    g.A = d->A; g.B = d->B; g.C = d->C; g.C2 = d->C2; g.bias = d->bias; g.aux = d->aux;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldc2 = d->ldc2; g.ldaux = d->ldaux;
+    g.sA = d->stride_a; g.sB = d->stride_b; g.sC = d->stride_c; g.sC2 = d->stride_c2; g.sBias = d->stride_bias; g.sAux = d->stride_aux;
+    g.batch = d->batch; g.splitk = d->split_k;
+    int kchunk = (d->K + d->split_k - 1) / d->split_k;
+    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    g.kchunk = kchunk > 0 ? kchunk : BK;
+    g.sSplit = d->split_stride;
+    g.act = d->activation; g.epi = d->epilogue;
+    g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
+    const size_t lds = sizeof(float) * 4 * TILE_FLOATS;   // 73,728 B -> two workgroups per CU
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
+    hipError_t e;
+#define LAUNCH(AK, BK_)                                                                                          \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BK_>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_f32: LDS attribute: %s", hipGetErrorString(e)); \
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
+    if (akc && bkc) { LAUNCH(true, true); }
+    else if (akc && !bkc) { LAUNCH(true, false); }
+    else { LAUNCH(false, false); }
+#undef LAUNCH
+    return check_launch("pulse_gemm_f32");
+}
+
+int pulse_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count, float* out, float scale,
+                       pulse_stream_t s) {
+    PULSE_REQUIRE(num_slabs >= 1 && count >= 0, "pulse_reduce_slabs: bad sizes");
+    if (count == 0) return PULSE_OK;
+    PULSE_REQUIRE(slabs && out, "pulse_reduce_slabs: null pointer");
+    PULSE_REQUIRE((slab_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                  "pulse_reduce_slabs: 16-byte alignment required");
+    long long blocks = (count / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), slabs, num_slabs, slab_stride, count, out, scale);
+    return check_launch("pulse_reduce_slabs");
+}
+
+int pulse_colsum_partial(const float* x, int32_t m, int32_t n, int32_t ld, int32_t num_chunks, float* partial, int64_t ld_partial,
+                         pulse_stream_t s) {
+    PULSE_REQUIRE(m >= 0 && n >= 0 && num_chunks >= 1, "pulse_colsum_partial: bad sizes");
+    if (n == 0) return PULSE_OK;
+    PULSE_REQUIRE(x && partial && ld >= n && ld_partial >= n, "pulse_colsum_partial: bad pointers / pitches");
+    const int rows = (m + num_chunks - 1) / num_chunks;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)num_chunks), dim3(256), 0, as_stream(s), x, m, n, ld,
+                       rows > 0 ? rows : 1, partial, (long long)ld_partial);
+    return check_launch("pulse_colsum_partial");
+}
+}

@@ -1,0 +1,481 @@
+// Learner-side elementwise / reduction kernels of the PPO update on gfx950 (all HBM- or latency-bound).
+//
+//   rms_normalize / rms_update   RunningMeanStd.forward, phc/utils/running_mean_std.py:56-109, fused with the
+//                                AMPDataset minibatch row gather (phc/learning/amp_datasets.py:81-94)
+//   policy_sample                rl_games ModelA2CContinuousLogStd eval branch + value un-normalise
+//                                (phc/learning/common_agent.py:262-288)
+//   ppo_loss                     _actor_loss/_critic_loss/bound_loss + neglogp + policy_kl and their analytic
+//                                gradients (phc/learning/common_agent.py:400-491,512-520,564-587)
+//   advantage_moments/normalize  _calc_advs (phc/learning/common_agent.py:589-599)
+//   sqnorm_partial / adam_step   clip_grad_norm_ + Adam.step over one flat parameter buffer (:472-478, :66)
+//
+// Statistics are accumulated in fp64 (the reference keeps fp64 running buffers; fp64 partials make the
+// batch moments independent of the block decomposition to ~1e-16).  Compiled with -ffp-contract=off.
+#include "common.h"
+
+namespace pulse {
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RunningMeanStd: wide matrices (cols >= 64): threads own columns, blocks own row chunks.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRmsMaxColsPerThread = 8;  // 256 threads x 8 = 2048 columns (AMP obs is 1960)
+
+__global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __restrict__ x, long long x_stride,
+                                                                const long long* __restrict__ row_idx, int rows, int cols,
+                                                                const double* __restrict__ mean, const double* __restrict__ var,
+                                                                float eps, float clip, int mode, float* __restrict__ y,
+                                                                long long y_stride, int y_cols, double* __restrict__ partials) {
+    const int tid = threadIdx.x;
+    const int nblk = gridDim.x;
+    const int per = (rows + nblk - 1) / nblk;
+    const int r0 = blockIdx.x * per;
+    const int r1 = min(rows, r0 + per);
+    float mu[kRmsMaxColsPerThread], den[kRmsMaxColsPerThread];
+    double s1[kRmsMaxColsPerThread], s2[kRmsMaxColsPerThread];
+#pragma unroll
+    for (int j = 0; j < kRmsMaxColsPerThread; ++j) {
+        const int c = tid + 256 * j;
+        s1[j] = 0.0; s2[j] = 0.0;
+        if (c < cols) {
+            mu[j] = (float)mean[c];
+            den[j] = sqrtf((float)var[c] + eps);
+        } else { mu[j] = 0.f; den[j] = 1.f; }
+    }
+    for (int r = r0; r < r1; ++r) {
+        const long long src = row_idx ? row_idx[r] : (long long)r;
+        const float* xr = x + src * x_stride;
+        float* yr = y + (long long)r * y_stride;
+#pragma unroll
+        for (int j = 0; j < kRmsMaxColsPerThread; ++j) {
+            const int c = tid + 256 * j;
+            if (c < cols) {
+                const float v = xr[c];
+                s1[j] += (double)v; s2[j] += (double)v * (double)v;
+                float o;
+                if (mode == 0) o = clampf((v - mu[j]) / den[j], -clip, clip);
+                else o = den[j] * clampf(v, -clip, clip) + mu[j];
+                yr[c] = o;
+            } else if (c < y_cols) {
+                yr[c] = 0.f;
+            }
+        }
+    }
+    if (partials) {
+        double* p = partials + (long long)blockIdx.x * 2 * cols;
+#pragma unroll
+        for (int j = 0; j < kRmsMaxColsPerThread; ++j) {
+            const int c = tid + 256 * j;
+            if (c < cols) { p[c] = s1[j]; p[cols + c] = s2[j]; }
+        }
+    }
+}
+
+// narrow matrices (cols < 64, e.g. the (B,1) value tensor): threads own rows.
+__global__ void __launch_bounds__(256) rms_normalize_narrow_kernel(const float* __restrict__ x, long long x_stride,
+                                                                  const long long* __restrict__ row_idx, int rows, int cols,
+                                                                  const double* __restrict__ mean, const double* __restrict__ var,
+                                                                  float eps, float clip, int mode, float* __restrict__ y,
+                                                                  long long y_stride, int y_cols, double* __restrict__ partials) {
+    __shared__ double red[2][4];
+    const int nblk = gridDim.x;
+    const int per = (rows + nblk - 1) / nblk;
+    const int r0 = blockIdx.x * per;
+    const int r1 = min(rows, r0 + per);
+    for (int c = 0; c < cols; ++c) {
+        const float mu = (float)mean[c];
+        const float den = sqrtf((float)var[c] + eps);
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+            const long long src = row_idx ? row_idx[r] : (long long)r;
+            const float v = x[src * x_stride + c];
+            s1 += (double)v; s2 += (double)v * (double)v;
+            float o;
+            if (mode == 0) o = clampf((v - mu) / den, -clip, clip);
+            else o = den * clampf(v, -clip, clip) + mu;
+            y[(long long)r * y_stride + c] = o;
+        }
+        if (partials) {
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double* p = partials + (long long)blockIdx.x * 2 * cols;
+                p[c] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+                p[cols + c] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = r0 + threadIdx.x; r < r1; r += 256)
+        for (int c = cols; c < y_cols; ++c) y[(long long)r * y_stride + c] = 0.f;
+}
+
+__global__ void __launch_bounds__(64) rms_update_kernel(double* __restrict__ mean, double* __restrict__ var, double* __restrict__ count_out,
+                                                       const double* __restrict__ partials, int nblk, int cols, double count,
+                                                       double n) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < cols) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s1 += partials[(long long)b * 2 * cols + c];
+            s2 += partials[(long long)b * 2 * cols + cols + c];
+        }
+        const double bm = s1 / n;
+        // unbiased variance like torch.var: sum (x - mean)^2 / (n - 1)
+        double bv = (s2 - n * bm * bm) / (n - 1.0);
+        if (bv < 0.0) bv = 0.0;
+        const double m = mean[c], v = var[c];
+        const double delta = bm - m;
+        const double tot = count + n;
+        const double new_mean = m + delta * n / tot;
+        const double m2 = v * count + bv * n + delta * delta * count * n / tot;
+        mean[c] = new_mean;
+        var[c] = m2 / tot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count_out) *count_out = count + n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gaussian policy head, rollout (eval) branch.  16 lanes per sample.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLanesPerSample = 16;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // 0.5 * ln(2 pi)
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, kLanesPerSample);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) policy_sample_kernel(const float* __restrict__ mu, long long mu_stride, const float* __restrict__ logstd,
+                                                           const float* __restrict__ noise, long long noise_stride,
+                                                           const float* __restrict__ value_raw, long long value_stride,
+                                                           const double* __restrict__ vmean, const double* __restrict__ vvar, int rows,
+                                                           int A, float* __restrict__ actions, long long actions_stride,
+                                                           float* __restrict__ sigmas, long long sigmas_stride, float* __restrict__ neglogp,
+                                                           long long neglogp_stride, float* __restrict__ values, long long values_stride) {
+    const int g = (blockIdx.x * 256 + threadIdx.x) / kLanesPerSample;
+    const int l = threadIdx.x % kLanesPerSample;
+    if (g >= rows) return;
+    float quad = 0.f, lsum = 0.f;
+    for (int j = l; j < A; j += kLanesPerSample) {
+        const float ls = logstd[j];
+        const float sg = expf(ls);
+        const float m = mu[(long long)g * mu_stride + j];
+        const float a = m + sg * noise[(long long)g * noise_stride + j];   // Normal(mu, sigma).sample()
+        const float zz = (a - m) / sg;
+        quad += zz * zz;
+        lsum += ls;
+        actions[(long long)g * actions_stride + j] = a;
+        if (sigmas) sigmas[(long long)g * sigmas_stride + j] = m * 0.0f + sg;   // amp_network_builder.py:142-148
+    }
+    quad = group16_sum(quad);
+    lsum = group16_sum(lsum);
+    if (l == 0) {
+        neglogp[(long long)g * neglogp_stride] = 0.5f * quad + kHalfLog2Pi * (float)A + lsum;
+        if (values) {
+            float v = value_raw[(long long)g * value_stride];
+            if (vmean) v = sqrtf((float)vvar[0] + 1e-5f) * clampf(v, -5.f, 5.f) + (float)vmean[0];
+            values[(long long)g * values_stride] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PPO losses + gradients w.r.t. (mu, value).  16 lanes per sample, 16 samples per 256-thread block.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ppo_loss_kernel(const pulse_ppo_loss_args a) {
+    __shared__ float red[5][16];
+    const int samples_per_block = 256 / kLanesPerSample;
+    const int slot = threadIdx.x / kLanesPerSample;
+    const int l = threadIdx.x % kLanesPerSample;
+    const int A = a.num_actions;
+    const float invB = 1.0f / (float)a.rows;
+    float acc_a = 0.f, acc_c = 0.f, acc_b = 0.f, acc_clip = 0.f, acc_kl = 0.f;
+    for (int base = blockIdx.x * samples_per_block; base < a.rows; base += gridDim.x * samples_per_block) {
+        const int i = base + slot;
+        if (i >= a.rows) continue;
+        const long long d = a.idx ? a.idx[i] : (long long)i;
+        const float* mu = a.mu + (long long)i * a.mu_stride;
+        const float* act = a.actions + d * a.actions_stride;
+        const float* omu = a.old_mu + d * a.old_mu_stride;
+        float quad = 0.f, lsum = 0.f, bl = 0.f, kl = 0.f;
+        for (int j = l; j < A; j += kLanesPerSample) {
+            const float ls = a.logstd[j], sg = expf(ls);
+            const float m = mu[j];
+            const float zz = (act[j] - m) / sg;
+            quad += zz * zz;
+            lsum += ls;
+            if (a.has_bounds_loss) {
+                const float hi = fmaxf(m - 1.0f, 0.f), lo = fminf(m + 1.0f, 0.f);
+                bl += lo * lo + hi * hi;
+            }
+            // rl_games policy_kl(p0 = new, p1 = old)
+            const float s1 = expf(a.old_logstd[j]);
+            const float dm = omu[j] - m;
+            kl += logf(s1 / sg + 1e-5f) + (sg * sg + dm * dm) / (2.0f * (s1 * s1 + 1e-5f)) + (-0.5f);
+        }
+        quad = group16_sum(quad); lsum = group16_sum(lsum); bl = group16_sum(bl); kl = group16_sum(kl);
+        const float nlp = 0.5f * quad + kHalfLog2Pi * (float)A + lsum;
+        const float adv = a.advantages[d];
+        const float ratio = expf(a.old_neglogp[d] - nlp);
+        const float rc = clampf(ratio, 1.0f - a.e_clip, 1.0f + a.e_clip);
+        const float l1 = -(adv * ratio), l2 = -(adv * rc);
+        const float a_loss = fmaxf(l1, l2);
+        // d a_loss / d ratio: -adv where the unclipped branch is active (or tied inside the clip range)
+        const bool inside = (ratio >= 1.0f - a.e_clip) && (ratio <= 1.0f + a.e_clip);
+        const float g_ratio = (inside || l1 > l2) ? -adv : 0.f;
+        const float g_nlp = g_ratio * (-ratio);                      // d ratio / d nlp = -ratio
+        const float clipped = fabsf(ratio - 1.0f) > a.e_clip ? 1.f : 0.f;
+        // critic
+        const float v = a.value[(long long)i * a.value_stride];
+        const float ret = a.returns[d];
+        float c_loss, g_v;
+        if (a.clip_value) {
+            const float vp = a.old_values[d];
+            const float dv = v - vp;
+            const float vpc = vp + clampf(dv, -a.e_clip, a.e_clip);
+            const float e1 = (v - ret) * (v - ret), e2 = (vpc - ret) * (vpc - ret);
+            c_loss = fmaxf(e1, e2);
+            if (e1 >= e2) g_v = 2.0f * (v - ret);
+            else g_v = (fabsf(dv) <= a.e_clip) ? 2.0f * (vpc - ret) : 0.f;
+        } else {
+            c_loss = (ret - v) * (ret - v);
+            g_v = -2.0f * (ret - v);
+        }
+        // gradients (mean over the batch folded in)
+        float* dmu = a.dmu + (long long)i * a.dmu_stride;
+        for (int j = l; j < A; j += kLanesPerSample) {
+            const float sg = expf(a.logstd[j]);
+            const float m = mu[j];
+            float gmu = g_nlp * (-(act[j] - m) / (sg * sg));
+            if (a.has_bounds_loss) gmu += a.bounds_loss_coef * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
+            dmu[j] = gmu * invB;
+        }
+        if (l == 0) {
+            a.dvalue[(long long)i * a.dvalue_stride] = a.critic_coef * g_v * invB;
+            acc_a += a_loss; acc_c += c_loss; acc_b += bl; acc_clip += clipped; acc_kl += kl;
+        }
+    }
+    if (l == 0) { red[0][slot] = acc_a; red[1][slot] = acc_c; red[2][slot] = acc_b; red[3][slot] = acc_clip; red[4][slot] = acc_kl; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float s = 0.f;
+        if (threadIdx.x < 5)
+            for (int k = 0; k < 16; ++k) s += red[threadIdx.x][k];
+        a.partials[(long long)blockIdx.x * 8 + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// advantages
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adv_moments_kernel(const float* __restrict__ ret, const float* __restrict__ val, long long count,
+                                                         float* __restrict__ adv, double* __restrict__ partials) {
+    __shared__ double red[2][4];
+    double s1 = 0.0, s2 = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float a = ret[i] - val[i];
+        adv[i] = a;
+        s1 += (double)a; s2 += (double)a * (double)a;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partials[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ void __launch_bounds__(256) adv_normalize_kernel(float* __restrict__ adv, long long count, const double* __restrict__ partials, int nblk) {
+    __shared__ float s_mean, s_den;
+    if (threadIdx.x == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = 0; b < nblk; ++b) { s1 += partials[2 * b]; s2 += partials[2 * b + 1]; }
+        const double n = (double)count;
+        const double m = s1 / n;
+        double var = (s2 - n * m * m) / (n - 1.0);
+        if (var < 0.0) var = 0.0;
+        s_mean = (float)m;
+        s_den = (float)sqrt(var) + 1e-8f;
+    }
+    __syncthreads();
+    const float m = s_mean, den = s_den;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) adv[i] = (adv[i] - m) / den;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient norm + Adam over the flat parameter buffer
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sqnorm_partial_kernel(const float* __restrict__ x, long long count, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long n4 = count >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = x4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0) for (long long i = (n4 << 2) + threadIdx.x; i < count; i += 256) s += x[i] * x[i];
+    s = wave_sumf(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  long long count, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                  float max_norm, const float* __restrict__ sq_partials, int npart, float* __restrict__ norm_out) {
+    __shared__ float red[4];
+    __shared__ float s_coef;
+    float coef = 1.0f;
+    if (sq_partials) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < npart; i += 256) s += (double)sq_partials[i];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (float)s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+            if (norm_out && blockIdx.x == 0) *norm_out = norm;
+            float c = 1.0f;
+            if (max_norm > 0.f) c = fminf(max_norm / (norm + 1e-6f), 1.0f);   // clip_grad_norm_
+            s_coef = c;
+        }
+        __syncthreads();
+        coef = s_coef;
+    }
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        float gi = g[i] * coef;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);           // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * (gi * gi);        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+}  // namespace pulse
+
+using namespace pulse;
+
+extern "C" {
+
+int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols, const double* mean,
+                        const double* var, float eps, float clip, int32_t mode, float* y, int64_t y_stride, int32_t y_cols,
+                        double* moment_partials, int32_t num_blocks, pulse_stream_t s) {
+    PULSE_REQUIRE(rows >= 0 && cols >= 0, "pulse_rms_normalize: negative size");
+    if (rows == 0 || cols == 0) return PULSE_OK;
+    PULSE_REQUIRE(x && y && mean && var, "pulse_rms_normalize: null pointer");
+    PULSE_REQUIRE(cols <= 256 * kRmsMaxColsPerThread, "pulse_rms_normalize: cols %d > %d", cols, 256 * kRmsMaxColsPerThread);
+    PULSE_REQUIRE(num_blocks >= 1, "pulse_rms_normalize: num_blocks < 1");
+    PULSE_REQUIRE(y_cols >= cols && y_stride >= y_cols && x_stride >= cols, "pulse_rms_normalize: bad pitches");
+    PULSE_REQUIRE(mode == 0 || mode == 1, "pulse_rms_normalize: bad mode");
+    if (cols >= 64)
+        hipLaunchKernelGGL(rms_normalize_wide_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
+    else
+        hipLaunchKernelGGL(rms_normalize_narrow_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
+    return check_launch("pulse_rms_normalize");
+}
+
+int pulse_rms_update(double* mean, double* var, double* count_out, const double* moment_partials, int32_t num_blocks, int32_t cols,
+                     double count_old, double batch_count, pulse_stream_t s) {
+    PULSE_REQUIRE(cols >= 0 && num_blocks >= 1, "pulse_rms_update: bad sizes");
+    if (cols == 0) return PULSE_OK;
+    PULSE_REQUIRE(mean && var && moment_partials, "pulse_rms_update: null pointer");
+    PULSE_REQUIRE(batch_count >= 2.0, "pulse_rms_update: batch of %g rows has no unbiased variance", batch_count);
+    hipLaunchKernelGGL(rms_update_kernel, dim3((cols + 63) / 64), dim3(64), 0, as_stream(s), mean, var, count_out, moment_partials, num_blocks,
+                       cols, count_old, batch_count);
+    return check_launch("pulse_rms_update");
+}
+
+int pulse_policy_sample(const float* mu, int64_t mu_stride, const float* logstd, const float* noise, int64_t noise_stride,
+                        const float* value_raw, int64_t value_stride, const double* value_mean, const double* value_var, int32_t rows,
+                        int32_t num_actions, float* actions, int64_t actions_stride, float* sigmas, int64_t sigmas_stride, float* neglogp,
+                        int64_t neglogp_stride, float* values, int64_t values_out_stride, pulse_stream_t s) {
+    PULSE_REQUIRE(rows >= 0 && num_actions >= 1, "pulse_policy_sample: bad sizes");
+    if (rows == 0) return PULSE_OK;
+    PULSE_REQUIRE(mu && logstd && noise && actions && neglogp, "pulse_policy_sample: null pointer");
+    PULSE_REQUIRE(values == nullptr || value_raw != nullptr, "pulse_policy_sample: values requested without value_raw");
+    PULSE_REQUIRE((value_mean == nullptr) == (value_var == nullptr), "pulse_policy_sample: value mean/var must come together");
+    const long long threads = (long long)rows * kLanesPerSample;
+    hipLaunchKernelGGL(policy_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(s), mu, (long long)mu_stride,
+                       logstd, noise, (long long)noise_stride, value_raw, (long long)value_stride, value_mean, value_var, rows, num_actions,
+                       actions, (long long)actions_stride, sigmas, (long long)sigmas_stride, neglogp, (long long)neglogp_stride, values,
+                       (long long)values_out_stride);
+    return check_launch("pulse_policy_sample");
+}
+
+int pulse_sizeof_ppo_loss_args(void) { return (int)sizeof(pulse_ppo_loss_args); }
+
+int pulse_ppo_loss(const pulse_ppo_loss_args* args, pulse_stream_t s) {
+    PULSE_REQUIRE(args != nullptr, "pulse_ppo_loss: null args");
+    const pulse_ppo_loss_args& a = *args;
+    PULSE_REQUIRE(a.rows >= 1 && a.num_actions >= 1 && a.num_blocks >= 1, "pulse_ppo_loss: bad sizes");
+    PULSE_REQUIRE(a.mu && a.value && a.logstd && a.old_logstd && a.actions && a.old_mu && a.old_neglogp && a.advantages && a.returns &&
+                      a.dmu && a.dvalue && a.partials,
+                  "pulse_ppo_loss: null pointer");
+    PULSE_REQUIRE(!a.clip_value || a.old_values, "pulse_ppo_loss: clip_value needs old_values");
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(a.num_blocks), dim3(256), 0, as_stream(s), a);
+    return check_launch("pulse_ppo_loss");
+}
+
+int pulse_advantage_moments(const float* returns, const float* values, int64_t count, float* adv, double* partials, int32_t num_blocks,
+                            pulse_stream_t s) {
+    PULSE_REQUIRE(count >= 2 && num_blocks >= 1, "pulse_advantage_moments: need >= 2 samples");
+    PULSE_REQUIRE(returns && values && adv && partials, "pulse_advantage_moments: null pointer");
+    hipLaunchKernelGGL(adv_moments_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), returns, values, (long long)count, adv, partials);
+    return check_launch("pulse_advantage_moments");
+}
+
+int pulse_advantage_normalize(float* adv, int64_t count, const double* partials, int32_t num_blocks, pulse_stream_t s) {
+    PULSE_REQUIRE(count >= 2 && num_blocks >= 1 && adv && partials, "pulse_advantage_normalize: bad arguments");
+    long long blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(adv_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), adv, (long long)count, partials, num_blocks);
+    return check_launch("pulse_advantage_normalize");
+}
+
+int pulse_sqnorm_partial(const float* x, int64_t count, float* partials, int32_t num_blocks, pulse_stream_t s) {
+    PULSE_REQUIRE(count >= 0 && num_blocks >= 1 && x && partials, "pulse_sqnorm_partial: bad arguments");
+    PULSE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "pulse_sqnorm_partial: x must be 16-byte aligned");
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)count, partials);
+    return check_launch("pulse_sqnorm_partial");
+}
+
+int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, float max_norm, const float* sqnorm_partials, int32_t num_partials,
+                    float* grad_norm_out, pulse_stream_t s) {
+    PULSE_REQUIRE(count >= 0 && step >= 1, "pulse_adam_step: bad count / step");
+    if (count == 0) return PULSE_OK;
+    PULSE_REQUIRE(params && grads && exp_avg && exp_avg_sq, "pulse_adam_step: null pointer");
+    PULSE_REQUIRE(sqnorm_partials == nullptr || num_partials >= 1, "pulse_adam_step: bad partial count");
+    // bias corrections in double like torch (python floats), handed to the kernel as fp32 scalars
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    long long blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), params, grads, exp_avg, exp_avg_sq, (long long)count, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), max_norm, sqnorm_partials, num_partials, grad_norm_out);
+    return check_launch("pulse_adam_step");
+}
+}

@@ -1,0 +1,128 @@
+"""Tensor-level wrappers for the learner-side C-ABI entries (GEMM, normaliser, PPO loss, Adam ...).
+
+Same rules as ``ops.py``: GPU tensors only, enqueue on torch's current stream, no fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SILU, EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG,
+                   GEMM_RED_CONTIG, GemmDesc, PpoLossArgs)
+from .ops import _dev, _ptr, _stream
+
+ACTIVATIONS = {"None": ACT_NONE, "none": ACT_NONE, None: ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def gemm(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, bias=None,
+         activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
+         stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
+         a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0):
+    """C[m][n] = epilogue(sum_k A(m,k) B(n,k)).  A/B/C/... are tensors used only as base pointers
+    (+ *_off floats); all geometry is explicit (pitches in floats)."""
+    d = GemmDesc()
+    d.A = A.data_ptr() + 4 * a_off
+    d.B = B.data_ptr() + 4 * b_off
+    d.C = C.data_ptr() + 4 * c_off
+    d.C2 = (C2.data_ptr() + 4 * c2_off) if C2 is not None else None
+    d.bias = (bias.data_ptr() + 4 * bias_off) if bias is not None else None
+    d.aux = (aux.data_ptr() + 4 * aux_off) if aux is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldc2, d.ldaux = lda, ldb, ldc, ldc2, ldaux
+    d.a_layout, d.b_layout, d.batch = a_layout, b_layout, batch
+    d.stride_a, d.stride_b, d.stride_c, d.stride_c2 = stride_a, stride_b, stride_c, stride_c2
+    d.stride_bias, d.stride_aux = stride_bias, stride_aux
+    d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
+    _lib.check(_lib.load().pulse_gemm_f32(ctypes.byref(d), _stream()), "pulse_gemm_f32")
+
+
+def linear_forward(x, w, bias=None, activation=ACT_NONE, out=None):
+    """Convenience: y = act(x @ w.T + bias) for 2-D row-major tensors with 16-byte aligned rows."""
+    x, w = _dev(x, "x"), _dev(w, "w")
+    m, k = x.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    gemm(x, w, out, M=m, N=n, K=k, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, activation=activation)
+    return out
+
+
+def reduce_slabs(slabs, num_slabs, slab_stride, count, out, scale=1.0, slabs_off=0, out_off=0):
+    _lib.check(_lib.load().pulse_reduce_slabs(slabs.data_ptr() + 4 * slabs_off, num_slabs, slab_stride, count,
+                                              out.data_ptr() + 4 * out_off, float(scale), _stream()), "pulse_reduce_slabs")
+
+
+def colsum_partial(x, m, n, ld, num_chunks, partial, ld_partial, x_off=0, partial_off=0):
+    _lib.check(_lib.load().pulse_colsum_partial(x.data_ptr() + 4 * x_off, m, n, ld, num_chunks,
+                                                partial.data_ptr() + 4 * partial_off, ld_partial, _stream()), "pulse_colsum_partial")
+
+
+def rms_normalize(x, mean, var, *, rows, cols, x_stride, y, y_stride, y_cols=None, row_idx=None, eps=1e-5, clip=5.0,
+                  unnorm=False, moment_partials=None, num_blocks=None):
+    if num_blocks is None:
+        num_blocks = max(1, min(256, rows // 32)) if moment_partials is None else moment_partials.shape[0]
+    _lib.check(_lib.load().pulse_rms_normalize(_p(x), x_stride, _p(row_idx), rows, cols, _p(mean), _p(var), eps, clip,
+                                               1 if unnorm else 0, _p(y), y_stride, cols if y_cols is None else y_cols,
+                                               _p(moment_partials), num_blocks, _stream()), "pulse_rms_normalize")
+
+
+def rms_update(mean, var, count, moment_partials, cols, count_old, batch_count):
+    _lib.check(_lib.load().pulse_rms_update(_p(mean), _p(var), _p(count), _p(moment_partials), moment_partials.shape[0], cols,
+                                            float(count_old), float(batch_count), _stream()), "pulse_rms_update")
+
+
+def policy_sample(mu, mu_stride, logstd, noise, noise_stride, rows, num_actions, actions, actions_stride, neglogp,
+                  neglogp_stride=1, sigmas=None, sigmas_stride=0, value_raw=None, value_stride=0, value_mean=None,
+                  value_var=None, values=None, values_stride=0, mu_off=0, actions_off=0, sigmas_off=0, neglogp_off=0,
+                  values_off=0):
+    def po(t, off):
+        return (t.data_ptr() + 4 * off) if t is not None else None
+    _lib.check(_lib.load().pulse_policy_sample(po(mu, mu_off), mu_stride, _p(logstd), _p(noise), noise_stride, _p(value_raw),
+                                               value_stride, _p(value_mean), _p(value_var), rows, num_actions,
+                                               po(actions, actions_off), actions_stride, po(sigmas, sigmas_off), sigmas_stride,
+                                               po(neglogp, neglogp_off), neglogp_stride, po(values, values_off), values_stride,
+                                               _stream()), "pulse_policy_sample")
+
+
+def ppo_loss(*, mu, mu_stride, value, value_stride, logstd, old_logstd, idx, actions, actions_stride, old_mu, old_mu_stride,
+             old_neglogp, advantages, old_values, returns, rows, num_actions, e_clip, critic_coef, bounds_loss_coef, clip_value,
+             dmu, dmu_stride, dvalue, dvalue_stride, partials):
+    a = PpoLossArgs()
+    a.mu, a.mu_stride, a.value, a.value_stride, a.logstd = _p(mu), mu_stride, _p(value), value_stride, _p(logstd)
+    a.idx, a.actions, a.actions_stride = _p(idx), _p(actions), actions_stride
+    a.old_mu, a.old_mu_stride, a.old_logstd = _p(old_mu), old_mu_stride, _p(old_logstd)
+    a.old_neglogp, a.advantages, a.old_values, a.returns = _p(old_neglogp), _p(advantages), _p(old_values), _p(returns)
+    a.rows, a.num_actions = rows, num_actions
+    a.e_clip, a.critic_coef = float(e_clip), float(critic_coef)
+    a.has_bounds_loss = 0 if bounds_loss_coef is None else 1
+    a.bounds_loss_coef = 0.0 if bounds_loss_coef is None else float(bounds_loss_coef)
+    a.clip_value = 1 if clip_value else 0
+    a.dmu, a.dmu_stride, a.dvalue, a.dvalue_stride = _p(dmu), dmu_stride, _p(dvalue), dvalue_stride
+    a.partials, a.num_blocks = _p(partials), partials.shape[0]
+    _lib.check(_lib.load().pulse_ppo_loss(ctypes.byref(a), _stream()), "pulse_ppo_loss")
+
+
+def advantage_normalize(returns, values, adv_out, partials):
+    """adv = (returns - values - mean) / (std + 1e-8) over flat tensors (common_agent.py:589-599)."""
+    n = returns.numel()
+    lib = _lib.load()
+    _lib.check(lib.pulse_advantage_moments(_p(returns), _p(values), n, _p(adv_out), _p(partials), partials.shape[0], _stream()),
+               "pulse_advantage_moments")
+    _lib.check(lib.pulse_advantage_normalize(_p(adv_out), n, _p(partials), partials.shape[0], _stream()), "pulse_advantage_normalize")
+    return adv_out
+
+
+def sqnorm_partial(x, count, partials):
+    _lib.check(_lib.load().pulse_sqnorm_partial(_p(x), count, _p(partials), partials.numel(), _stream()), "pulse_sqnorm_partial")
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+              max_norm=0.0, sqnorm_partials=None, grad_norm_out=None):
+    _lib.check(_lib.load().pulse_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), count, float(lr), beta1, beta2,
+                                           eps, weight_decay, int(step), float(max_norm), _p(sqnorm_partials),
+                                           sqnorm_partials.numel() if sqnorm_partials is not None else 0, _p(grad_norm_out),
+                                           _stream()), "pulse_adam_step")

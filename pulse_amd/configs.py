@@ -1,0 +1,62 @@
+"""The BASELINE.json configurations as concrete configs (values from the reference's YAML files).
+
+learning/im.yaml:46-91 hyper-parameters; env/env_im.yaml env switches.  ``make_agent`` wires a
+recorded synthetic rollout (pulse_amd/env/sim.py) to HumanoidIm and a CommonAgent.
+"""
+import copy
+
+NETWORK_IM = {            # phc/data/cfg/learning/im.yaml:12-44
+    "name": "amp", "separate": True,
+    "space": {"continuous": {"mu_activation": "None", "sigma_activation": "None", "mu_init": {"name": "default"},
+                             "sigma_init": {"name": "const_initializer", "val": -2.9}, "fixed_sigma": True, "learn_sigma": False}},
+    "mlp": {"units": [1024, 512], "activation": "relu", "d2rl": False, "initializer": {"name": "default"}},
+}
+
+PPO_IM = {                # phc/data/cfg/learning/im.yaml:46-91
+    "name": "Humanoid", "multi_gpu": False, "ppo": True, "mixed_precision": False, "normalize_input": True,
+    "normalize_value": True, "reward_shaper": {"scale_value": 1}, "normalize_advantage": True, "gamma": 0.99, "tau": 0.95,
+    "learning_rate": 2e-5, "lr_schedule": "constant", "entropy_coef": 0.0, "truncate_grads": True, "grad_norm": 50.0,
+    "e_clip": 0.2, "horizon_length": 32, "minibatch_size": 16384, "mini_epochs": 6, "critic_coef": 5, "clip_value": False,
+    "bounds_loss_coef": 10,
+}
+
+ENV_IM = {"obs_v": 6, "self_obs_v": 1, "power_reward": True, "local_root_obs": True, "root_height_obs": True,
+          "enableEarlyTermination": True, "terminationDistance": 0.25, "episode_length": 300}
+
+CONFIGS = {
+    # BASELINE.json configs[0]: 64-env synthetic rollout (horizon 16), 2x512 MLP, one PPO+GAE epoch
+    "cfg1": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "units": [512, 512]},
+    # BASELINE.json configs[1]: 4096 SMPL humanoids, horizon 32, imitation reward/obs + PPO
+    "cfg2": {"num_envs": 4096, "horizon_length": 32, "minibatch_size": 16384, "units": [1024, 512]},
+}
+
+
+def agent_config(name, **overrides):
+    c = CONFIGS[name]
+    net = copy.deepcopy(NETWORK_IM)
+    net["mlp"]["units"] = list(c["units"])
+    cfg = copy.deepcopy(PPO_IM)
+    cfg.update({"horizon_length": c["horizon_length"], "minibatch_size": c["minibatch_size"], "network": net})
+    cfg.update(overrides)
+    return cfg, c["num_envs"]
+
+
+def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None):
+    from .env.humanoid_im import HumanoidIm, VecTaskPythonWrapper
+    from .env.sim import RecordedMotion, RecordedRollout, RecordedSim
+    if rollout is None:
+        rollout = RecordedRollout(num_envs, horizon + 1, seed=seed, rank=rank)
+    rollout.to(device)
+    sim = RecordedSim(rollout)
+    motion = RecordedMotion(rollout, sim)
+    task = HumanoidIm({"env": dict(ENV_IM)}, sim, motion, device=device)
+    task.progress_buf.copy_(rollout.init_progress)
+    return VecTaskPythonWrapper(task, rl_device=device), rollout
+
+
+def make_agent(name="cfg2", device="cuda:0", seed=1234, rank=0, rollout=None, **overrides):
+    from .learning.common_agent import CommonAgent
+    cfg, num_envs = agent_config(name, **overrides)
+    vec_env, rollout = make_env(num_envs, cfg["horizon_length"], device, seed=seed, rank=rank, rollout=rollout)
+    cfg.update({"vec_env": vec_env, "device": device, "seed": seed})
+    return CommonAgent("pulse_amd", cfg), rollout

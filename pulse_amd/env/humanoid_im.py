@@ -1,0 +1,247 @@
+"""HumanoidIm task on MI355X: the env side of ``env.step()`` without the physics.
+
+Mirrors the buffer contract and step order of the reference class chain
+  Humanoid -> HumanoidAMP -> HumanoidAMPTask -> HumanoidIm
+  (phc/env/tasks/humanoid.py:1222-1346, humanoid_amp.py:181-210, humanoid_im.py:662-706,853-919,1119-1192)
+and the VecTask return convention (phc/env/tasks/vec_task.py:145-162, vec_task_wrappers.py:45-81):
+
+    step(actions):  pre_physics_step -> _physics_step -> post_physics_step
+    post_physics_step:  progress_buf += 1 ; refresh ; _compute_reward ; _compute_reset ;
+                        _compute_observations ; extras['terminate'|'reward_raw']
+
+The reference issues three chains of TorchScript calls for reward / reset / observations; here
+``post_physics_step`` is ONE launch of ``pulse_im_step`` (pulse_amd/csrc/env_step.hip) that writes
+``rew_buf``, ``reward_raw``, ``reset_buf``, ``_terminate_buf`` and ``obs_buf`` in place.  The
+per-piece methods (``_compute_reward`` ...) are kept -- same names, same buffers -- and launch the
+same kernel with a narrower ``what`` mask, so partial recomputes (``reset(env_ids)``) and tests
+can call them exactly like the reference.
+
+Buffers: ``obs_buf`` (N, 934) float32 is a view of an (N, 960) allocation (GEMM-ready pitch, zero
+pad); ``rew_buf`` (N,), ``reset_buf`` / ``progress_buf`` / ``_terminate_buf`` (N,) int64.
+The simulator and the motion library are injected (pulse_amd/env/sim.py) because Isaac Gym is
+closed source and AMASS data is not redistributable -- both are OUT OF SCOPE of this build.
+"""
+import torch
+
+from .. import ops
+from .. import synthetic as syn
+from .._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS
+
+
+class Box:
+    """Minimal gym.spaces.Box stand-in (gym is not installed)."""
+
+    def __init__(self, low, high, shape):
+        import numpy as np
+        self.shape = tuple(shape)
+        self.low = np.full(self.shape, low, dtype=np.float32)
+        self.high = np.full(self.shape, high, dtype=np.float32)
+
+
+class HumanoidIm:
+    def __init__(self, cfg, sim, motion_lib, device="cuda:0"):
+        env = cfg.get("env", cfg)
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.sim, self._motion_lib = sim, motion_lib
+        self.num_envs = sim.num_envs
+        self.num_bodies = syn.NUM_BODIES
+        self.dt = 2.0 / 60.0                                                   # controlFrequencyInv 2 @ 60 Hz
+        self.obs_v = int(env.get("obs_v", 6))
+        self.self_obs_v = int(env.get("self_obs_v", 1))
+        if self.self_obs_v != 1 or self.obs_v not in (6, 7):
+            raise NotImplementedError("self_obs_v 1 with obs_v 6 | 7 are built (SURVEY.md 8a); others are listed as next")
+        self._fut_tracks = bool(env.get("fut_tracks", False))
+        self._num_traj_samples = int(env.get("numTrajSamples", 3)) if self._fut_tracks else 1
+        if self._fut_tracks:
+            raise NotImplementedError("fut_tracks needs a motion library with future sampling (next row f-1)")
+        self._local_root_obs = bool(env.get("local_root_obs", True))
+        self._root_height_obs = bool(env.get("root_height_obs", True))
+        self._full_body_reward = bool(env.get("full_body_reward", True))        # humanoid_im.py:37
+        self.power_reward = bool(env.get("power_reward", True))                 # env_im.yaml:23
+        self.power_coefficient = float(env.get("power_coefficient", 0.0005))     # humanoid_im.py:92
+        self.reward_specs = dict(ops.DEFAULT_REWARD_SPECS)
+        self.reward_specs.update(env.get("reward_specs", {}))
+        self._enable_early_termination = bool(env.get("enableEarlyTermination", True))
+        self.max_episode_length = int(env.get("episode_length", 300))
+        self.cycle_motion = bool(env.get("cycle_motion", False))
+        track = env.get("trackBodies", syn.SMPL_BODY_NAMES)
+        reset = env.get("reset_bodies", syn.RESET_BODY_NAMES)
+        self._track_bodies_id = torch.tensor([syn.SMPL_BODY_NAMES.index(b) for b in track], dtype=torch.int32, device=self.device)
+        self._reset_bodies_id = torch.tensor([syn.SMPL_BODY_NAMES.index(b) for b in reset], dtype=torch.int32, device=self.device)
+        self._termination_distances = torch.full((self.num_bodies,), float(env.get("terminationDistance", 0.25)), device=self.device)
+        self._dof_size = syn.NUM_DOF
+        self._pd_action_offset = torch.zeros(self._dof_size, device=self.device)
+        self._pd_action_scale = torch.ones(self._dof_size, device=self.device)
+        self.clip_obs = float("inf")                                            # parse_task.py:68
+        # ---- sizes (humanoid.py:653, humanoid_im.py:457-491)
+        self._self_obs_size = 1 + 15 * self.num_bodies - 3 if self._root_height_obs else 15 * self.num_bodies - 3
+        jt = self._track_bodies_id.numel()
+        self._task_obs_size = (24 if self.obs_v == 6 else 9) * jt * self._num_traj_samples
+        self.num_obs = self._self_obs_size + self._task_obs_size
+        self.num_actions = self._dof_size
+        self.obs_pitch = (self.num_obs + 31) // 32 * 32
+        # ---- buffers (base_task.py:98-104)
+        n, dev = self.num_envs, self.device
+        self._obs_store = torch.zeros(n, self.obs_pitch, device=dev)
+        self.obs_buf = self._obs_store[:, :self.num_obs]
+        self.rew_buf = torch.zeros(n, device=dev)
+        self.reward_raw = torch.zeros(n, 5 if self.power_reward else 4, device=dev)
+        self.reset_buf = torch.ones(n, dtype=torch.int64, device=dev)
+        self.progress_buf = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._terminate_buf = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._cycle_counter = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._motion_start_times = torch.zeros(n, device=dev)
+        self._motion_start_times_offset = torch.zeros(n, device=dev)
+        self._pass_time = torch.zeros(n, dtype=torch.bool, device=dev)
+        self.extras = {}
+        self.actions = None
+        # attributes the agent reaches for (amp_agent.py:59-63; common_agent.py:54)
+        self.temp_running_mean = True
+        self.kin_lr = 5e-4
+        self.fitting = False
+        self.z_type = None
+        self.humanoid_type = "smpl"
+        self.has_task = True
+        self.viewer = None
+
+    # ------------------------------------------------------------------ sizes / spaces
+    def get_obs_size(self):
+        return self.num_obs
+
+    def get_self_obs_size(self):
+        return self._self_obs_size
+
+    def get_task_obs_size(self):
+        return self._task_obs_size
+
+    def get_action_size(self):
+        return self.num_actions
+
+    def get_running_mean_size(self):
+        return (self.get_obs_size(),)
+
+    def get_task_obs_size_detail(self):
+        return []
+
+    # ------------------------------------------------------------------ step phases
+    def step(self, actions):
+        self.pre_physics_step(actions)
+        self._physics_step()
+        self.post_physics_step()
+
+    def _action_to_pd_targets(self, action):
+        return self._pd_action_offset + self._pd_action_scale * action           # humanoid.py:1392-1394
+
+    def pre_physics_step(self, actions):
+        self.actions = actions
+        self.sim.set_dof_position_target_tensor(self._action_to_pd_targets(actions))
+
+    def _physics_step(self):
+        self.sim.simulate_and_refresh()                                         # Isaac Gym: OUT OF SCOPE
+
+    def _update_pass_time(self):
+        # humanoid_im.py:1120-1123 (+ :1148 when cycle_motion)
+        if self.cycle_motion:
+            torch.ge(self.progress_buf, self.max_episode_length - 1, out=self._pass_time)
+        else:
+            t = self.progress_buf * self.dt + self._motion_start_times + self._motion_start_times_offset
+            torch.ge(t, self._motion_lib._motion_lengths, out=self._pass_time)
+
+    def _im_step(self, what, env_ids=None, env_mask=None, ref_next=None):
+        need_now = what & (PULSE_IM_REWARD | PULSE_IM_RESET)
+        return ops.im_step(
+            self.sim.rigid_body_state, what=what,
+            ref_now=self._motion_lib.now() if need_now else None,
+            ref_next=(ref_next if ref_next is not None else self._motion_lib.next()) if what & PULSE_IM_TASK_OBS else None,
+            time_steps=self._num_traj_samples, dof_force=self.sim.dof_force, dof_vel=self.sim.dof_vel,
+            progress=self.progress_buf, pass_time=self._pass_time, cycle_counter=self._cycle_counter,
+            track_ids=self._track_bodies_id, reset_ids=self._reset_bodies_id, term_dist=self._termination_distances,
+            reset_use_mean=False, full_body_reward=self._full_body_reward, obs_version=self.obs_v,
+            local_root_obs=self._local_root_obs, root_height_obs=self._root_height_obs, specs=self.reward_specs,
+            power_coef=self.power_coefficient, power_reward=self.power_reward, env_ids=env_ids, env_mask=env_mask,
+            obs=self._obs_store, obs_cols=self.obs_pitch, rew=self.rew_buf, rew_raw=self.reward_raw,
+            reset=self.reset_buf, terminate=self._terminate_buf)
+
+    def _compute_reward(self, actions=None):
+        self._im_step(PULSE_IM_REWARD)
+
+    def _compute_reset(self):
+        self._update_pass_time()
+        self._im_step(PULSE_IM_RESET)
+
+    def _compute_observations(self, env_ids=None, env_mask=None, ref_next=None):
+        self._im_step(PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, env_ids=env_ids, env_mask=env_mask, ref_next=ref_next)
+
+    def post_physics_step(self):
+        self.progress_buf += 1
+        self._update_pass_time()
+        # reward -> reset -> observations (humanoid.py:1325-1328), fused into one launch
+        self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
+        self.extras["terminate"] = self._terminate_buf
+        self.extras["reward_raw"] = self.reward_raw
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, env_ids=None):
+        """Partial reset by env id (vec_task_wrappers.py:54-56, humanoid.py:526-541): None = every env,
+        empty list / tensor = no env."""
+        if env_ids is None:
+            self.reset_masked(torch.ones(self.num_envs, dtype=torch.bool, device=self.device))
+            return
+        if not isinstance(env_ids, torch.Tensor):
+            if len(env_ids) == 0:
+                return
+            env_ids = torch.tensor(env_ids, dtype=torch.int64, device=self.device)
+        if env_ids.numel() == 0:
+            return
+        mask = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        mask[env_ids] = True
+        self.reset_masked(mask)
+
+    def reset_masked(self, mask):
+        """Sync-free form of reset(env_ids): mask is a (N,) bool device tensor.
+        _reset_envs (humanoid.py:541-560): state init, buffer clears, observation recompute."""
+        self.sim.set_env_states_masked(mask)
+        keep = ~mask
+        self.progress_buf.mul_(keep)
+        self.reset_buf.mul_(keep)
+        self._terminate_buf.mul_(keep)
+        self._compute_observations(env_mask=mask, ref_next=self._motion_lib.next_after_reset())
+
+
+class VecTaskPythonWrapper:
+    """VecTaskPython + wrapper: phc/env/tasks/vec_task.py:145-162, vec_task_wrappers.py:45-81,
+    plus RLGPUEnv's get_env_info (phc/run_hydra.py:224-243)."""
+
+    def __init__(self, task, rl_device="cuda:0", clip_observations=float("inf"), clip_actions=1.0):
+        self.task = task
+        self.env = self                  # agent code reaches vec_env.env.task (amp_agent.py:59)
+        self.num_envs = task.num_envs
+        self.num_obs = task.num_obs
+        self.num_actions = task.num_actions
+        self.clip_obs, self.clip_actions = clip_observations, clip_actions
+        self.obs_space = Box(-float("inf"), float("inf"), (self.num_obs,))
+        self.act_space = Box(-1.0, 1.0, (self.num_actions,))
+        self.rl_device = rl_device
+
+    def step(self, actions):
+        actions_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)
+        self.task.step(actions_tensor)
+        obs = self.task.obs_buf
+        if self.clip_obs != float("inf"):
+            obs = torch.clamp(obs, -self.clip_obs, self.clip_obs)
+        return obs, self.task.rew_buf, self.task.reset_buf, self.task.extras
+
+    def reset(self, env_ids=None):
+        self.task.reset(env_ids)
+        return self.task.obs_buf
+
+    def reset_masked(self, mask):
+        self.task.reset_masked(mask)
+        return self.task.obs_buf
+
+    def get_number_of_agents(self):
+        return 1
+
+    def get_env_info(self):
+        return {"action_space": self.act_space, "observation_space": self.obs_space, "task_obs_size": self.task.get_task_obs_size()}

@@ -1,0 +1,124 @@
+"""Stand-ins for the two things the hot path reads but does not own: the simulator's state
+tensors (Isaac Gym / PhysX, closed source, OUT OF SCOPE) and the reference-motion frames.
+
+``RecordedRollout`` holds pre-recorded synthetic frames generated once on the CPU
+(pulse_amd/synthetic.py) and resident in HBM -- "identical pre-recorded rollout buffers" that both
+the CPU oracle and the HIP path consume.  ``RecordedSim`` exposes them the way Isaac Gym exposes
+its tensors to phc/env/tasks/humanoid.py:175-243 (a persistent (N, bodies, 13) rigid-body buffer
+that "physics" overwrites every step, dof force / velocity tensors, a PD-target setter), and
+``RecordedMotion`` plays the role of ``MotionLibBase.get_motion_state``
+(phc/utils/motion_lib_base.py:434-517) for the two evaluations per step (time t and t+1).
+"""
+import torch
+
+from .. import synthetic as syn
+
+
+class RecordedRollout:
+    """frames[f] for f in 0..num_frames-1: everything one env step reads."""
+
+    def __init__(self, num_envs, num_frames, seed=1234, rank=0, done_rate=0.02):
+        g = syn.make_generator(seed, rank)
+        self.num_envs, self.num_frames = num_envs, num_frames
+        n = num_envs
+        keys = ("rb", "reset_rb", "dof_force", "dof_vel")
+        self.data = {k: [] for k in keys}
+        self.ref_now = {k: [] for k in ("pos", "rot", "vel", "ang")}
+        self.ref_next = {k: [] for k in ("pos", "rot", "vel", "ang")}
+        self.ref_next_reset = {k: [] for k in ("pos", "rot", "vel", "ang")}
+        for _ in range(num_frames):
+            d = syn.env_step_inputs(g, n, edge_cases=False)
+            self.data["rb"].append(d["rb"])
+            self.data["dof_force"].append(d["dof_force"])
+            self.data["dof_vel"].append(d["dof_vel"])
+            for k in self.ref_now:
+                self.ref_now[k].append(d["ref_now"][k])
+                self.ref_next[k].append(d["ref_next"][k])
+            rrb = syn.rigid_body_state(g, n)
+            self.data["reset_rb"].append(rrb)
+            rr = syn.reference_frame(g, rrb)
+            for k in self.ref_next_reset:
+                self.ref_next_reset[k].append(rr[k])
+        self.data = {k: torch.stack(v) for k, v in self.data.items()}
+        self.ref_now = {k: torch.stack(v) for k, v in self.ref_now.items()}
+        self.ref_next = {k: torch.stack(v) for k, v in self.ref_next.items()}
+        self.ref_next_reset = {k: torch.stack(v) for k, v in self.ref_next_reset.items()}
+        # episode clock: motion length / start time so that ~done_rate of the envs time out per step
+        self.dt = 2.0 / 60.0                                                    # humanoid.py:122, controlFrequencyInv 2
+        self.motion_lengths = 1.0 + 2.0 * (1.0 / max(done_rate, 1e-6)) * self.dt * torch.rand(n, generator=g)
+        self.motion_start_times = torch.zeros(n)
+        self.init_progress = torch.randint(0, 40, (n,), generator=g, dtype=torch.int64)
+        # some envs drift far from their reference -> early termination
+        far = torch.rand(num_frames, n, generator=g) < done_rate / 2
+        self.ref_now["pos"][:, :, 13, :] += far[..., None].float() * 1.0
+
+    def to(self, device):
+        self.data = {k: v.to(device) for k, v in self.data.items()}
+        for d in (self.ref_now, self.ref_next, self.ref_next_reset):
+            for k in d:
+                d[k] = d[k].to(device)
+        self.motion_lengths = self.motion_lengths.to(device)
+        self.motion_start_times = self.motion_start_times.to(device)
+        self.init_progress = self.init_progress.to(device)
+        return self
+
+
+class RecordedSim:
+    """Isaac-Gym-shaped tensor API over a RecordedRollout (device resident)."""
+
+    def __init__(self, rollout):
+        self.rollout = rollout
+        dev = rollout.data["rb"].device
+        n = rollout.num_envs
+        self.num_envs = n
+        self.frame = 0
+        self.rigid_body_state = rollout.data["rb"][0].clone()               # the persistent "gym tensor"
+        self.dof_force = rollout.data["dof_force"][0].clone()
+        self.dof_vel = rollout.data["dof_vel"][0].clone()
+        self.pd_targets = torch.zeros(n, syn.NUM_DOF, device=dev)
+
+    def rewind(self):
+        self.frame = 0
+        self._load(0)
+
+    def _load(self, f):
+        r = self.rollout.data
+        self.rigid_body_state.copy_(r["rb"][f])
+        self.dof_force.copy_(r["dof_force"][f])
+        self.dof_vel.copy_(r["dof_vel"][f])
+
+    def set_dof_position_target_tensor(self, pd_tar):
+        # the recorded "physics" ignores the targets; they are kept so the write happens as in
+        # phc/env/tasks/humanoid.py:1246-1247
+        self.pd_targets = pd_tar
+
+    def simulate_and_refresh(self):
+        """control_freq_inv x gym.simulate + refresh_*_tensor (humanoid.py:1282-1297, humanoid_amp.py:599-620)."""
+        self.frame = (self.frame + 1) % self.rollout.num_frames
+        self._load(self.frame)
+
+    def set_env_states_masked(self, mask):
+        """Reference-state init of the masked envs (humanoid_amp.py:447-488): their records are
+        replaced by this frame's recorded reset state."""
+        rr = self.rollout.data["reset_rb"][self.frame]
+        torch.where(mask[:, None, None], rr, self.rigid_body_state, out=self.rigid_body_state)
+
+
+class RecordedMotion:
+    """get_motion_state stand-in: the frames recorded for the current sim frame."""
+
+    def __init__(self, rollout, sim):
+        self.rollout, self.sim = rollout, sim
+        self._motion_lengths = rollout.motion_lengths
+
+    def now(self):
+        f = self.sim.frame
+        return {k: v[f] for k, v in self.rollout.ref_now.items()}
+
+    def next(self):
+        f = self.sim.frame
+        return {k: v[f] for k, v in self.rollout.ref_next.items()}
+
+    def next_after_reset(self):
+        f = self.sim.frame
+        return {k: v[f] for k, v in self.rollout.ref_next_reset.items()}

@@ -1,0 +1,487 @@
+"""CommonAgent on MI355X: PPO + GAE behind the rl_games-style ``train_epoch()`` / ``env.step()`` surface.
+
+Mirrors phc/learning/common_agent.py (CommonAgent(a2c_continuous.A2CAgent)):
+  __init__            :36-90      (+ the A2CBase config plumbing of rl_games 1.1.4)
+  init_tensors        :92-98
+  train               :100-185
+  train_epoch         :191-260
+  get_action_values   :262-288
+  play_steps          :290-355
+  prepare_dataset     :357-398
+  calc_gradients      :400-491
+  discount_values     :493-505
+  bound_loss / _actor_loss / _critic_loss / _calc_advs   :512-520, :564-599
+Method names, dict keys and tensor shapes follow the reference so the class drops into the
+``algo_factory.register_builder(...)`` call of phc/run_hydra.py:250-268.
+
+What is different underneath (MI355X-first):
+  * every tensor op of the hot loops is a HIP kernel behind the C ABI (pulse_amd/csrc): the
+    observation normaliser fused with the minibatch gather, fp32 MFMA GEMMs with fused
+    bias/activation/derivative epilogues, one PPO loss+gradient kernel, one slab reduce, one fused
+    clip+Adam over a flat parameter buffer.  No autograd graph, no per-parameter optimiser loop;
+  * rollout storage is env-major so the (T,N)->(N*T) flatten is free; network outputs are written
+    straight into their experience-buffer slots;
+  * no device->host read inside an epoch (the reference syncs on `.nonzero()` every step and on
+    `kl.item()` every minibatch); episode statistics use masked, device-side meters;
+  * multi-GPU = one process per GPU; the single exchange step per optimiser step is one RCCL
+    all-reduce of the flat gradient (pulse_amd/parallel.py).
+"""
+import math
+import time
+
+import torch
+
+from .. import kernels as K
+from .. import ops
+from ..parallel import DistContext
+from . import rlg
+from .network import A2CNetwork
+from .running_mean_std import RunningMeanStd
+
+
+class CommonAgent:
+    def __init__(self, base_name, config):
+        # ---------------- A2CBase.__init__ (rl_games 3P) ----------------
+        self.config = self.cfg = config
+        self.base_name = base_name
+        self.exp_name = str(config.get("train_dir", "output/pulse_amd")).split("/")[-1]
+        self.multi_gpu = bool(config.get("multi_gpu", False))
+        self.dist = config.get("dist") or DistContext(enabled=None if self.multi_gpu else False)
+        self.rank, self.world_size = self.dist.rank, self.dist.world_size
+        self.ppo_device = self.device = torch.device(config.get("device", config.get("ppo_device", "cuda:0")))
+        if self.ppo_device.type != "cuda":
+            raise ValueError("pulse_amd agents run on the GPU only (there is no CPU path)")
+        self.vec_env = config["vec_env"]
+        self.env_info = config.get("env_info") or self.vec_env.get_env_info()
+        self.num_actors = int(config.get("num_actors", self.vec_env.num_envs))
+        self.num_agents = 1
+        self.value_size = self.env_info.get("value_size", 1)
+        self.observation_space = self.env_info["observation_space"]
+        self.obs_shape = self.observation_space.shape
+        self.normalize_input = bool(config.get("normalize_input", True))
+        self.normalize_value = bool(config.get("normalize_value", True))
+        self.normalize_advantage = bool(config.get("normalize_advantage", True))
+        self.horizon_length = int(config["horizon_length"])
+        self.gamma, self.tau = float(config["gamma"]), float(config["tau"])
+        self.e_clip = float(config["e_clip"])
+        self.clip_value = bool(config["clip_value"])
+        self.critic_coef = float(config["critic_coef"])
+        self.entropy_coef = float(config.get("entropy_coef", 0.0))
+        self.grad_norm = float(config.get("grad_norm", 1.0))
+        self.truncate_grads = bool(config.get("truncate_grads", False))
+        self.mini_epochs_num = int(config["mini_epochs"])
+        self.minibatch_size = int(config["minibatch_size"])
+        self.batch_size = self.horizon_length * self.num_actors * self.num_agents
+        assert self.batch_size % self.minibatch_size == 0, "batch_size must be divisible by minibatch_size"
+        self.num_minibatches = self.batch_size // self.minibatch_size
+        self.mixed_precision = bool(config.get("mixed_precision", False))
+        if self.mixed_precision:
+            raise NotImplementedError("fp16 autocast + GradScaler path (config 5) is not built; fp32 only")
+        self.weight_decay = float(config.get("weight_decay", 0.0))
+        self.schedule_type = config.get("schedule_type", "legacy")
+        self.is_adaptive_lr = config.get("lr_schedule", "constant") == "adaptive"
+        self.scheduler = rlg.AdaptiveScheduler(config.get("kl_threshold", 0.008)) if self.is_adaptive_lr else rlg.IdentityScheduler()
+        self.rewards_shaper = rlg.DefaultRewardsShaper(**config.get("reward_shaper", {}))
+        self.max_epochs = int(config.get("max_epochs", 1e6))
+        self.save_freq = int(config.get("save_frequency", 0))
+        self.games_to_track = int(config.get("games_to_track", 100))
+        self.seq_len = int(config.get("seq_length", 4))
+        self.is_rnn = False
+        self.has_central_value = False
+        self.use_action_masks = False
+        self.epoch_num = 0
+        self.frame = 0
+        self.curr_frames = 0
+        self.states = None
+        self.rnn_states = None
+
+        # ---------------- CommonAgent.__init__ (common_agent.py:36-90) ----------------
+        self._load_config_params(config)
+        self.is_discrete = False
+        self._setup_action_space()
+        self.bounds_loss_coef = config.get("bounds_loss_coef", None)
+        self.clip_actions = config.get("clip_actions", True)
+        net_config = self._build_net_config()
+        task = self.vec_env.env.task
+        self.obs_pitch = getattr(task, "obs_pitch", (self.obs_shape[0] + 31) // 32 * 32)
+        if self.normalize_input:
+            self.running_mean_std = RunningMeanStd(task.get_running_mean_size(), device=self.ppo_device)
+        else:
+            raise NotImplementedError("normalize_input: False (every shipped config sets True; amp_agent.py:594-603 requires it)")
+        self.value_mean_std = RunningMeanStd((1,), device=self.ppo_device) if self.normalize_value else None
+        self.model = self._build_model(net_config)
+        self.last_lr = float(self.last_lr)
+        # Adam(lr, eps=1e-8) over the flat parameter buffer (common_agent.py:66)
+        n = self.model.parameters_count()
+        self.exp_avg = torch.zeros(n, device=self.ppo_device)
+        self.exp_avg_sq = torch.zeros(n, device=self.ppo_device)
+        self.optimizer_step = 0
+        self._sq_partials = torch.zeros(256, device=self.ppo_device)
+        self._grad_norm = torch.zeros(1, device=self.ppo_device)
+        self._loss_partials = torch.zeros(max(1, min(512, self.minibatch_size // 16)), 8, device=self.ppo_device)
+        self._adv_partials = torch.zeros(128, 2, dtype=torch.float64, device=self.ppo_device)
+        seed = int(config.get("seed", 0)) + self.rank                       # run_hydra.py:124
+        self.noise_generator = torch.Generator(device=self.ppo_device)
+        self.noise_generator.manual_seed(seed)
+        perm_gen = torch.Generator()
+        perm_gen.manual_seed(seed)
+        self.dataset = rlg.AMPDataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn, self.ppo_device, self.seq_len,
+                                      generator=perm_gen)
+        self.game_rewards = rlg.AverageMeter((self.value_size,), self.games_to_track, self.ppo_device)
+        self.game_lengths = rlg.AverageMeter((1,), self.games_to_track, self.ppo_device)
+        self.train_result = {}
+        self._entropy = None
+        self._tensors_ready = False
+
+    # ------------------------------------------------------------------ construction helpers
+    def _load_config_params(self, config):
+        self.last_lr = config["learning_rate"]
+
+    def _setup_action_space(self):
+        action_space = self.env_info["action_space"]
+        self.actions_num = action_space.shape[0]
+        self.actions_low = torch.from_numpy(action_space.low.copy()).float().to(self.ppo_device)
+        self.actions_high = torch.from_numpy(action_space.high.copy()).float().to(self.ppo_device)
+
+    def _build_net_config(self):
+        return {"actions_num": self.actions_num, "input_shape": self.obs_shape, "num_seqs": self.num_actors * self.num_agents,
+                "value_size": self.env_info.get("value_size", 1)}
+
+    def _build_model(self, net_config):
+        params = self.config["network"]
+        return A2CNetwork(params, actions_num=net_config["actions_num"], input_shape=net_config["input_shape"],
+                          value_size=net_config["value_size"], device=self.ppo_device, split_k=int(self.config.get("split_k", 8)))
+
+    # ------------------------------------------------------------------ init_tensors (common_agent.py:92-98)
+    def init_tensors(self):
+        net = self.model
+        self.experience_buffer = rlg.ExperienceBuffer(self.num_actors, self.horizon_length, self.obs_shape[0], self.obs_pitch,
+                                                      self.actions_num, net.a_pitch, self.ppo_device)
+        self.experience_buffer.add("next_obses", like="obses")
+        self.experience_buffer.add("next_values", like="values")
+        self.current_rewards = torch.zeros(self.num_actors, self.value_size, device=self.ppo_device)
+        self.current_lengths = torch.zeros(self.num_actors, device=self.ppo_device)
+        self.dones = torch.ones(self.num_actors, dtype=torch.uint8, device=self.ppo_device)
+        self.update_list = ["actions", "neglogpacs", "values", "mus", "sigmas"]
+        self.tensor_list = self.update_list + ["obses", "states", "dones"] + ["next_obses"]
+        self._tensors_ready = True
+
+    # ------------------------------------------------------------------ mode switches
+    def set_eval(self):
+        self.model.eval()
+        self.running_mean_std.eval()
+        if self.value_mean_std is not None:
+            self.value_mean_std.eval()
+
+    def set_train(self):
+        self.model.train()
+        self.running_mean_std.train()
+        if self.value_mean_std is not None:
+            self.value_mean_std.train()
+
+    def update_lr(self, lr):
+        self.last_lr = lr
+
+    def update_epoch(self):
+        self.epoch_num += 1
+        return self.epoch_num
+
+    # ------------------------------------------------------------------ env plumbing (A2CBase)
+    def obs_to_tensors(self, obs):
+        return obs if isinstance(obs, dict) else {"obs": obs}
+
+    def env_reset(self, env_ids=None):
+        obs = self.vec_env.reset(env_ids)
+        return self.obs_to_tensors(obs)
+
+    def _env_reset_masked(self, mask):
+        return self.obs_to_tensors(self.vec_env.reset_masked(mask))
+
+    def env_step(self, actions):
+        if self.clip_actions:
+            # rescale_actions(low, high, clamp(a, -1, 1)) with +-1 spaces is the clamp itself
+            actions = torch.clamp(actions, -1.0, 1.0)
+        obs, rewards, dones, infos = self.vec_env.step(actions)
+        if self.value_size == 1:
+            rewards = rewards.unsqueeze(1)
+        return self.obs_to_tensors(obs), rewards, dones, infos
+
+    # ------------------------------------------------------------------ inference (common_agent.py:262-288, 551-562)
+    def _obs_store(self, obs):
+        """The pitched allocation behind an (N, obs_dim) observation view (zero copy)."""
+        return obs
+
+    def _preproc_obs(self, obs_batch, ws, rows, row_idx=None):
+        """running_mean_std(obs) written into the network's GEMM-ready input buffer."""
+        self.running_mean_std.forward(obs_batch, row_idx=row_idx, out=ws["x"], out_cols=self.model.in_pitch)
+        return ws["x"]
+
+    def get_action_values(self, obs, slot=None):
+        """Actor + critic inference and action sampling for one rollout step.  With ``slot`` (time
+        index) the outputs are produced directly inside the experience buffer."""
+        n = self.num_actors
+        net = self.model
+        ws = net.workspace(n, train=False)
+        net.eval()
+        self._preproc_obs(obs["obs"], ws, n)
+        eb = self.experience_buffer
+        t = self.horizon_length
+        ap = net.a_pitch
+        s = 0 if slot is None else slot
+        net.forward(ws, n, mu_out=eb.phys["mus"], mu_ld=t * ap, mu_off=s * ap)
+        noise = torch.randn(n, self.actions_num, device=self.ppo_device, generator=self.noise_generator)
+        vm = self.value_mean_std
+        K.policy_sample(eb.phys["mus"], t * ap, net.sigma, noise, self.actions_num, n, self.actions_num,
+                        eb.phys["actions"], t * ap, eb.phys["neglogpacs"], t, sigmas=eb.phys["sigmas"], sigmas_stride=t * ap,
+                        value_raw=ws["val"], value_stride=4, value_mean=vm.running_mean if vm else None,
+                        value_var=vm.running_var if vm else None, values=eb.phys["values"], values_stride=t,
+                        mu_off=s * ap, actions_off=s * ap, sigmas_off=s * ap, neglogp_off=s, values_off=s)
+        td = eb.tensor_dict
+        return {"actions": td["actions"][s], "neglogpacs": td["neglogpacs"][s], "values": td["values"][s], "mus": td["mus"][s],
+                "sigmas": td["sigmas"][s], "rnn_states": None}
+
+    def _eval_critic(self, obs_dict, out=None):
+        n = self.num_actors
+        net = self.model
+        ws = net.workspace(n, train=False)
+        net.eval()
+        self._preproc_obs(obs_dict["obs"], ws, n)
+        net.eval_critic(ws, n)
+        value = torch.empty(n, 1, device=self.ppo_device) if out is None else out
+        if self.normalize_value:
+            self.value_mean_std.forward(ws["val"], unnorm=True, out=value, out_cols=1)
+        else:
+            value.copy_(ws["val"][:, :1])
+        return value
+
+    # ------------------------------------------------------------------ rollout (common_agent.py:290-355)
+    def play_steps(self):
+        self.set_eval()
+        eb = self.experience_buffer
+        done_mask = None
+        for n in range(self.horizon_length):
+            self.obs = self._env_reset_masked(done_mask) if done_mask is not None else self.env_reset([])
+            eb.update_data("obses", n, self.obs["obs"])
+            res_dict = self.get_action_values(self.obs, slot=n)
+            for k in self.update_list:
+                eb.update_data(k, n, res_dict[k])
+            self.obs, rewards, self.dones, infos = self.env_step(res_dict["actions"])
+            shaped_rewards = self.rewards_shaper(rewards)
+            eb.update_data("rewards", n, shaped_rewards)
+            eb.update_data("next_obses", n, self.obs["obs"])
+            eb.update_data("dones", n, self.dones)
+            terminated = infos["terminate"].float().unsqueeze(-1)
+            next_vals = self._eval_critic(self.obs)
+            next_vals *= (1.0 - terminated)
+            eb.update_data("next_values", n, next_vals)
+
+            self.current_rewards += rewards
+            self.current_lengths += 1
+            done_mask = self.dones != 0
+            self.game_rewards.update_masked(self.current_rewards, done_mask)
+            self.game_lengths.update_masked(self.current_lengths.unsqueeze(1), done_mask)
+            not_dones = 1.0 - self.dones.float()
+            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+            self.current_lengths = self.current_lengths * not_dones
+        self._pending_done_mask = done_mask
+
+        td = eb.tensor_dict
+        mb_advs, mb_returns = ops.discount_values(td["dones"], td["values"], td["rewards"], td["next_values"], self.gamma, self.tau,
+                                                  return_returns=True)
+        batch_dict = eb.get_transformed_list(rlg.swap_and_flatten01, self.tensor_list)
+        batch_dict["returns"] = rlg.swap_and_flatten01(mb_returns)
+        batch_dict["advs_raw"] = rlg.swap_and_flatten01(mb_advs)
+        batch_dict["played_frames"] = self.batch_size
+        return batch_dict
+
+    def discount_values(self, mb_fdones, mb_values, mb_rewards, mb_next_values):
+        return ops.discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, self.gamma, self.tau)
+
+    # ------------------------------------------------------------------ dataset (common_agent.py:357-398, 589-599)
+    def _calc_advs(self, batch_dict):
+        returns, values = batch_dict["returns"], batch_dict["values"]
+        b = returns.shape[0]
+        adv = torch.empty(b, device=self.ppo_device)
+        if self.normalize_advantage:
+            K.advantage_normalize(returns.reshape(-1), values.reshape(-1), adv, self._adv_partials)
+        else:
+            torch.sub(returns.reshape(-1), values.reshape(-1), out=adv)
+        return adv
+
+    def prepare_dataset(self, batch_dict):
+        returns, values = batch_dict["returns"], batch_dict["values"]
+        advantages = self._calc_advs(batch_dict)
+        if self.normalize_value:
+            values = self.value_mean_std(values.reshape(-1, 1))
+            returns = self.value_mean_std(returns.reshape(-1, 1))
+        eb = self.experience_buffer
+        dataset_dict = {
+            "old_values": values, "old_logp_actions": batch_dict["neglogpacs"], "advantages": advantages, "returns": returns,
+            "actions": batch_dict["actions"], "obs": batch_dict["obses"], "rnn_states": None, "rnn_masks": None,
+            "mu": batch_dict["mus"], "sigma": batch_dict["sigmas"],
+            # pitched, un-sliced storage for the fused-gather kernels
+            "_obs_store": eb.flat("obses"), "_actions_store": eb.flat("actions"), "_mu_store": eb.flat("mus"),
+        }
+        self.dataset.update_values_dict(dataset_dict)
+        return dataset_dict
+
+    # ------------------------------------------------------------------ update (common_agent.py:400-491)
+    def train_actor_critic(self, input_dict):
+        self.calc_gradients(input_dict)
+        return self.train_result
+
+    def _gather_inputs(self, input_dict):
+        """Accept the fused form ({'idx', 'dataset'}) or a reference-style gathered dict."""
+        if "idx" in input_dict and "dataset" in input_dict:
+            d = input_dict["dataset"]
+            return (input_dict["idx"], d["_obs_store"], d["_actions_store"], d["_mu_store"], d["old_logp_actions"], d["advantages"],
+                    d["old_values"], d["returns"])
+        ap = self.model.a_pitch
+        def pitched(t, w):
+            buf = torch.zeros(t.shape[0], w, device=self.ppo_device)
+            buf[:, :t.shape[1]] = t
+            return buf
+        return (None, pitched(input_dict["obs"], self.obs_pitch), pitched(input_dict["actions"], ap), pitched(input_dict["mu"], ap),
+                input_dict["old_logp_actions"].contiguous(), input_dict["advantages"].contiguous(),
+                input_dict["old_values"].contiguous(), input_dict["returns"].contiguous())
+
+    def _obs_normalizer_for_update(self):
+        """CommonAgent normalises minibatches with the LIVE statistics (and updates them)."""
+        return self.running_mean_std, None
+
+    def calc_gradients(self, input_dict):
+        self.set_train()
+        idx, obs_store, act_store, mu_store, old_nlp, adv, old_val, ret = self._gather_inputs(input_dict)
+        mb = idx.numel() if idx is not None else obs_store.shape[0]
+        net = self.model
+        ws = net.workspace(mb, train=True)
+        norm, live = self._obs_normalizer_for_update()
+        norm.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch)
+        if live is not None:      # AMPAgent: normalise with the frozen copy, still update the live stats
+            live.update_only(obs_store, idx)
+        net.forward(ws, mb)
+        ap = net.a_pitch
+        K.ppo_loss(mu=ws["mu"], mu_stride=ap, value=ws["val"], value_stride=4, logstd=net.sigma, old_logstd=net.sigma, idx=idx,
+                   actions=act_store, actions_stride=act_store.stride(0), old_mu=mu_store, old_mu_stride=mu_store.stride(0),
+                   old_neglogp=old_nlp, advantages=adv, old_values=old_val, returns=ret, rows=mb, num_actions=self.actions_num,
+                   e_clip=self.e_clip, critic_coef=self.critic_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
+                   dmu=ws["dmu"], dmu_stride=ap, dvalue=ws["dval"], dvalue_stride=4, partials=self._loss_partials)
+        net.backward(ws, mb, grad_scale=1.0 / self.world_size)
+        if self.multi_gpu:
+            self.dist.sync_gradients(net.grad)                          # optimizer.synchronize()
+        self.optimizer_step += 1
+        K.sqnorm_partial(net.grad, net.n_flat, self._sq_partials)
+        K.adam_step(net.flat, net.grad, self.exp_avg, self.exp_avg_sq, net.n_flat, lr=self.last_lr, step=self.optimizer_step,
+                    weight_decay=self.weight_decay, max_norm=self.grad_norm if self.truncate_grads else 0.0,
+                    sqnorm_partials=self._sq_partials, grad_norm_out=self._grad_norm)
+        info = self._loss_partials.sum(0) / mb                          # [a_loss, c_loss, b_loss, clip_frac, kl]
+        if self._entropy is None:
+            ent = float((0.5 + 0.5 * math.log(2 * math.pi)) * self.actions_num) + float(net.sigma.sum().item())
+            self._entropy = torch.tensor(ent, device=self.ppo_device)
+        self.train_result = {"entropy": self._entropy, "kl": info[4], "last_lr": self.last_lr, "lr_mul": 1.0, "b_loss": info[2],
+                             "actor_loss": info[0], "actor_clip_frac": info[3], "critic_loss": info[1],
+                             "grad_norm": self._grad_norm.clone()}
+
+    # ------------------------------------------------------------------ epoch (common_agent.py:191-260)
+    def train_epoch(self):
+        if not self._tensors_ready:
+            self.init_tensors()
+            self.obs = self.env_reset()
+        torch.cuda.synchronize()
+        play_time_start = time.time()
+        batch_dict = self.play_steps()
+        torch.cuda.synchronize()
+        play_time_end = time.time()
+        update_time_start = time.time()
+        self.set_train()
+        self.curr_frames = batch_dict.pop("played_frames")
+        self.prepare_dataset(batch_dict)
+        train_info = None
+        for _ in range(0, self.mini_epochs_num):
+            for i in range(len(self.dataset)):
+                curr_train_info = self.train_actor_critic(self.dataset[i])
+                if self.schedule_type == "legacy":
+                    if self.multi_gpu and self.is_adaptive_lr:
+                        curr_train_info["kl"] = self.dist.average_value(curr_train_info["kl"], "ep_kls")
+                    if self.is_adaptive_lr:   # the constant schedule ignores kl: no device read (reference reads kl.item())
+                        self.last_lr, self.entropy_coef = self.scheduler.update(self.last_lr, self.entropy_coef, self.epoch_num, 0,
+                                                                                curr_train_info["kl"].item())
+                        self.update_lr(self.last_lr)
+                if train_info is None:
+                    train_info = {k: [v] for k, v in curr_train_info.items()}
+                else:
+                    for k, v in curr_train_info.items():
+                        train_info[k].append(v)
+            if self.schedule_type == "standard" and self.is_adaptive_lr:
+                av_kls = torch.stack(train_info["kl"]).mean()
+                if self.multi_gpu:
+                    av_kls = self.dist.average_value(av_kls, "ep_kls")
+                self.last_lr, self.entropy_coef = self.scheduler.update(self.last_lr, self.entropy_coef, self.epoch_num, 0, av_kls.item())
+                self.update_lr(self.last_lr)
+        torch.cuda.synchronize()
+        update_time_end = time.time()
+        train_info["play_time"] = play_time_end - play_time_start
+        train_info["update_time"] = update_time_end - update_time_start
+        train_info["total_time"] = update_time_end - play_time_start
+        self._record_train_batch_info(batch_dict, train_info)
+        return train_info
+
+    def _record_train_batch_info(self, batch_dict, train_info):
+        return
+
+    # ------------------------------------------------------------------ train loop (common_agent.py:100-185)
+    def train(self, max_epochs=None):
+        self.init_tensors()
+        self.obs = self.env_reset()
+        if self.multi_gpu:
+            self.dist.setup_algo(self.model.flat, (self.model.sigma, self.exp_avg, self.exp_avg_sq))
+        self._init_train()
+        total_time = 0.0
+        max_epochs = self.max_epochs if max_epochs is None else max_epochs
+        while True:
+            epoch_num = self.update_epoch()
+            train_info = self.train_epoch()
+            if self.multi_gpu:
+                self.curr_frames = self.dist.sync_stats([self.running_mean_std, self.value_mean_std], self.curr_frames)
+            total_time += train_info["total_time"]
+            self.frame += self.curr_frames
+            if self.rank == 0:
+                fps_step = self.curr_frames / train_info["play_time"]
+                fps_total = self.curr_frames / train_info["total_time"]
+                mean_rewards = self.game_rewards.get_mean()
+                print(f"epoch: {epoch_num} frames: {self.frame} fps step: {fps_step:.1f} fps total: {fps_total:.1f} "
+                      f"reward: {mean_rewards}", flush=True)
+            if epoch_num >= max_epochs:
+                return self.game_rewards.get_mean(), epoch_num
+
+    def _init_train(self):
+        return
+
+    # ------------------------------------------------------------------ checkpoint surface
+    def get_full_state_weights(self):
+        state = {"model": self.model.state_dict(), "epoch": self.epoch_num, "frame": self.frame,
+                 "optimizer": {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.optimizer_step}}
+        if self.normalize_input:
+            state["running_mean_std"] = self.running_mean_std.state_dict()
+        if self.normalize_value:
+            state["reward_mean_std"] = self.value_mean_std.state_dict()
+        return state
+
+    def set_full_state_weights(self, weights):
+        self.model.load_state_dict(weights["model"])
+        self.epoch_num = weights.get("epoch", 0)
+        self.frame = weights.get("frame", 0)
+        if "optimizer" in weights and "exp_avg" in weights["optimizer"]:
+            self.exp_avg.copy_(weights["optimizer"]["exp_avg"])
+            self.exp_avg_sq.copy_(weights["optimizer"]["exp_avg_sq"])
+            self.optimizer_step = int(weights["optimizer"]["step"])
+        if self.normalize_input and "running_mean_std" in weights:
+            self.running_mean_std.load_state_dict(weights["running_mean_std"])
+        if self.normalize_value and "reward_mean_std" in weights:
+            self.value_mean_std.load_state_dict(weights["reward_mean_std"])
+
+    def save(self, fn):
+        torch.save(self.get_full_state_weights(), fn + ".pth")
+
+    def restore(self, fn):
+        self.set_full_state_weights(torch.load(fn, map_location=self.ppo_device))

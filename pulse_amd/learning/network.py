@@ -1,0 +1,289 @@
+"""Actor / critic MLP pair on the gfx950 GEMM kernel, with an explicit (non-autograd) backward.
+
+Mirrors the *MLP branch* of the reference network stack:
+  A2CBuilder.Network / AMPBuilder.Network   phc/learning/network_builder.py:188-291,
+                                            phc/learning/amp_network_builder.py:19-40,58-216
+  ModelA2CContinuousLogStd (rl_games 3P)    SURVEY.md Appendix B
+i.e. ``separate: True`` actor and critic MLPs of identical shape, a linear ``mu`` head, a
+state-independent non-learned ``sigma`` (``fixed_sigma: True, learn_sigma: False``,
+learning/im.yaml:21-25) and a linear ``value`` head.  Checkpoint key names are the reference's
+(``a2c_network.actor_mlp.0.weight`` ...) because ``network_loader.py:76-176`` treats them as a
+wire format.
+
+MI355X-first layout (what differs from a stack of nn.Linear):
+  * ALL parameters live in one flat fp32 buffer (one fused clip+Adam launch, one RCCL all-reduce);
+    same-shaped actor / critic layers are adjacent so one batched GEMM launch serves both nets;
+  * layer 1 of both nets is ONE GEMM of N = 2*u1 over the shared normalised observation;
+  * the observation pitch is padded to a multiple of 32 floats (934 -> 960), weights carry the
+    matching zero columns;
+  * backward is hand-derived: dX GEMMs fuse the activation derivative, dW GEMMs split the batch
+    (reduction) dimension into S slabs that are summed by one deterministic reduce launch which
+    also yields the flat gradient ready for all-reduce / clipping.
+"""
+import math
+
+import torch
+
+from .. import kernels as K
+from .._lib import (ACT_NONE, ACT_RELU, ACT_SILU, EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG, GEMM_RED_CONTIG)
+
+
+def _r4(x):
+    return (x + 3) // 4 * 4
+
+
+def _r32(x):
+    return (x + 31) // 32 * 32
+
+
+class A2CNetwork:
+    """Separate actor/critic MLP with mu / value heads.  Parameters: flat buffer ``self.flat``."""
+
+    def __init__(self, params, *, actions_num, input_shape, value_size=1, device="cuda:0", split_k=8):
+        self.device = torch.device(device)
+        self._load(params)
+        if not self.separate:
+            raise NotImplementedError("only `separate: True` actor / critic networks are supported")
+        if value_size != 1:
+            raise NotImplementedError("value_size != 1")
+        self.actions_num = int(actions_num)
+        self.value_size = 1
+        self.in_dim = int(input_shape[0] if isinstance(input_shape, (tuple, list)) else input_shape)
+        self.in_pitch = _r32(self.in_dim)
+        self.units = [int(u) for u in self.units]
+        if any(u % 4 for u in self.units) or not self.units:
+            raise NotImplementedError("MLP unit sizes must be non-empty multiples of 4")
+        self.act = K.ACTIVATIONS[self.activation]
+        if self.act not in (ACT_RELU, ACT_SILU):
+            raise NotImplementedError(f"activation {self.activation!r} (relu / silu supported)")
+        self.split_k = int(split_k)
+        self.a_pitch = _r4(self.actions_num)
+        self._build_layout()
+        self.flat = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+        self.sigma = torch.zeros(self.actions_num, dtype=torch.float32, device=self.device)   # log-std, non-learned
+        self._slabs = None
+        self._ws = {}
+        self.training = True
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ config (network_builder.py:461-502)
+    def _load(self, params):
+        self.separate = params.get("separate", False)
+        self.units = params["mlp"]["units"]
+        self.activation = params["mlp"]["activation"]
+        self.initializer = params["mlp"].get("initializer", {"name": "default"})
+        if params["mlp"].get("d2rl", False) or params.get("normalization", None) is not None:
+            raise NotImplementedError("d2rl / normalization layers are not used by the PULSE configs")
+        if "rnn" in params or "cnn" in params:
+            raise NotImplementedError("rnn / cnn branches are out of scope (no shipped config enables them)")
+        space = params.get("space", {}).get("continuous")
+        if space is None:
+            raise NotImplementedError("continuous action space required")
+        self.space_config = space
+        if not space.get("fixed_sigma", True) or space.get("learn_sigma", True):
+            raise NotImplementedError("only fixed_sigma: True / learn_sigma: False (state-independent constant sigma)")
+        if space.get("mu_activation", "None") != "None" or space.get("sigma_activation", "None") != "None":
+            raise NotImplementedError("mu / sigma activations other than None")
+        if self.initializer.get("name", "default") != "default":
+            raise NotImplementedError("only the `default` (nn.Linear) initializer")
+
+    # ------------------------------------------------------------------ flat layout
+    def _build_layout(self):
+        u, L = self.units, len(self.units)
+        off = 0
+        self.w_off, self.b_off, self.in_w = [], [], []
+        for l in range(L):
+            k = self.in_pitch if l == 0 else u[l - 1]
+            self.in_w.append(k)
+            self.w_off.append(off)
+            off += 2 * u[l] * k             # [actor rows | critic rows], pitch k
+            self.b_off.append(off)
+            off += 2 * u[l]
+        self.wmu_off = off; off += self.actions_num * u[-1]
+        off = _r4(off)
+        self.bmu_off = off; off += self.a_pitch
+        self.wv_off = off; off += u[-1]
+        self.bv_off = off; off += 4
+        self.n_flat = _r4(off)
+
+    def _w_view(self, buf, l, net):
+        u, k = self.units[l], self.in_w[l]
+        o = self.w_off[l] + net * u * k
+        w = buf[o:o + u * k].view(u, k)
+        return w[:, :self.in_dim] if l == 0 else w
+
+    def _b_view(self, buf, l, net):
+        u = self.units[l]
+        o = self.b_off[l] + net * u
+        return buf[o:o + u]
+
+    def named_parameters(self, buf=None):
+        """Reference key names -> views into the flat buffer (Sequential indices: Linear at 2*l)."""
+        buf = self.flat if buf is None else buf
+        out = {}
+        for net, name in ((0, "actor_mlp"), (1, "critic_mlp")):
+            for l in range(len(self.units)):
+                out[f"a2c_network.{name}.{2 * l}.weight"] = self._w_view(buf, l, net)
+                out[f"a2c_network.{name}.{2 * l}.bias"] = self._b_view(buf, l, net)
+        uL = self.units[-1]
+        out["a2c_network.value.weight"] = buf[self.wv_off:self.wv_off + uL].view(1, uL)
+        out["a2c_network.value.bias"] = buf[self.bv_off:self.bv_off + 1]
+        out["a2c_network.mu.weight"] = buf[self.wmu_off:self.wmu_off + self.actions_num * uL].view(self.actions_num, uL)
+        out["a2c_network.mu.bias"] = buf[self.bmu_off:self.bmu_off + self.actions_num]
+        return out
+
+    def named_gradients(self):
+        return self.named_parameters(self.grad)
+
+    def state_dict(self):
+        sd = {k: v.clone() for k, v in self.named_parameters().items()}
+        sd["a2c_network.sigma"] = self.sigma.clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        mine = self.named_parameters()
+        for k, v in mine.items():
+            if k not in sd:
+                if strict:
+                    raise KeyError(k)
+                continue
+            if tuple(sd[k].shape) != tuple(v.shape):
+                raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {tuple(v.shape)}")
+            v.copy_(sd[k].to(self.device, torch.float32))
+        if "a2c_network.sigma" in sd:
+            self.sigma.copy_(sd["a2c_network.sigma"].to(self.device, torch.float32))
+
+    def reset_parameters(self, generator=None):
+        """nn.Linear default init (kaiming_uniform(a=sqrt 5) == U(+-1/sqrt(fan_in))), biases zeroed
+        (network_builder.py:273-277), sigma = const_initializer(val) (im.yaml:21-23), drawn on the
+        CPU in the reference's module-construction order so a shared seed reproduces the oracle."""
+        def lin(o, i):
+            w = torch.empty(o, i)
+            torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5), generator=generator)
+            bound = 1 / math.sqrt(i)
+            torch.empty(o).uniform_(-bound, bound, generator=generator)        # nn.Linear draws its bias too
+            return w
+        p = self.named_parameters()
+        self.flat.zero_()
+        for name in ("actor_mlp", "critic_mlp"):
+            for l, uu in enumerate(self.units):
+                i = self.in_dim if l == 0 else self.units[l - 1]
+                p[f"a2c_network.{name}.{2 * l}.weight"].copy_(lin(uu, i))
+        p["a2c_network.value.weight"].copy_(lin(1, self.units[-1]))
+        p["a2c_network.mu.weight"].copy_(lin(self.actions_num, self.units[-1]))
+        si = self.space_config.get("sigma_init", {"name": "const_initializer", "val": 0.0})
+        self.sigma.fill_(float(si.get("val", 0.0)))
+
+    def parameters_count(self):
+        return self.n_flat
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def is_rnn(self):
+        return False
+
+    # ------------------------------------------------------------------ workspaces
+    def workspace(self, m, train):
+        key = (m, bool(train))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev, u = self.device, self.units
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        ws = {"x": e(m, self.in_pitch), "h": [e(m, 2 * uu) for uu in u], "mu": e(m, self.a_pitch), "val": e(m, 4)}
+        if self.act == ACT_SILU:
+            ws["z"] = [e(m, 2 * uu) for uu in u]
+        if train:
+            ws["dh"] = [e(m, 2 * uu) for uu in u]
+            ws["dmu"] = torch.zeros(m, self.a_pitch, dtype=torch.float32, device=dev)
+            ws["dval"] = torch.zeros(m, 4, dtype=torch.float32, device=dev)
+            if self._slabs is None:
+                self._slabs = torch.zeros(self.split_k, self.n_flat, dtype=torch.float32, device=dev)
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def _mlp_forward(self, ws, m, nets):
+        """nets: (first_net, count) with count in {1, 2}; hidden activations land in ws['h'][l][:, net*u:]."""
+        n0, cnt = nets
+        u, f = self.units, self.flat
+        pre = ws.get("z")
+        for l, uu in enumerate(u):
+            k = self.in_w[l]
+            if l == 0:
+                K.gemm(ws["x"], f, ws["h"][0], M=m, N=cnt * uu, K=k, lda=k, ldb=k, ldc=2 * uu, bias=f, activation=self.act,
+                       b_off=self.w_off[0] + n0 * uu * k, bias_off=self.b_off[0] + n0 * uu, c_off=n0 * uu,
+                       C2=pre[0] if pre else None, ldc2=2 * uu, c2_off=n0 * uu)
+            else:
+                up = u[l - 1]
+                K.gemm(ws["h"][l - 1], f, ws["h"][l], M=m, N=uu, K=up, lda=2 * up, ldb=up, ldc=2 * uu, bias=f, activation=self.act,
+                       batch=cnt, stride_a=up, stride_b=uu * up, stride_c=uu, stride_bias=uu,
+                       a_off=n0 * up, b_off=self.w_off[l] + n0 * uu * up, bias_off=self.b_off[l] + n0 * uu, c_off=n0 * uu,
+                       C2=pre[l] if pre else None, ldc2=2 * uu, stride_c2=uu, c2_off=n0 * uu)
+
+    def _heads(self, ws, m, mu_out=None, mu_ld=None, mu_off=0, actor=True, critic=True):
+        uL, f = self.units[-1], self.flat
+        hL = ws["h"][-1]
+        if actor:
+            tgt = ws["mu"] if mu_out is None else mu_out
+            K.gemm(hL, f, tgt, M=m, N=self.actions_num, K=uL, lda=2 * uL, ldb=uL, ldc=self.a_pitch if mu_ld is None else mu_ld,
+                   bias=f, b_off=self.wmu_off, bias_off=self.bmu_off, c_off=mu_off)
+        if critic:
+            K.gemm(hL, f, ws["val"], M=m, N=1, K=uL, lda=2 * uL, ldb=uL, ldc=4, bias=f, a_off=uL, b_off=self.wv_off, bias_off=self.bv_off)
+
+    def forward(self, ws, m, *, mu_out=None, mu_ld=None, mu_off=0):
+        """Actor + critic forward on the normalised input already in ws['x'].  mu -> ws['mu'] (pitch
+        a_pitch) or the caller's buffer, raw value -> ws['val'][:, 0]."""
+        self._mlp_forward(ws, m, (0, 2))
+        self._heads(ws, m, mu_out, mu_ld, mu_off)
+
+    def eval_critic(self, ws, m):
+        """Critic only (CommonAgent._eval_critic, common_agent.py:551-562)."""
+        self._mlp_forward(ws, m, (1, 1))
+        self._heads(ws, m, actor=False)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ws, m, grad_scale=1.0):
+        """Given d loss / d mu in ws['dmu'] and d loss / d value in ws['dval'][:, 0], fill self.grad
+        (flat, same layout as self.flat).  Deterministic: split-K slabs + one ordered reduce."""
+        u, f, S = self.units, self.flat, self.split_k
+        L = len(u)
+        uL = u[-1]
+        slabs, P = self._slabs, self.n_flat
+        egrad = EPI_RELU_GRAD if self.act == ACT_RELU else EPI_SILU_GRAD
+        aux = ws["h"] if self.act == ACT_RELU else ws["z"]
+        # heads -> dH_L (activation derivative fused)
+        K.gemm(ws["dmu"], f, ws["dh"][-1], M=m, N=uL, K=self.actions_num, lda=self.a_pitch, ldb=uL, ldc=2 * uL,
+               b_layout=GEMM_OUT_CONTIG, b_off=self.wmu_off, epilogue=egrad, aux=aux[-1], ldaux=2 * uL)
+        K.gemm(ws["dval"], f, ws["dh"][-1], M=m, N=uL, K=1, lda=4, ldb=uL, ldc=2 * uL, b_layout=GEMM_OUT_CONTIG,
+               b_off=self.wv_off, c_off=uL, epilogue=egrad, aux=aux[-1], ldaux=2 * uL, aux_off=uL)
+        # head weight / bias gradients
+        K.gemm(ws["dmu"], ws["h"][-1], slabs, M=self.actions_num, N=uL, K=m, lda=self.a_pitch, ldb=2 * uL, ldc=uL,
+               a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, c_off=self.wmu_off, split_k=S, split_stride=P)
+        K.gemm(ws["dval"], ws["h"][-1], slabs, M=1, N=uL, K=m, lda=4, ldb=2 * uL, ldc=uL, a_layout=GEMM_OUT_CONTIG,
+               b_layout=GEMM_OUT_CONTIG, b_off=uL, c_off=self.wv_off, split_k=S, split_stride=P)
+        K.colsum_partial(ws["dmu"], m, self.actions_num, self.a_pitch, S, slabs, P, partial_off=self.bmu_off)
+        K.colsum_partial(ws["dval"], m, 1, 4, S, slabs, P, partial_off=self.bv_off)
+        for l in range(L - 1, -1, -1):
+            uu, k = u[l], self.in_w[l]
+            dz = ws["dh"][l]
+            K.colsum_partial(dz, m, 2 * uu, 2 * uu, S, slabs, P, partial_off=self.b_off[l])
+            if l == 0:
+                K.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
+                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P)
+            else:
+                up = u[l - 1]
+                K.gemm(dz, ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
+                       b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],
+                       split_k=S, split_stride=P)
+                K.gemm(dz, f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
+                       batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
+                       aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
+        K.reduce_slabs(slabs, S, P, P, self.grad, scale=grad_scale)
+        return self.grad

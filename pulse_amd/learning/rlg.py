@@ -1,0 +1,187 @@
+"""The slice of rl_games 1.1.4 the PULSE agents lean on, rebuilt for device-resident, sync-free use.
+
+rl_games is a third-party dependency of the reference (requirement.txt:27) that is absent here;
+the semantics below follow the reference's call sites (phc/learning/common_agent.py,
+amp_agent.py, amp_datasets.py) and the public 1.1.4 behaviour summarised in SURVEY.md Appendix B.
+
+  ExperienceBuffer  a2c_common.A2CBase.init_tensors / experience.ExperienceBuffer
+  AMPDataset        phc/learning/amp_datasets.py:36-100 over rl_games datasets.PPODataset
+  AverageMeter      torch_ext.AverageMeter (windowed mean of finished-episode stats)
+  IdentityScheduler / AdaptiveScheduler   rl_games schedulers
+  DefaultRewardsShaper
+
+MI355X-first choices:
+  * rollout tensors are stored ENV-MAJOR, physically (N, T, .), and exposed through the reference's
+    (T, N, .) indexing as strided views.  ``swap_and_flatten01`` -- a transposing copy of every
+    tensor in the reference (~1 GB of traffic at 4096 x 32 x 934) -- becomes a free reshape;
+  * observation rows keep the GEMM-ready pitch (934 -> 960) all the way into the dataset;
+  * nothing here reads a device value back to the host.
+"""
+import torch
+
+
+def swap_and_flatten01(arr):
+    """a2c_common.swap_and_flatten01: (T, N, ...) -> (N*T, ...) with row index env*T + t."""
+    if arr is None:
+        return arr
+    s = arr.size()
+    return arr.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+class ExperienceBuffer:
+    def __init__(self, num_actors, horizon_length, obs_dim, obs_pitch, actions_num, action_pitch, device):
+        self.num_actors, self.horizon_length = num_actors, horizon_length
+        self.device = torch.device(device)
+        self.obs_base_shape = (horizon_length, num_actors)
+        n, t = num_actors, horizon_length
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=self.device)
+        # physical storage, env-major
+        self.phys = {
+            "obses": z(n, t, obs_pitch), "rewards": z(n, t, 1), "values": z(n, t, 1), "neglogpacs": z(n, t),
+            "dones": z(n, t, dtype=torch.uint8), "actions": z(n, t, action_pitch), "mus": z(n, t, action_pitch),
+            "sigmas": z(n, t, action_pitch),
+        }
+        self.widths = {"obses": obs_dim, "actions": actions_num, "mus": actions_num, "sigmas": actions_num}
+        self.tensor_dict = {}
+        for k in self.phys:
+            self._expose(k)
+
+    def _expose(self, k):
+        v = self.phys[k].transpose(0, 1)                  # (T, N, pitch) view
+        w = self.widths.get(k)
+        self.tensor_dict[k] = v[..., :w] if w is not None else v
+
+    def add(self, name, like=None, width=None, pitch=None, dtype=torch.float32):
+        n, t = self.num_actors, self.horizon_length
+        if like is not None:
+            self.phys[name] = torch.zeros_like(self.phys[like])
+            if like in self.widths:
+                self.widths[name] = self.widths[like]
+        else:
+            self.phys[name] = torch.zeros(n, t, pitch or width, dtype=dtype, device=self.device)
+            if pitch and pitch != width:
+                self.widths[name] = width
+        self._expose(name)
+
+    def slot(self, name, index):
+        """(N, pitch) strided view of time step ``index`` in physical storage."""
+        return self.phys[name][:, index]
+
+    def update_data(self, name, index, val):
+        dst = self.tensor_dict[name][index]
+        if isinstance(val, torch.Tensor) and val.data_ptr() == dst.data_ptr() and val.stride() == dst.stride():
+            return                                      # the producer already wrote in place
+        dst.copy_(val)
+
+    def get_transformed_list(self, transform_op, tensor_list):
+        return {k: transform_op(self.tensor_dict[k]) for k in tensor_list if k in self.tensor_dict}
+
+    def flat(self, name):
+        """(N*T, pitch) view of the physical storage (row = env*T + t), pitch preserved."""
+        p = self.phys[name]
+        return p.reshape(p.shape[0] * p.shape[1], *p.shape[2:])
+
+
+class AMPDataset:
+    """Random-permutation minibatcher (amp_datasets.py:81-100).  ``__getitem__`` returns the index
+    slice plus references to the un-gathered tensors: the gather is fused into the consuming
+    kernels (normaliser, PPO loss).  ``gather(i)`` materialises the reference-style dict."""
+
+    def __init__(self, batch_size, minibatch_size, is_discrete, is_rnn, device, seq_len, generator=None):
+        if is_rnn:
+            raise NotImplementedError("sequence minibatches (use_seq_rl) are part of the PULSE-VAE row")
+        self.batch_size, self.minibatch_size = batch_size, minibatch_size
+        self.device = torch.device(device)
+        self.length = batch_size // minibatch_size
+        self.generator = generator
+        self.special_names = ["rnn_states"]
+        self.values_dict = None
+        self._idx_buf = self._randperm()
+
+    def _randperm(self):
+        # drawn on the CPU like the reference (torch.randperm(self.batch_size), amp_datasets.py:7) then kept on the device
+        return torch.randperm(self.batch_size, generator=self.generator).to(self.device)
+
+    def set_permutation(self, perm):
+        self._idx_buf = perm.to(self.device, torch.int64)
+
+    def update_values_dict(self, values_dict, **_):
+        self.values_dict = values_dict
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        start, end = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
+        out = {"idx": self._idx_buf[start:end], "dataset": self.values_dict}
+        if end >= self.batch_size:
+            self._shuffle_idx_buf()
+        return out
+
+    def gather(self, idx):
+        start, end = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
+        sample_idx = self._idx_buf[start:end]
+        return {k: v[sample_idx] for k, v in self.values_dict.items() if k not in self.special_names and v is not None}
+
+    def _shuffle_idx_buf(self):
+        self._idx_buf = self._randperm()
+
+
+class AverageMeter:
+    """torch_ext.AverageMeter with a masked, sync-free update."""
+
+    def __init__(self, in_shape, max_size, device):
+        self.max_size = max_size
+        self.mean = torch.zeros(in_shape, dtype=torch.float32, device=device)
+        self.current_size = torch.zeros((), dtype=torch.float32, device=device)
+
+    def update_masked(self, values, mask):
+        """values (N, ...) / mask (N,) bool: same as update(values[mask]) without materialising it."""
+        m = mask.to(values.dtype)
+        size = m.sum()
+        w = m.view(-1, *([1] * (values.dim() - 1)))
+        new_mean = (values * w).sum(0) / torch.clamp(size, min=1.0)
+        size_c = torch.clamp(size, 0, self.max_size)
+        old_size = torch.minimum(self.max_size - size_c, self.current_size)
+        size_sum = old_size + size_c
+        upd = (self.mean * old_size + new_mean * size_c) / torch.clamp(size_sum, min=1.0)
+        has = size > 0
+        self.mean = torch.where(has, upd, self.mean)
+        self.current_size = torch.where(has, size_sum, self.current_size)
+
+    def clear(self):
+        self.current_size.zero_()
+        self.mean.zero_()
+
+    def get_mean(self):
+        return self.mean.squeeze(0).cpu().numpy()
+
+
+class IdentityScheduler:
+    def update(self, current_lr, entropy_coef, epoch, frames, kl_dist, **kwargs):
+        return current_lr, entropy_coef
+
+
+class AdaptiveScheduler:
+    def __init__(self, kl_threshold=0.008):
+        self.min_lr, self.max_lr, self.kl_threshold = 1e-6, 1e-2, kl_threshold
+
+    def update(self, current_lr, entropy_coef, epoch, frames, kl_dist, **kwargs):
+        lr = current_lr
+        if kl_dist > (2.0 * self.kl_threshold):
+            lr = max(current_lr / 1.5, self.min_lr)
+        if kl_dist < (0.5 * self.kl_threshold):
+            lr = min(current_lr * 1.5, self.max_lr)
+        return lr, entropy_coef
+
+
+class DefaultRewardsShaper:
+    def __init__(self, scale_value=1, shift_value=0, min_val=-float("inf"), max_val=float("inf")):
+        self.scale_value, self.shift_value, self.min_val, self.max_val = scale_value, shift_value, min_val, max_val
+        self.identity = scale_value == 1 and shift_value == 0 and min_val == -float("inf") and max_val == float("inf")
+
+    def __call__(self, reward):
+        if self.identity:
+            return reward
+        reward = (reward + self.shift_value) * self.scale_value
+        return torch.clamp(reward, self.min_val, self.max_val)

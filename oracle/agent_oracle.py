@@ -1,0 +1,335 @@
+"""PyTorch-CPU restatement of the learner path: CommonAgent + the rl_games pieces it inherits.
+
+ORACLE / TEST INFRASTRUCTURE -- never imported by ``pulse_amd``.  Used by tests/ (parity on
+identical recorded rollouts) and by bench.py's ``cpu_baseline`` leg (kind "port": the reference's
+agent cannot be imported here because rl_games / isaacgym / gym are absent).
+
+Everything is plain eager PyTorch: nn.Linear modules, autograd, torch.optim.Adam,
+nn.utils.clip_grad_norm_, the reference's time-major (T, N, .) experience buffer and its
+transposing ``swap_and_flatten01``.  Line references are to /root/reference.
+
+  OracleRunningMeanStd   phc/utils/running_mean_std.py:9-109   (pinned: tests/golden/rms.npz)
+  OracleNet              network_builder.py:188-291 + amp_network_builder.py:19-40,127-148,206-211 (MLP branch),
+                         ModelA2CContinuousLogStd (rl_games 1.1.4) -- UNPINNED 3P boundary
+  OracleEnv              HumanoidIm.step over a recorded rollout (humanoid.py:1315-1331 order)
+  OracleCommonAgent      phc/learning/common_agent.py:36-98,191-599 (GAE / losses pinned: tests/golden/agent_math.npz)
+"""
+import math
+import time
+
+import torch
+import torch.nn as nn
+
+from . import env_oracle as E
+
+
+class OracleRunningMeanStd(nn.Module):
+    """phc/utils/running_mean_std.py (non-per-channel branch)."""
+
+    def __init__(self, insize, epsilon=1e-05):
+        super().__init__()
+        self.insize = insize
+        self.mean_size = insize[0]
+        self.epsilon = epsilon
+        self.register_buffer("running_mean", torch.zeros(insize, dtype=torch.float64))
+        self.register_buffer("running_var", torch.ones(insize, dtype=torch.float64))
+        self.register_buffer("count", torch.ones((), dtype=torch.float64))
+        self.forzen = False
+
+    def freeze(self):
+        self.forzen = True
+
+    def forward(self, input, unnorm=False):
+        mean, var = self.running_mean, self.running_var
+        if unnorm:
+            y = torch.clamp(input, min=-5.0, max=5.0)
+            y = torch.sqrt(var.float() + self.epsilon) * y + mean.float()
+        else:
+            y = (input - mean.float()) / torch.sqrt(var.float() + self.epsilon)
+            y = torch.clamp(y, min=-5.0, max=5.0)
+        if self.training and not self.forzen:
+            bm, bv, bc = input.mean([0]), input.var([0]), input.size()[0]
+            delta = bm - mean
+            tot = self.count + bc
+            new_mean = mean + delta * bc / tot
+            m2 = var * self.count + bv * bc + delta ** 2 * self.count * bc / tot
+            self.running_mean, self.running_var, self.count = new_mean, m2 / tot, tot
+        return y
+
+
+class OracleNet(nn.Module):
+    """AMPBuilder.Network (MLP branch, no discriminator) + the Gaussian log-std model wrapper."""
+
+    def __init__(self, obs_dim, actions_num, units, activation="relu", sigma_val=-2.9):
+        super().__init__()
+        act = {"relu": nn.ReLU, "silu": nn.SiLU}[activation]
+
+        def mlp():
+            layers, i = [], obs_dim
+            for u in units:
+                layers += [nn.Linear(i, u), act()]
+                i = u
+            return nn.Sequential(*layers)
+        # construction order of A2CBuilder.Network.__init__ (network_builder.py:245-261)
+        self.actor_mlp = mlp()
+        self.critic_mlp = mlp()
+        self.value = nn.Linear(units[-1], 1)
+        self.mu = nn.Linear(units[-1], actions_num)
+        for m in self.modules():                                   # :273-277 default init, zero biases
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.bias)
+        self.sigma = nn.Parameter(torch.full((actions_num,), float(sigma_val)), requires_grad=False)   # amp_network_builder.py:22-27
+
+    def eval_actor(self, obs):
+        mu = self.mu(self.actor_mlp(obs))
+        return mu, mu * 0.0 + self.sigma                           # amp_network_builder.py:142-148
+
+    def eval_critic(self, obs):
+        return self.value(self.critic_mlp(obs))
+
+    def state_dict_ref(self):
+        return {"a2c_network." + k: v.detach().clone() for k, v in self.state_dict().items()}
+
+    @staticmethod
+    def neglogp(x, mean, std, logstd):
+        return 0.5 * (((x - mean) / std) ** 2).sum(dim=-1) + 0.5 * math.log(2.0 * math.pi) * x.size()[-1] + logstd.sum(dim=-1)
+
+    def forward(self, d):
+        """ModelA2CContinuousLogStd.Network.forward (rl_games 3P)."""
+        mu, logstd = self.eval_actor(d["obs"])
+        value = self.eval_critic(d["obs"])
+        sigma = torch.exp(logstd)
+        if d.get("is_train", True):
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
+            return {"prev_neglogp": torch.squeeze(self.neglogp(d["prev_actions"], mu, sigma, logstd)), "values": value,
+                    "entropy": entropy, "mus": mu, "sigmas": sigma}
+        noise = d["noise"] if d.get("noise") is not None else torch.randn_like(mu)
+        action = mu + sigma * noise                                 # Normal(mu, sigma).sample()
+        return {"neglogpacs": torch.squeeze(self.neglogp(action, mu, sigma, logstd)), "values": value, "actions": action,
+                "mus": mu, "sigmas": sigma}
+
+
+def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma, reduce=True):
+    """rl_games torch_ext.policy_kl."""
+    c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
+    c2 = (p0_sigma ** 2 + (p1_mu - p0_mu) ** 2) / (2.0 * (p1_sigma ** 2 + 1e-5))
+    kl = (c1 + c2 + -0.5).sum(dim=-1)
+    return kl.mean() if reduce else kl
+
+
+def swap_and_flatten01(arr):
+    s = arr.size()
+    return arr.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+class OracleEnv:
+    """HumanoidIm over a RecordedRollout, on the CPU, with the reference's step order."""
+
+    def __init__(self, rollout, reset_body_ids, track_body_ids):
+        self.r = rollout
+        self.num_envs = rollout.num_envs
+        self.frame = 0
+        self.rb = rollout.data["rb"][0].clone()
+        self.progress_buf = rollout.init_progress.clone()
+        self.reset_ids, self.track_ids = reset_body_ids, track_body_ids
+        self.term_dist = torch.full((1, 24), 0.25)
+        self.obs_buf = torch.zeros(self.num_envs, 934)
+        self.dt = rollout.dt
+
+    def _ref(self, d):
+        return {k: v[self.frame] for k, v in d.items()}
+
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            env_ids = torch.arange(self.num_envs)
+        if len(env_ids) > 0:
+            self.rb[env_ids] = self.r.data["reset_rb"][self.frame][env_ids]
+            self.progress_buf[env_ids] = 0
+            bp, br, bv, ba = E.split_rb(self.rb[env_ids])
+            rx = {k: v[env_ids] for k, v in self._ref(self.r.ref_next_reset).items()}
+            so = E.self_obs_smpl_max(bp, br, bv, ba)
+            tb = self.track_ids
+            to = E.im_obs_v6(bp[:, 0], br[:, 0], bp[:, tb], br[:, tb], bv[:, tb], ba[:, tb], rx["pos"][:, tb], rx["rot"][:, tb],
+                             rx["vel"][:, tb], rx["ang"][:, tb], 1)
+            self.obs_buf[env_ids] = torch.cat([so, to], dim=-1)
+        return self.obs_buf
+
+    def step(self, actions):
+        actions = torch.clamp(actions, -1.0, 1.0)                        # VecTaskPython.step
+        self.frame = (self.frame + 1) % self.r.num_frames                 # physics: recorded
+        self.rb = self.r.data["rb"][self.frame].clone()
+        self.progress_buf += 1
+        t = self.progress_buf * self.dt + self.r.motion_start_times
+        pass_time = t >= self.r.motion_lengths
+        out = E.post_physics(self.rb, self._ref(self.r.ref_now), self._ref(self.r.ref_next), self.r.data["dof_force"][self.frame],
+                             self.r.data["dof_vel"][self.frame], self.progress_buf, pass_time, self.reset_ids, self.track_ids,
+                             self.term_dist)
+        self.obs_buf = out["obs"]
+        return self.obs_buf, out["rew"], out["reset"], {"terminate": out["terminate"], "reward_raw": out["raw"]}
+
+
+class OracleCommonAgent:
+    """phc/learning/common_agent.py restated on the CPU (fp32, eager)."""
+
+    def __init__(self, config, env, units, seed=0, noise=None):
+        self.env = env
+        self.num_actors = env.num_envs
+        self.horizon_length = config["horizon_length"]
+        self.gamma, self.tau = config["gamma"], config["tau"]
+        self.e_clip, self.critic_coef = config["e_clip"], config["critic_coef"]
+        self.bounds_loss_coef = config.get("bounds_loss_coef", None)
+        self.clip_value = config["clip_value"]
+        self.grad_norm, self.truncate_grads = config["grad_norm"], config["truncate_grads"]
+        self.mini_epochs_num, self.minibatch_size = config["mini_epochs"], config["minibatch_size"]
+        self.normalize_advantage = config["normalize_advantage"]
+        self.batch_size = self.horizon_length * self.num_actors
+        self.last_lr = float(config["learning_rate"])
+        self.actions_num, obs_dim = 69, 934
+        self.model = OracleNet(obs_dim, self.actions_num, units, config["network"]["mlp"]["activation"],
+                               config["network"]["space"]["continuous"]["sigma_init"]["val"])
+        self.running_mean_std = OracleRunningMeanStd((obs_dim,))
+        self.value_mean_std = OracleRunningMeanStd((1,))
+        self.optimizer = torch.optim.Adam(self.model.parameters(), self.last_lr, eps=1e-08, weight_decay=0.0)   # :66
+        g = torch.Generator()
+        g.manual_seed(seed)
+        self._perm_gen = g
+        self._idx_buf = torch.randperm(self.batch_size, generator=g)                                             # amp_datasets.py:7
+        self.noise = noise                      # optional (epochs, T, N, A) tensor shared with the device run
+        self.epoch = 0
+        t, n = self.horizon_length, self.num_actors
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype)
+        self.tensor_dict = {"obses": z(t, n, obs_dim), "rewards": z(t, n, 1), "values": z(t, n, 1), "neglogpacs": z(t, n),
+                            "dones": z(t, n, dtype=torch.uint8), "actions": z(t, n, 69), "mus": z(t, n, 69), "sigmas": z(t, n, 69)}
+        self.tensor_dict["next_obses"] = torch.zeros_like(self.tensor_dict["obses"])                              # :92-98
+        self.tensor_dict["next_values"] = torch.zeros_like(self.tensor_dict["values"])
+        self.update_list = ["actions", "neglogpacs", "values", "mus", "sigmas"]
+        self.tensor_list = self.update_list + ["obses", "dones", "next_obses"]
+        self.obs = None
+        self.grad_norms = []
+
+    def set_eval(self):
+        self.model.eval(); self.running_mean_std.eval(); self.value_mean_std.eval()
+
+    def set_train(self):
+        self.model.train(); self.running_mean_std.train(); self.value_mean_std.train()
+
+    # :262-288
+    def get_action_values(self, obs, noise):
+        processed = self.running_mean_std(obs)
+        self.model.eval()
+        with torch.no_grad():
+            res = self.model({"is_train": False, "prev_actions": None, "obs": processed, "noise": noise})
+        res["values"] = self.value_mean_std(res["values"], True)
+        return res
+
+    # :551-562
+    def _eval_critic(self, obs):
+        self.model.eval()
+        value = self.model.eval_critic(self.running_mean_std(obs))
+        return self.value_mean_std(value, True)
+
+    # :290-355
+    def play_steps(self):
+        self.set_eval()
+        done_indices = []
+        td = self.tensor_dict
+        for n in range(self.horizon_length):
+            self.obs = self.env.reset(done_indices)
+            td["obses"][n, :] = self.obs
+            noise = self.noise[self.epoch, n] if self.noise is not None else None
+            res = self.get_action_values(self.obs, noise)
+            for k in self.update_list:
+                td[k][n, :] = res[k]
+            self.obs, rewards, self.dones, infos = self.env.step(res["actions"])
+            rewards = rewards.unsqueeze(1)
+            td["rewards"][n, :] = rewards
+            td["next_obses"][n, :] = self.obs
+            td["dones"][n, :] = self.dones
+            terminated = infos["terminate"].float().unsqueeze(-1)
+            next_vals = self._eval_critic(self.obs)
+            next_vals *= (1.0 - terminated)
+            td["next_values"][n, :] = next_vals
+            all_done_indices = self.dones.nonzero(as_tuple=False)
+            done_indices = all_done_indices[:, 0]
+        mb_fdones = td["dones"].float()
+        mb_advs = E.gae(mb_fdones, td["values"], td["rewards"], td["next_values"], self.gamma, self.tau)       # :493-505
+        mb_returns = mb_advs + td["values"]
+        batch_dict = {k: swap_and_flatten01(td[k]) for k in self.tensor_list}
+        batch_dict["returns"] = swap_and_flatten01(mb_returns)
+        batch_dict["advs_raw"] = swap_and_flatten01(mb_advs)
+        return batch_dict
+
+    # :357-398, :589-599
+    def prepare_dataset(self, bd):
+        advantages = torch.sum(bd["returns"] - bd["values"], axis=1)
+        if self.normalize_advantage:
+            advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+        values = self.value_mean_std(bd["values"])
+        returns = self.value_mean_std(bd["returns"])
+        self.values_dict = {"old_values": values, "old_logp_actions": bd["neglogpacs"], "advantages": advantages, "returns": returns,
+                            "actions": bd["actions"], "obs": bd["obses"], "mu": bd["mus"], "sigma": bd["sigmas"]}
+        return self.values_dict
+
+    def _get_item(self, idx):                                                                                    # amp_datasets.py:81-100
+        start, end = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
+        sample_idx = self._idx_buf[start:end]
+        out = {k: v[sample_idx] for k, v in self.values_dict.items()}
+        if end >= self.batch_size:
+            self._idx_buf = torch.randperm(self.batch_size, generator=self._perm_gen)
+        return out
+
+    # :400-491, :512-520, :564-587
+    def calc_gradients(self, d):
+        self.set_train()
+        obs_batch = self.running_mean_std(d["obs"])
+        res = self.model({"is_train": True, "prev_actions": d["actions"], "obs": obs_batch})
+        action_log_probs, values, mu, sigma = res["prev_neglogp"], res["values"], res["mus"], res["sigmas"]
+        ratio = torch.exp(d["old_logp_actions"] - action_log_probs)
+        surr1 = d["advantages"] * ratio
+        surr2 = d["advantages"] * torch.clamp(ratio, 1.0 - self.e_clip, 1.0 + self.e_clip)
+        a_loss = torch.max(-surr1, -surr2)
+        if self.clip_value:
+            vpc = d["old_values"] + (values - d["old_values"]).clamp(-self.e_clip, self.e_clip)
+            c_loss = torch.max((values - d["returns"]) ** 2, (vpc - d["returns"]) ** 2)
+        else:
+            c_loss = (d["returns"] - values) ** 2
+        if self.bounds_loss_coef is not None:
+            b_loss = (torch.clamp_max(mu + 1.0, 0.0) ** 2 + torch.clamp_min(mu - 1.0, 0.0) ** 2).sum(axis=-1)
+        else:
+            b_loss = torch.zeros(1)
+        a_loss, c_loss, b_loss, entropy = torch.mean(a_loss), torch.mean(c_loss), torch.mean(b_loss), torch.mean(res["entropy"])
+        loss = a_loss + self.critic_coef * c_loss - 0.0 * entropy + (self.bounds_loss_coef or 0.0) * b_loss
+        for p in self.model.parameters():
+            p.grad = None
+        loss.backward()
+        gn = None
+        if self.truncate_grads:
+            gn = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+        self.optimizer.step()
+        with torch.no_grad():
+            kl = policy_kl(mu.detach(), sigma.detach(), d["mu"], d["sigma"], True)
+        self.grad_norms.append(float(gn) if gn is not None else float("nan"))
+        return {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "kl": kl, "grad_norm": gn}
+
+    # :191-260
+    def train_epoch(self, max_minibatches=None):
+        if self.obs is None:
+            self.obs = self.env.reset()
+        t0 = time.time()
+        with torch.no_grad():
+            batch_dict = self.play_steps()
+        t1 = time.time()
+        self.set_train()
+        self.prepare_dataset(batch_dict)
+        infos = []
+        nmb = self.batch_size // self.minibatch_size
+        done = 0
+        for _ in range(self.mini_epochs_num):
+            for i in range(nmb):
+                if max_minibatches is not None and done >= max_minibatches:
+                    break
+                infos.append(self.calc_gradients(self._get_item(i)))
+                done += 1
+        t2 = time.time()
+        self.epoch += 1
+        return {"batch_dict": batch_dict, "infos": infos, "play_time": t1 - t0, "update_time": t2 - t1, "minibatches": done}

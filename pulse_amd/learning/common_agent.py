@@ -130,6 +130,8 @@ class CommonAgent:
         self.game_rewards = rlg.AverageMeter((self.value_size,), self.games_to_track, self.ppo_device)
         self.game_lengths = rlg.AverageMeter((1,), self.games_to_track, self.ppo_device)
         self.train_result = {}
+        self.noise_provider = None
+        self.epoch_counter = 0
         self._entropy = None
         self._tensors_ready = False
 
@@ -229,7 +231,10 @@ class CommonAgent:
         ap = net.a_pitch
         s = 0 if slot is None else slot
         net.forward(ws, n, mu_out=eb.phys["mus"], mu_ld=t * ap, mu_off=s * ap)
-        noise = torch.randn(n, self.actions_num, device=self.ppo_device, generator=self.noise_generator)
+        if self.noise_provider is not None:        # parity tests share pre-drawn noise with the CPU oracle
+            noise = self.noise_provider(self.epoch_counter, s)
+        else:
+            noise = torch.randn(n, self.actions_num, device=self.ppo_device, generator=self.noise_generator)
         vm = self.value_mean_std
         K.policy_sample(eb.phys["mus"], t * ap, net.sigma, noise, self.actions_num, n, self.actions_num,
                         eb.phys["actions"], t * ap, eb.phys["neglogpacs"], t, sigmas=eb.phys["sigmas"], sigmas_stride=t * ap,
@@ -420,6 +425,7 @@ class CommonAgent:
                 self.update_lr(self.last_lr)
         torch.cuda.synchronize()
         update_time_end = time.time()
+        self.epoch_counter += 1
         train_info["play_time"] = play_time_end - play_time_start
         train_info["update_time"] = update_time_end - update_time_start
         train_info["total_time"] = update_time_end - play_time_start

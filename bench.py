@@ -1,0 +1,189 @@
+"""Headline benchmark: env-steps/sec through the PPO update (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``agent.train_epoch()`` over one synthetic rollout batch: T=32 env steps of the fused
+observation / imitation-reward / reset kernel + actor/critic inference + experience-buffer writes for
+N=4096 SMPL humanoids, GAE, dataset prep, and 6 x 8 PPO minibatch steps (forward, losses, backward,
+[RCCL all-reduce], clip, Adam) on the [1024, 512] actor + critic -- BASELINE.json configs[1].
+All inputs are resident in HBM before the timed region.  With N > 1 every rank owns its own 4096
+environments (weak scaling, envs shard with no data-path collective; the one exchange per optimiser
+step is the flat-gradient all-reduce).
+
+Prints ONE JSON line on rank 0.  ``roofline`` is measured live: every launch of the dominant
+kernel (gemm_f32_kernel, the fp32 MFMA GEMM) inside the timed region is bracketed by a HIP event
+pair on the launch stream; achieved = algorithmic FLOPs / summed kernel time.  ``cpu_baseline`` is
+the PyTorch-CPU oracle agent (oracle/agent_oracle.py, kind "port") timed on the host cores on a
+bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-minibatches", type=int, default=4, help="PPO minibatch steps timed on the CPU oracle")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="rollout steps timed on the CPU oracle")
+    ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock bound of the CPU baseline subprocess (s)")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-roofline", action="store_true", help="do not bracket GEMM launches with events")
+    return ap.parse_args()
+
+
+def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches):
+    """Runs in a SUBPROCESS (hard wall-clock bound): the oracle agent on the host cores for a bounded
+    sample -- ``sample_steps`` of the T rollout steps and ``n_minibatches`` PPO minibatch steps at the
+    full N and the full minibatch size -- extrapolated linearly to the whole epoch."""
+    import torch
+    from oracle import agent_oracle as AO
+    from pulse_amd import configs, synthetic as syn
+    from pulse_amd.env.sim import RecordedRollout
+    cores = torch.get_num_threads()                         # PyTorch's own default intra-op pool: what the reference would use
+    cfg, num_envs = configs.agent_config(cfg_name)
+    T = cfg["horizon_length"]
+    total_mb = cfg["mini_epochs"] * (T * num_envs // cfg["minibatch_size"])
+    scfg = dict(cfg)
+    scfg["horizon_length"] = sample_steps
+    assert sample_steps * num_envs % cfg["minibatch_size"] == 0
+    rollout = RecordedRollout(num_envs, sample_steps + 1, seed=seed)
+    torch.manual_seed(seed)
+    env = AO.OracleEnv(rollout, syn.RESET_BODY_IDS, list(range(24)))
+    agent = AO.OracleCommonAgent(scfg, env, cfg["network"]["mlp"]["units"], seed=seed)
+    agent.obs = env.reset()
+    t0 = time.time()
+    r = agent.train_epoch(max_minibatches=n_minibatches)
+    wall = time.time() - t0
+    per_step = r["play_time"] / sample_steps
+    per_mb = r["update_time"] / max(1, r["minibatches"])
+    epoch_s = per_step * T + per_mb * total_mb
+    return {"value": T * num_envs / epoch_s, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cfg_name} at full width ({num_envs} envs, minibatch {cfg['minibatch_size']}): {sample_steps} of {T} rollout steps "
+                      f"({r['play_time']:.1f} s) + {r['minibatches']} of {total_mb} PPO minibatch steps ({r['update_time']:.1f} s), each extrapolated "
+                      f"linearly to the epoch; {wall:.1f} s of CPU work; oracle/agent_oracle.py, torch {torch.__version__} eager fp32, "
+                      f"{cores} intra-op threads of {os.cpu_count()} logical CPUs",
+            "rollout_s_per_step": per_step, "update_s_per_minibatch": per_mb, "epoch_s_extrapolated": epoch_s}
+
+
+def cpu_baseline(cfg_name, seed, sample_steps, n_minibatches, budget_s):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", cfg_name, "--cpu-steps", str(sample_steps),
+           "--cpu-minibatches", str(n_minibatches)]
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""                           # the worker never touches the GPU
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=budget_s, env=env)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"value": None, "unit": "env-steps/s", "cores": None, "kind": "port", "sample": f"worker failed: {p.stderr[-300:]}"}
+        return json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "env-steps/s", "cores": None, "kind": "port", "sample": f"worker exceeded its {budget_s} s budget"}
+
+
+def main():
+    a = parse()
+    if a.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker(a.config, 1234, a.cpu_steps, a.cpu_minibatches)), flush=True)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    from pulse_amd import _lib, configs, kernels
+    from pulse_amd.env.sim import RecordedRollout
+    from pulse_amd.parallel import DistContext
+    _lib.load()                                                   # fail loudly before anything else if the HIP library is missing
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    dist = DistContext(enabled=world > 1)
+    seed = 1234
+    cfg, num_envs = configs.agent_config(a.config)
+    T = cfg["horizon_length"]
+    rollout_cpu = RecordedRollout(num_envs, T + 1, seed=seed, rank=rank)     # synthetic rollout inputs, seed 1234 + rank
+    log(f"rank {rank}: synthetic rollout generated")
+    agent, _ = configs.make_agent(a.config, device=device, seed=seed, rank=rank, rollout=rollout_cpu, multi_gpu=world > 1, dist=dist)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent._tensors_ready = True
+    if world > 1:
+        dist.setup_algo(agent.model.flat, (agent.model.sigma, agent.exp_avg, agent.exp_avg_sq))
+
+    log(f"rank {rank}: agent ready, warmup")
+    for _ in range(a.warmup):
+        agent.train_epoch()
+    log(f"rank {rank}: timing {a.steps} steps")
+    prof = kernels.PROFILER
+    dist.barrier()
+    torch.cuda.synchronize()
+    if not a.no_roofline:
+        prof.start()
+    t0 = time.perf_counter()
+    play = upd = 0.0
+    for _ in range(a.steps):
+        info = agent.train_epoch()
+        play += info["play_time"]
+        upd += info["update_time"]
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof.stop()
+    elapsed = dist.max_over_ranks(elapsed)
+    log(f"rank {rank}: timed region done: {elapsed:.3f} s")
+
+    env_steps = a.steps * T * num_envs * world
+    out = {
+        "metric": "env-steps/sec through PPO update", "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.config}: {num_envs} SMPL-humanoid envs/GPU x horizon {T}, imitation obs/reward/reset + PPO "
+                               f"(actor+critic MLP {cfg['network']['mlp']['units']}, minibatch {cfg['minibatch_size']} x {cfg['mini_epochs']} mini-epochs)",
+                   "num_envs_per_gpu": num_envs, "horizon": T, "global_batch": T * num_envs * world, "parallelism": f"dp{world}"},
+        "play_ms_per_step": 1e3 * play / a.steps, "update_ms_per_step": 1e3 * upd / a.steps,
+    }
+    if not a.no_roofline:
+        s = prof.summary()
+        n = sum(v[0] for v in s.values())
+        t = sum(v[1] for v in s.values())
+        f = sum(v[2] for v in s.values())
+        out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": f / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_f32_kernel",
+                           "launches": n, "avg_us": 1e6 * t / max(1, n), "kernel_time_frac_of_step": t / elapsed,
+                           "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in s.items()}}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("timing the CPU oracle (subprocess, bounded)")
+        out["cpu_baseline"] = cpu_baseline(a.config, seed, a.cpu_steps, a.cpu_minibatches, a.cpu_budget)
+        if out["cpu_baseline"]["value"]:
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,10 +18,43 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
+class GemmProfiler:
+    """Brackets every pulse_gemm_f32 launch with a HIP event pair on the launch stream (torch's
+    current stream IS the stream the kernels are enqueued on) and tallies algorithmic FLOPs.
+    Used by bench.py for the live roofline figure; off by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (start_event, end_event, flops, tag)
+        self._pool = []
+
+    def start(self):
+        self.enabled, self.records = True, []
+
+    def stop(self):
+        self.enabled = False
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+
+    def summary(self):
+        """-> dict tag -> (launches, seconds, flops); call after a synchronize."""
+        out = {}
+        for s, e, fl, tag in self.records:
+            n, t, f = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, t + s.elapsed_time(e) * 1e-3, f + fl)
+            self._pool += [s, e]
+        self.records = []
+        return out
+
+
+PROFILER = GemmProfiler()
+
+
 def gemm(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, bias=None,
          activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
          stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
-         a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0):
+         a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None):
     """C[m][n] = epilogue(sum_k A(m,k) B(n,k)).  A/B/C/... are tensors used only as base pointers
     (+ *_off floats); all geometry is explicit (pitches in floats)."""
     d = GemmDesc()
@@ -37,6 +70,14 @@ def gemm(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=
     d.stride_a, d.stride_b, d.stride_c, d.stride_c2 = stride_a, stride_b, stride_c, stride_c2
     d.stride_bias, d.stride_aux = stride_bias, stride_aux
     d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
+    if PROFILER.enabled:
+        ev0, ev1 = PROFILER._event(), PROFILER._event()
+        ev0.record()
+        _lib.check(_lib.load().pulse_gemm_f32(ctypes.byref(d), _stream()), "pulse_gemm_f32")
+        ev1.record()
+        tag = ("fwd" if b_layout == GEMM_RED_CONTIG else "dx") if a_layout == GEMM_RED_CONTIG else "dw"
+        PROFILER.records.append((ev0, ev1, 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch, tag))
+        return
     _lib.check(_lib.load().pulse_gemm_f32(ctypes.byref(d), _stream()), "pulse_gemm_f32")
 
 

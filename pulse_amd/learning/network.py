@@ -217,7 +217,7 @@ class A2CNetwork:
         for l, uu in enumerate(u):
             k = self.in_w[l]
             if l == 0:
-                K.gemm(ws["x"], f, ws["h"][0], M=m, N=cnt * uu, K=k, lda=k, ldb=k, ldc=2 * uu, bias=f, activation=self.act,
+                K.gemm(ws["x"], f, ws["h"][0], M=m, N=cnt * uu, K=k, lda=k, ldb=k, ldc=2 * uu, bias=f, activation=self.act, algo_k=self.in_dim,
                        b_off=self.w_off[0] + n0 * uu * k, bias_off=self.b_off[0] + n0 * uu, c_off=n0 * uu,
                        C2=pre[0] if pre else None, ldc2=2 * uu, c2_off=n0 * uu)
             else:
@@ -276,7 +276,7 @@ class A2CNetwork:
             K.colsum_partial(dz, m, 2 * uu, 2 * uu, S, slabs, P, partial_off=self.b_off[l])
             if l == 0:
                 K.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
-                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P)
+                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P, algo_n=self.in_dim)
             else:
                 up = u[l - 1]
                 K.gemm(dz, ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,

@@ -245,19 +245,45 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
 }
 
 // ---- column sums (bias gradients): partial[chunk][n] = sum over the chunk's rows of X[m][n] ------
+// HBM-bound (each dZ element read once).  256 threads = 64 column groups (one float4 = 4 columns each,
+// so a row segment of 1 KiB is read per 64 lanes) x 4 row lanes; 4 independent loads in flight per thread.
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ X, int M, int N, int ld, int rows_per_chunk,
                                                             float* __restrict__ partial, long long ldp) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    __shared__ float4 red[4][64];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + cg * 4;
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(M, r0 + rows_per_chunk);
-    float s = 0.f;
-    if (c < N)
-        for (int r = r0 + rl; r < r1; r += 4) s += X[(long long)r * ld + c];
-    red[rl][threadIdx.x & 63] = s;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (c < N) {
+        const float* p = X + c;
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (long long)r * ld);
+            const float4 b = *reinterpret_cast<const float4*>(p + (long long)(r + 4) * ld);
+            const float4 cc = *reinterpret_cast<const float4*>(p + (long long)(r + 8) * ld);
+            const float4 d = *reinterpret_cast<const float4*>(p + (long long)(r + 12) * ld);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s2.x += cc.x; s2.y += cc.y; s2.z += cc.z; s2.w += cc.w;
+            s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+        }
+        for (; r < r1; r += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (long long)r * ld);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    s0.x += s1.x + s2.x + s3.x; s0.y += s1.y + s2.y + s3.y; s0.z += s1.z + s2.z + s3.z; s0.w += s1.w + s2.w + s3.w;
+    red[rl][cg] = s0;
     __syncthreads();
-    if (rl == 0 && c < N) partial[(long long)blockIdx.y * ldp + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (rl == 0 && c < N) {
+        const float4 a = red[0][cg], b = red[1][cg], cc = red[2][cg], d = red[3][cg];
+        float* o = partial + (long long)blockIdx.y * ldp + c;
+        o[0] = a.x + b.x + cc.x + d.x;
+        if (c + 1 < N) o[1] = a.y + b.y + cc.y + d.y;
+        if (c + 2 < N) o[2] = a.z + b.z + cc.z + d.z;
+        if (c + 3 < N) o[3] = a.w + b.w + cc.w + d.w;
+    }
 }
 
 }  // namespace pulse
@@ -335,9 +361,10 @@ int pulse_colsum_partial(const float* x, int32_t m, int32_t n, int32_t ld, int32
                          pulse_stream_t s) {
     PULSE_REQUIRE(m >= 0 && n >= 0 && num_chunks >= 1, "pulse_colsum_partial: bad sizes");
     if (n == 0) return PULSE_OK;
-    PULSE_REQUIRE(x && partial && ld >= n && ld_partial >= n, "pulse_colsum_partial: bad pointers / pitches");
+    PULSE_REQUIRE(x && partial && ld >= ((n + 3) & ~3) && ld_partial >= n, "pulse_colsum_partial: bad pointers / pitches (ld must cover roundup4(n))");
+    PULSE_REQUIRE((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "pulse_colsum_partial: x rows must be 16-byte aligned");
     const int rows = (m + num_chunks - 1) / num_chunks;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)num_chunks), dim3(256), 0, as_stream(s), x, m, n, ld,
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)num_chunks), dim3(256), 0, as_stream(s), x, m, n, ld,
                        rows > 0 ? rows : 1, partial, (long long)ld_partial);
     return check_launch("pulse_colsum_partial");
 }

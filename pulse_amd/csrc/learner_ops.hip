@@ -83,6 +83,67 @@ __global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __
     }
 }
 
+// 16-byte variant of the wide kernel: each thread owns groups of 4 adjacent columns (a wave reads 1 KiB
+// of a row per instruction).  Needs 16-byte aligned rows on both sides and y_cols % 4 == 0.
+constexpr int kRmsVecGroups = 2;   // 256 threads x 4 columns x 2 groups = 2048 columns
+
+__global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
+                                                                const long long* __restrict__ row_idx, int rows, int cols,
+                                                                const double* __restrict__ mean, const double* __restrict__ var,
+                                                                float eps, float clip, int mode, float* __restrict__ y,
+                                                                long long y_stride, int y_cols, double* __restrict__ partials) {
+    const int tid = threadIdx.x;
+    const int nblk = gridDim.x;
+    const int per = (rows + nblk - 1) / nblk;
+    const int r0 = blockIdx.x * per;
+    const int r1 = min(rows, r0 + per);
+    float mu[kRmsVecGroups][4], den[kRmsVecGroups][4];
+    double s1[kRmsVecGroups][4], s2[kRmsVecGroups][4];
+#pragma unroll
+    for (int j = 0; j < kRmsVecGroups; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (tid + 256 * j) * 4 + k;
+            s1[j][k] = 0.0; s2[j][k] = 0.0;
+            if (c < cols) { mu[j][k] = (float)mean[c]; den[j][k] = sqrtf((float)var[c] + eps); }
+            else { mu[j][k] = 0.f; den[j][k] = 1.f; }
+        }
+    for (int r = r0; r < r1; ++r) {
+        const long long src = row_idx ? row_idx[r] : (long long)r;
+        const float* xr = x + src * x_stride;
+        float* yr = y + (long long)r * y_stride;
+#pragma unroll
+        for (int j = 0; j < kRmsVecGroups; ++j) {
+            const int c = (tid + 256 * j) * 4;
+            if (c < y_cols) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < cols) v = *reinterpret_cast<const float4*>(xr + c);      // x rows are padded to the same pitch
+                float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (c + k < cols) {
+                        s1[j][k] += (double)in[k]; s2[j][k] += (double)in[k] * (double)in[k];
+                        o[k] = mode == 0 ? clampf((in[k] - mu[j][k]) / den[j][k], -clip, clip) : den[j][k] * clampf(in[k], -clip, clip) + mu[j][k];
+                    } else {
+                        o[k] = 0.f;
+                    }
+                }
+                *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (partials) {
+        double* p = partials + (long long)blockIdx.x * 2 * cols;
+#pragma unroll
+        for (int j = 0; j < kRmsVecGroups; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = (tid + 256 * j) * 4 + k;
+                if (c < cols) { p[c] = s1[j][k]; p[cols + c] = s2[j][k]; }
+            }
+    }
+}
+
 // narrow matrices (cols < 64, e.g. the (B,1) value tensor): threads own rows.
 __global__ void __launch_bounds__(256) rms_normalize_narrow_kernel(const float* __restrict__ x, long long x_stride,
                                                                   const long long* __restrict__ row_idx, int rows, int cols,
@@ -123,16 +184,24 @@ __global__ void __launch_bounds__(256) rms_normalize_narrow_kernel(const float* 
         for (int c = cols; c < y_cols; ++c) y[(long long)r * y_stride + c] = 0.f;
 }
 
-__global__ void __launch_bounds__(64) rms_update_kernel(double* __restrict__ mean, double* __restrict__ var, double* __restrict__ count_out,
-                                                       const double* __restrict__ partials, int nblk, int cols, double count,
-                                                       double n) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(256) rms_update_kernel(double* __restrict__ mean, double* __restrict__ var, double* __restrict__ count_out,
+                                                        const double* __restrict__ partials, int nblk, int cols, double count,
+                                                        double n) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
     if (c < cols) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < nblk; ++b) {
+        for (int b = pl; b < nblk; b += 4) {
             s1 += partials[(long long)b * 2 * cols + c];
             s2 += partials[(long long)b * 2 * cols + cols + c];
         }
+    }
+    red[0][pl][cl] = s1; red[1][pl][cl] = s2;
+    __syncthreads();
+    if (pl == 0 && c < cols) {
+        s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
         const double bm = s1 / n;
         // unbiased variance like torch.var: sum (x - mean)^2 / (n - 1)
         double bv = (s2 - n * bm * bm) / (n - 1.0);
@@ -388,7 +457,13 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
     PULSE_REQUIRE(num_blocks >= 1, "pulse_rms_normalize: num_blocks < 1");
     PULSE_REQUIRE(y_cols >= cols && y_stride >= y_cols && x_stride >= cols, "pulse_rms_normalize: bad pitches");
     PULSE_REQUIRE(mode == 0 || mode == 1, "pulse_rms_normalize: bad mode");
-    if (cols >= 64)
+    const bool vec_ok = cols >= 64 && cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (y_stride % 4) == 0 && (y_cols % 4) == 0 &&
+                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                        x_stride >= ((cols + 3) & ~3);
+    if (vec_ok)
+        hipLaunchKernelGGL(rms_normalize_vec4_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
+    else if (cols >= 64)
         hipLaunchKernelGGL(rms_normalize_wide_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
     else
@@ -403,7 +478,7 @@ int pulse_rms_update(double* mean, double* var, double* count_out, const double*
     if (cols == 0) return PULSE_OK;
     PULSE_REQUIRE(mean && var && moment_partials, "pulse_rms_update: null pointer");
     PULSE_REQUIRE(batch_count >= 2.0, "pulse_rms_update: batch of %g rows has no unbiased variance", batch_count);
-    hipLaunchKernelGGL(rms_update_kernel, dim3((cols + 63) / 64), dim3(64), 0, as_stream(s), mean, var, count_out, moment_partials, num_blocks,
+    hipLaunchKernelGGL(rms_update_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(s), mean, var, count_out, moment_partials, num_blocks,
                        cols, count_old, batch_count);
     return check_launch("pulse_rms_update");
 }

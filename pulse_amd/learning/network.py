@@ -205,6 +205,8 @@ class A2CNetwork:
             ws["dval"] = torch.zeros(m, 4, dtype=torch.float32, device=dev)
             if self._slabs is None:
                 self._slabs = torch.zeros(self.split_k, self.n_flat, dtype=torch.float32, device=dev)
+                self._bias_chunks = 64
+                self._bias_scratch = torch.zeros(self._bias_chunks, 2 * max(u) + 8, dtype=torch.float32, device=dev)
         self._ws[key] = ws
         return ws
 
@@ -249,6 +251,14 @@ class A2CNetwork:
         self._heads(ws, m, actor=False)
 
     # ------------------------------------------------------------------ backward
+    def _bias_grad(self, dz, m, n, ld, off):
+        """db = column sums of dz: 64 row chunks (enough workgroups to stream at HBM rate) into a scratch,
+        then one ordered reduce straight into slab 0 (the other slabs stay zero for bias positions)."""
+        c = self._bias_chunks if m >= 64 * 16 else 1
+        sc = self._bias_scratch
+        K.colsum_partial(dz, m, n, ld, c, sc, sc.stride(0))
+        K.reduce_slabs(sc, c, sc.stride(0), n, self._slabs, out_off=off)
+
     def backward(self, ws, m, grad_scale=1.0):
         """Given d loss / d mu in ws['dmu'] and d loss / d value in ws['dval'][:, 0], fill self.grad
         (flat, same layout as self.flat).  Deterministic: split-K slabs + one ordered reduce."""
@@ -268,12 +278,12 @@ class A2CNetwork:
                a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, c_off=self.wmu_off, split_k=S, split_stride=P)
         K.gemm(ws["dval"], ws["h"][-1], slabs, M=1, N=uL, K=m, lda=4, ldb=2 * uL, ldc=uL, a_layout=GEMM_OUT_CONTIG,
                b_layout=GEMM_OUT_CONTIG, b_off=uL, c_off=self.wv_off, split_k=S, split_stride=P)
-        K.colsum_partial(ws["dmu"], m, self.actions_num, self.a_pitch, S, slabs, P, partial_off=self.bmu_off)
-        K.colsum_partial(ws["dval"], m, 1, 4, S, slabs, P, partial_off=self.bv_off)
+        self._bias_grad(ws["dmu"], m, self.actions_num, self.a_pitch, self.bmu_off)
+        self._bias_grad(ws["dval"], m, 1, 4, self.bv_off)
         for l in range(L - 1, -1, -1):
             uu, k = u[l], self.in_w[l]
             dz = ws["dh"][l]
-            K.colsum_partial(dz, m, 2 * uu, 2 * uu, S, slabs, P, partial_off=self.b_off[l])
+            self._bias_grad(dz, m, 2 * uu, 2 * uu, self.b_off[l])
             if l == 0:
                 K.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P, algo_n=self.in_dim)

@@ -47,49 +47,59 @@ struct GemmArgs {
 };
 
 // ---- global -> register staging -------------------------------------------------------------
+// Loads are BRANCH-FREE (addresses are clamped to valid memory instead of predicated) so that nothing
+// consumes a loaded register before the MFMA block: the reduction-tail / out-of-range zeroing happens in
+// store_tile, after the compute of the current tile, when the data must have landed anyway.  (A first
+// version masked inside the load and the compiler had to put s_waitcnt vmcnt(0) right behind every load,
+// exposing the full HBM latency once per k-tile.)
 template <bool KC>
 __device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ P, int ld, int out0, int ext,
-                                          int k0, int kend, int tid) {
+                                          int k0, int kbeg, int kend, int tid) {
     if constexpr (KC) {
-        const int kq = (tid & 7) * 4;
-        const int k = k0 + kq;
+        int k = k0 + (tid & 7) * 4;
+        k = k < kend ? k : kbeg;                           // fully past the end: read something valid, masked later
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int row = out0 + (tid >> 3) + 32 * i;
-            row = row < ext ? row : ext - 1;              // clamp: rows beyond the extent are never stored
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend) {
-                v = *reinterpret_cast<const float4*>(P + (long long)row * ld + k);
-                if (k + 3 >= kend) {                       // reduction tail: zero the lanes past K
-                    if (k + 1 >= kend) v.y = 0.f;
-                    if (k + 2 >= kend) v.z = 0.f;
-                    v.w = 0.f;
-                }
-            }
-            r[i] = v;
+            row = row < ext ? row : ext - 1;              // rows beyond the extent are never stored
+            r[i] = *reinterpret_cast<const float4*>(P + (long long)row * ld + k);
         }
     } else {
-        const int m = out0 + (tid & 31) * 4;
+        int m = out0 + (tid & 31) * 4;
+        m = m < ext ? m : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = k0 + (tid >> 5) + 8 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend && m < ext) v = *reinterpret_cast<const float4*>(P + (long long)k * ld + m);
-            r[i] = v;
+            int k = k0 + (tid >> 5) + 8 * i;
+            k = k < kend ? k : kend - 1;
+            r[i] = *reinterpret_cast<const float4*>(P + (long long)k * ld + m);
         }
     }
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int tid) {
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int k0, int kend, int tid) {
     if constexpr (KC) {
+        const int k = k0 + (tid & 7) * 4;
+        const bool full = k + 3 < kend;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * PITCH_KC + (tid & 7) * 4) = r[i];
+        for (int i = 0; i < 4; ++i) {
+            float4 v = r[i];
+            if (!full) {                                   // reduction tail: zero the lanes past K
+                if (k >= kend) v.x = 0.f;
+                if (k + 1 >= kend) v.y = 0.f;
+                if (k + 2 >= kend) v.z = 0.f;
+                v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * PITCH_KC + (tid & 7) * 4) = v;
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * PITCH_MC + (tid & 31) * 4) = r[i];
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (tid >> 5) + 8 * i;
+            float4 v = r[i];
+            if (k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * PITCH_MC + (tid & 31) * 4) = v;
+        }
     }
 }
 
@@ -144,18 +154,18 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     float4 ra[4], rb[4];
     const int nkt = (kend - kbeg + BK - 1) / BK;
     if (nkt > 0) {
-        load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
-        load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
-        store_tile<AKC>(smem, ra, tid);
-        store_tile<BKC>(smem + TILE_FLOATS, rb, tid);
+        load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg, kbeg, kend, tid);
+        load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg, kbeg, kend, tid);
+        store_tile<AKC>(smem, ra, kbeg, kend, tid);
+        store_tile<BKC>(smem + TILE_FLOATS, rb, kbeg, kend, tid);
     }
     __syncthreads();
 
     for (int t = 0; t < nkt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nkt) {
-            load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg + (t + 1) * BK, kend, tid);
-            load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kend, tid);
+            load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg + (t + 1) * BK, kbeg, kend, tid);
+            load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kbeg, kend, tid);
         }
         const float* a_s = smem + cur * 2 * TILE_FLOATS;
         const float* b_s = a_s + TILE_FLOATS;
@@ -178,8 +188,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
                 }
         }
         if (t + 1 < nkt) {
-            store_tile<AKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS, ra, tid);
-            store_tile<BKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS + TILE_FLOATS, rb, tid);
+            store_tile<AKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS, ra, kbeg + (t + 1) * BK, kend, tid);
+            store_tile<BKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS + TILE_FLOATS, rb, kbeg + (t + 1) * BK, kend, tid);
         }
         __syncthreads();
     }

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 2
+#define PULSE_ABI_VERSION 3
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -232,6 +232,7 @@ int pulse_policy_sample(const float* mu, int64_t mu_stride, const float* logstd,
                         const float* value_raw, int64_t value_stride, const double* value_mean, const double* value_var,
                         int32_t rows, int32_t num_actions, float* actions, int64_t actions_stride, float* sigmas,
                         int64_t sigmas_stride, float* neglogp, int64_t neglogp_stride, float* values, int64_t values_out_stride,
+                        float* mus_out /* optional copy of mu, e.g. the experience-buffer slot */, int64_t mus_out_stride,
                         pulse_stream_t s);
 
 typedef struct pulse_ppo_loss_args {

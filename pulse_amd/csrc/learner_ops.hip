@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(const float* __restr
                                                            const double* __restrict__ vmean, const double* __restrict__ vvar, int rows,
                                                            int A, float* __restrict__ actions, long long actions_stride,
                                                            float* __restrict__ sigmas, long long sigmas_stride, float* __restrict__ neglogp,
-                                                           long long neglogp_stride, float* __restrict__ values, long long values_stride) {
+                                                           long long neglogp_stride, float* __restrict__ values, long long values_stride,
+                                                           float* __restrict__ mus_out, long long mus_out_stride) {
     const int g = (blockIdx.x * 256 + threadIdx.x) / kLanesPerSample;
     const int l = threadIdx.x % kLanesPerSample;
     if (g >= rows) return;
@@ -249,6 +250,7 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(const float* __restr
         quad += zz * zz;
         lsum += ls;
         actions[(long long)g * actions_stride + j] = a;
+        if (mus_out) mus_out[(long long)g * mus_out_stride + j] = m;
         if (sigmas) sigmas[(long long)g * sigmas_stride + j] = m * 0.0f + sg;   // amp_network_builder.py:142-148
     }
     quad = group16_sum(quad);
@@ -486,7 +488,8 @@ int pulse_rms_update(double* mean, double* var, double* count_out, const double*
 int pulse_policy_sample(const float* mu, int64_t mu_stride, const float* logstd, const float* noise, int64_t noise_stride,
                         const float* value_raw, int64_t value_stride, const double* value_mean, const double* value_var, int32_t rows,
                         int32_t num_actions, float* actions, int64_t actions_stride, float* sigmas, int64_t sigmas_stride, float* neglogp,
-                        int64_t neglogp_stride, float* values, int64_t values_out_stride, pulse_stream_t s) {
+                        int64_t neglogp_stride, float* values, int64_t values_out_stride, float* mus_out, int64_t mus_out_stride,
+                        pulse_stream_t s) {
     PULSE_REQUIRE(rows >= 0 && num_actions >= 1, "pulse_policy_sample: bad sizes");
     if (rows == 0) return PULSE_OK;
     PULSE_REQUIRE(mu && logstd && noise && actions && neglogp, "pulse_policy_sample: null pointer");
@@ -496,7 +499,7 @@ int pulse_policy_sample(const float* mu, int64_t mu_stride, const float* logstd,
     hipLaunchKernelGGL(policy_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(s), mu, (long long)mu_stride,
                        logstd, noise, (long long)noise_stride, value_raw, (long long)value_stride, value_mean, value_var, rows, num_actions,
                        actions, (long long)actions_stride, sigmas, (long long)sigmas_stride, neglogp, (long long)neglogp_stride, values,
-                       (long long)values_out_stride);
+                       (long long)values_out_stride, mus_out, (long long)mus_out_stride);
     return check_launch("pulse_policy_sample");
 }
 

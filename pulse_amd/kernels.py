@@ -51,12 +51,11 @@ class GemmProfiler:
 PROFILER = GemmProfiler()
 
 
-def gemm(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, bias=None,
-         activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
-         stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
-         a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None):
-    """C[m][n] = epilogue(sum_k A(m,k) B(n,k)).  A/B/C/... are tensors used only as base pointers
-    (+ *_off floats); all geometry is explicit (pitches in floats)."""
+def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, bias=None,
+                   activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
+                   stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
+                   a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None):
+    """Build (descriptor, algorithmic FLOPs, variant tag) once; launch many times with launch_gemm."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -70,15 +69,50 @@ def gemm(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=
     d.stride_a, d.stride_b, d.stride_c, d.stride_c2 = stride_a, stride_b, stride_c, stride_c2
     d.stride_bias, d.stride_aux = stride_bias, stride_aux
     d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
+    tag = ("fwd" if b_layout == GEMM_RED_CONTIG else "dx") if a_layout == GEMM_RED_CONTIG else "dw"
+    flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
+    return d, flops, tag
+
+
+def launch_gemm(d, flops=0.0, tag="fwd", stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
     if PROFILER.enabled:
         ev0, ev1 = PROFILER._event(), PROFILER._event()
         ev0.record()
-        _lib.check(_lib.load().pulse_gemm_f32(ctypes.byref(d), _stream()), "pulse_gemm_f32")
+        _lib.check(lib.pulse_gemm_f32(ctypes.byref(d), st), "pulse_gemm_f32")
         ev1.record()
-        tag = ("fwd" if b_layout == GEMM_RED_CONTIG else "dx") if a_layout == GEMM_RED_CONTIG else "dw"
-        PROFILER.records.append((ev0, ev1, 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch, tag))
+        PROFILER.records.append((ev0, ev1, flops, tag))
         return
-    _lib.check(_lib.load().pulse_gemm_f32(ctypes.byref(d), _stream()), "pulse_gemm_f32")
+    _lib.check(lib.pulse_gemm_f32(ctypes.byref(d), st), "pulse_gemm_f32")
+
+
+def gemm(A, B, C, **kw):
+    """C[m][n] = epilogue(sum_k A(m,k) B(n,k)).  A/B/C/... are tensors used only as base pointers
+    (+ *_off floats); all geometry is explicit (pitches in floats)."""
+    launch_gemm(*make_gemm_desc(A, B, C, **kw))
+
+
+class Plan:
+    """A pre-built launch sequence: GEMM descriptors and bound C-ABI calls are created once per
+    workspace, so replaying a forward / backward pass costs one ctypes call per kernel."""
+
+    def __init__(self):
+        self.ops = []
+
+    def gemm(self, A, B, C, **kw):
+        self.ops.append((0,) + make_gemm_desc(A, B, C, **kw))
+
+    def call(self, name, *args):
+        self.ops.append((1, getattr(_lib.load(), name), args, name))
+
+    def run(self):
+        st = _stream()
+        for op in self.ops:
+            if op[0] == 0:
+                launch_gemm(op[1], op[2], op[3], st)
+            else:
+                _lib.check(op[1](*op[2], st), op[3])
 
 
 def linear_forward(x, w, bias=None, activation=ACT_NONE, out=None):
@@ -119,14 +153,14 @@ def rms_update(mean, var, count, moment_partials, cols, count_old, batch_count):
 def policy_sample(mu, mu_stride, logstd, noise, noise_stride, rows, num_actions, actions, actions_stride, neglogp,
                   neglogp_stride=1, sigmas=None, sigmas_stride=0, value_raw=None, value_stride=0, value_mean=None,
                   value_var=None, values=None, values_stride=0, mu_off=0, actions_off=0, sigmas_off=0, neglogp_off=0,
-                  values_off=0):
+                  values_off=0, mus_out=None, mus_out_stride=0, mus_out_off=0):
     def po(t, off):
         return (t.data_ptr() + 4 * off) if t is not None else None
     _lib.check(_lib.load().pulse_policy_sample(po(mu, mu_off), mu_stride, _p(logstd), _p(noise), noise_stride, _p(value_raw),
                                                value_stride, _p(value_mean), _p(value_var), rows, num_actions,
                                                po(actions, actions_off), actions_stride, po(sigmas, sigmas_off), sigmas_stride,
                                                po(neglogp, neglogp_off), neglogp_stride, po(values, values_off), values_stride,
-                                               _stream()), "pulse_policy_sample")
+                                               po(mus_out, mus_out_off), mus_out_stride, _stream()), "pulse_policy_sample")
 
 
 def ppo_loss(*, mu, mu_stride, value, value_stride, logstd, old_logstd, idx, actions, actions_stride, old_mu, old_mu_stride,

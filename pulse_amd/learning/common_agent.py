@@ -230,17 +230,18 @@ class CommonAgent:
         t = self.horizon_length
         ap = net.a_pitch
         s = 0 if slot is None else slot
-        net.forward(ws, n, mu_out=eb.phys["mus"], mu_ld=t * ap, mu_off=s * ap)
+        net.forward(ws, n)
         if self.noise_provider is not None:        # parity tests share pre-drawn noise with the CPU oracle
             noise = self.noise_provider(self.epoch_counter, s)
         else:
             noise = torch.randn(n, self.actions_num, device=self.ppo_device, generator=self.noise_generator)
         vm = self.value_mean_std
-        K.policy_sample(eb.phys["mus"], t * ap, net.sigma, noise, self.actions_num, n, self.actions_num,
+        K.policy_sample(ws["heads"], 2 * ap, net.sigma, noise, self.actions_num, n, self.actions_num,
                         eb.phys["actions"], t * ap, eb.phys["neglogpacs"], t, sigmas=eb.phys["sigmas"], sigmas_stride=t * ap,
-                        value_raw=ws["val"], value_stride=4, value_mean=vm.running_mean if vm else None,
+                        value_raw=ws["val"], value_stride=2 * ap, value_mean=vm.running_mean if vm else None,
                         value_var=vm.running_var if vm else None, values=eb.phys["values"], values_stride=t,
-                        mu_off=s * ap, actions_off=s * ap, sigmas_off=s * ap, neglogp_off=s, values_off=s)
+                        mus_out=eb.phys["mus"], mus_out_stride=t * ap, mus_out_off=s * ap,
+                        actions_off=s * ap, sigmas_off=s * ap, neglogp_off=s, values_off=s)
         td = eb.tensor_dict
         return {"actions": td["actions"][s], "neglogpacs": td["neglogpacs"][s], "values": td["values"][s], "mus": td["mus"][s],
                 "sigmas": td["sigmas"][s], "rnn_states": None}
@@ -256,7 +257,7 @@ class CommonAgent:
         if self.normalize_value:
             self.value_mean_std.forward(ws["val"], unnorm=True, out=value, out_cols=1)
         else:
-            value.copy_(ws["val"][:, :1])
+            value.copy_(ws["val"])
         return value
 
     # ------------------------------------------------------------------ rollout (common_agent.py:290-355)
@@ -366,11 +367,11 @@ class CommonAgent:
             live.update_only(obs_store, idx)
         net.forward(ws, mb)
         ap = net.a_pitch
-        K.ppo_loss(mu=ws["mu"], mu_stride=ap, value=ws["val"], value_stride=4, logstd=net.sigma, old_logstd=net.sigma, idx=idx,
+        K.ppo_loss(mu=ws["heads"], mu_stride=2 * ap, value=ws["val"], value_stride=2 * ap, logstd=net.sigma, old_logstd=net.sigma, idx=idx,
                    actions=act_store, actions_stride=act_store.stride(0), old_mu=mu_store, old_mu_stride=mu_store.stride(0),
                    old_neglogp=old_nlp, advantages=adv, old_values=old_val, returns=ret, rows=mb, num_actions=self.actions_num,
                    e_clip=self.e_clip, critic_coef=self.critic_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
-                   dmu=ws["dmu"], dmu_stride=ap, dvalue=ws["dval"], dvalue_stride=4, partials=self._loss_partials)
+                   dmu=ws["dheads"], dmu_stride=2 * ap, dvalue=ws["dheads"][:, ap:], dvalue_stride=2 * ap, partials=self._loss_partials)
         net.backward(ws, mb, grad_scale=1.0 / self.world_size)
         if self.multi_gpu:
             self.dist.sync_gradients(net.grad)                          # optimizer.synchronize()

@@ -100,11 +100,14 @@ class A2CNetwork:
             off += 2 * u[l] * k             # [actor rows | critic rows], pitch k
             self.b_off.append(off)
             off += 2 * u[l]
-        self.wmu_off = off; off += self.actions_num * u[-1]
+        # heads: two blocks of identical shape [A][uL] so ONE batched GEMM serves both:
+        #   block 0 = mu.weight (A rows), block 1 row 0 = value.weight, rows 1.. stay zero (zero gradient, Adam keeps 0)
+        self.head_rows = self.actions_num
+        self.wh_off = off; off += 2 * self.head_rows * u[-1]
         off = _r4(off)
-        self.bmu_off = off; off += self.a_pitch
-        self.wv_off = off; off += u[-1]
-        self.bv_off = off; off += 4
+        self.bh_off = off; off += 2 * self.a_pitch
+        self.wmu_off, self.wv_off = self.wh_off, self.wh_off + self.head_rows * u[-1]
+        self.bmu_off, self.bv_off = self.bh_off, self.bh_off + self.a_pitch
         self.n_flat = _r4(off)
 
     def _w_view(self, buf, l, net):
@@ -127,7 +130,7 @@ class A2CNetwork:
                 out[f"a2c_network.{name}.{2 * l}.weight"] = self._w_view(buf, l, net)
                 out[f"a2c_network.{name}.{2 * l}.bias"] = self._b_view(buf, l, net)
         uL = self.units[-1]
-        out["a2c_network.value.weight"] = buf[self.wv_off:self.wv_off + uL].view(1, uL)
+        out["a2c_network.value.weight"] = buf[self.wv_off:self.wv_off + uL].view(1, uL)          # row 0 of head block 1
         out["a2c_network.value.bias"] = buf[self.bv_off:self.bv_off + 1]
         out["a2c_network.mu.weight"] = buf[self.wmu_off:self.wmu_off + self.actions_num * uL].view(self.actions_num, uL)
         out["a2c_network.mu.bias"] = buf[self.bmu_off:self.bmu_off + self.actions_num]
@@ -188,112 +191,120 @@ class A2CNetwork:
     def is_rnn(self):
         return False
 
-    # ------------------------------------------------------------------ workspaces
+    # ------------------------------------------------------------------ workspaces + launch plans
     def workspace(self, m, train):
+        """Buffers and pre-built launch plans for a batch of m rows.
+        ws['x']      (m, in_pitch)   normalised network input (written by the caller)
+        ws['h'][l]   (m, 2*u_l)      hidden activations [actor | critic]
+        ws['heads']  (m, 2*a_pitch)  [mu (A cols) .. | value at col a_pitch ..]
+        train: ws['dheads'] (m, 2*a_pitch) = [d loss/d mu | d loss/d value at col a_pitch], ws['dh'][l]."""
         key = (m, bool(train))
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         dev, u = self.device, self.units
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        ws = {"x": e(m, self.in_pitch), "h": [e(m, 2 * uu) for uu in u], "mu": e(m, self.a_pitch), "val": e(m, 4)}
+        ws = {"x": e(m, self.in_pitch), "h": [e(m, 2 * uu) for uu in u], "heads": torch.zeros(m, 2 * self.a_pitch, device=dev)}
+        ws["mu"] = ws["heads"][:, :self.actions_num]
+        ws["val"] = ws["heads"][:, self.a_pitch:self.a_pitch + 1]
         if self.act == ACT_SILU:
             ws["z"] = [e(m, 2 * uu) for uu in u]
+        ws["plan_fwd"] = self._plan_forward(ws, m, 0, 2)
+        ws["plan_critic"] = self._plan_forward(ws, m, 1, 1)
         if train:
             ws["dh"] = [e(m, 2 * uu) for uu in u]
-            ws["dmu"] = torch.zeros(m, self.a_pitch, dtype=torch.float32, device=dev)
-            ws["dval"] = torch.zeros(m, 4, dtype=torch.float32, device=dev)
+            ws["dheads"] = torch.zeros(m, 2 * self.a_pitch, dtype=torch.float32, device=dev)
             if self._slabs is None:
                 self._slabs = torch.zeros(self.split_k, self.n_flat, dtype=torch.float32, device=dev)
                 self._bias_chunks = 64
-                self._bias_scratch = torch.zeros(self._bias_chunks, 2 * max(u) + 8, dtype=torch.float32, device=dev)
+                self._bias_scratch = torch.zeros(self._bias_chunks, 2 * max(max(u), self.a_pitch) + 8, dtype=torch.float32, device=dev)
+                self._head_split = 32
+                self._head_scratch = torch.zeros(self._head_split, 2 * self.head_rows * u[-1], dtype=torch.float32, device=dev)
+            ws["plan_bwd"] = self._plan_backward(ws, m)
         self._ws[key] = ws
         return ws
 
-    # ------------------------------------------------------------------ forward
-    def _mlp_forward(self, ws, m, nets):
-        """nets: (first_net, count) with count in {1, 2}; hidden activations land in ws['h'][l][:, net*u:]."""
-        n0, cnt = nets
+    def _plan_forward(self, ws, m, n0, cnt):
+        """nets n0 .. n0+cnt-1 (0 = actor, 1 = critic)."""
         u, f = self.units, self.flat
         pre = ws.get("z")
+        p = K.Plan()
         for l, uu in enumerate(u):
             k = self.in_w[l]
-            if l == 0:
-                K.gemm(ws["x"], f, ws["h"][0], M=m, N=cnt * uu, K=k, lda=k, ldb=k, ldc=2 * uu, bias=f, activation=self.act, algo_k=self.in_dim,
-                       b_off=self.w_off[0] + n0 * uu * k, bias_off=self.b_off[0] + n0 * uu, c_off=n0 * uu,
+            if l == 0:   # both nets read the same input: one GEMM of N = cnt*u1
+                p.gemm(ws["x"], f, ws["h"][0], M=m, N=cnt * uu, K=k, lda=k, ldb=k, ldc=2 * uu, bias=f, activation=self.act,
+                       algo_k=self.in_dim, b_off=self.w_off[0] + n0 * uu * k, bias_off=self.b_off[0] + n0 * uu, c_off=n0 * uu,
                        C2=pre[0] if pre else None, ldc2=2 * uu, c2_off=n0 * uu)
             else:
                 up = u[l - 1]
-                K.gemm(ws["h"][l - 1], f, ws["h"][l], M=m, N=uu, K=up, lda=2 * up, ldb=up, ldc=2 * uu, bias=f, activation=self.act,
+                p.gemm(ws["h"][l - 1], f, ws["h"][l], M=m, N=uu, K=up, lda=2 * up, ldb=up, ldc=2 * uu, bias=f, activation=self.act,
                        batch=cnt, stride_a=up, stride_b=uu * up, stride_c=uu, stride_bias=uu,
                        a_off=n0 * up, b_off=self.w_off[l] + n0 * uu * up, bias_off=self.b_off[l] + n0 * uu, c_off=n0 * uu,
                        C2=pre[l] if pre else None, ldc2=2 * uu, stride_c2=uu, c2_off=n0 * uu)
+        uL, ap, hr = u[-1], self.a_pitch, self.head_rows
+        # heads (batched: mu from the actor half of h_L, value from the critic half)
+        p.gemm(ws["h"][-1], f, ws["heads"], M=m, N=hr, K=uL, lda=2 * uL, ldb=uL, ldc=2 * ap, bias=f, batch=cnt, stride_a=uL,
+               stride_b=hr * uL, stride_c=ap, stride_bias=ap, a_off=n0 * uL, b_off=self.wh_off + n0 * hr * uL,
+               bias_off=self.bh_off + n0 * ap, c_off=n0 * ap, algo_n=(self.actions_num + 1) / 2.0 if cnt == 2 else (self.actions_num if n0 == 0 else 1))
+        return p
 
-    def _heads(self, ws, m, mu_out=None, mu_ld=None, mu_off=0, actor=True, critic=True):
-        uL, f = self.units[-1], self.flat
-        hL = ws["h"][-1]
-        if actor:
-            tgt = ws["mu"] if mu_out is None else mu_out
-            K.gemm(hL, f, tgt, M=m, N=self.actions_num, K=uL, lda=2 * uL, ldb=uL, ldc=self.a_pitch if mu_ld is None else mu_ld,
-                   bias=f, b_off=self.wmu_off, bias_off=self.bmu_off, c_off=mu_off)
-        if critic:
-            K.gemm(hL, f, ws["val"], M=m, N=1, K=uL, lda=2 * uL, ldb=uL, ldc=4, bias=f, a_off=uL, b_off=self.wv_off, bias_off=self.bv_off)
-
-    def forward(self, ws, m, *, mu_out=None, mu_ld=None, mu_off=0):
-        """Actor + critic forward on the normalised input already in ws['x'].  mu -> ws['mu'] (pitch
-        a_pitch) or the caller's buffer, raw value -> ws['val'][:, 0]."""
-        self._mlp_forward(ws, m, (0, 2))
-        self._heads(ws, m, mu_out, mu_ld, mu_off)
+    def forward(self, ws, m):
+        """Actor + critic forward on the normalised input in ws['x'] -> ws['heads'] (mu | value)."""
+        ws["plan_fwd"].run()
 
     def eval_critic(self, ws, m):
-        """Critic only (CommonAgent._eval_critic, common_agent.py:551-562)."""
-        self._mlp_forward(ws, m, (1, 1))
-        self._heads(ws, m, actor=False)
+        """Critic only (CommonAgent._eval_critic, common_agent.py:551-562) -> ws['val']."""
+        ws["plan_critic"].run()
 
     # ------------------------------------------------------------------ backward
-    def _bias_grad(self, dz, m, n, ld, off):
-        """db = column sums of dz: 64 row chunks (enough workgroups to stream at HBM rate) into a scratch,
-        then one ordered reduce straight into slab 0 (the other slabs stay zero for bias positions)."""
-        c = self._bias_chunks if m >= 64 * 16 else 1
-        sc = self._bias_scratch
-        K.colsum_partial(dz, m, n, ld, c, sc, sc.stride(0))
-        K.reduce_slabs(sc, c, sc.stride(0), n, self._slabs, out_off=off)
-
-    def backward(self, ws, m, grad_scale=1.0):
-        """Given d loss / d mu in ws['dmu'] and d loss / d value in ws['dval'][:, 0], fill self.grad
-        (flat, same layout as self.flat).  Deterministic: split-K slabs + one ordered reduce."""
+    def _plan_backward(self, ws, m):
         u, f, S = self.units, self.flat, self.split_k
-        L = len(u)
-        uL = u[-1]
+        L, uL, ap, hr = len(u), u[-1], self.a_pitch, self.head_rows
         slabs, P = self._slabs, self.n_flat
         egrad = EPI_RELU_GRAD if self.act == ACT_RELU else EPI_SILU_GRAD
         aux = ws["h"] if self.act == ACT_RELU else ws["z"]
-        # heads -> dH_L (activation derivative fused)
-        K.gemm(ws["dmu"], f, ws["dh"][-1], M=m, N=uL, K=self.actions_num, lda=self.a_pitch, ldb=uL, ldc=2 * uL,
-               b_layout=GEMM_OUT_CONTIG, b_off=self.wmu_off, epilogue=egrad, aux=aux[-1], ldaux=2 * uL)
-        K.gemm(ws["dval"], f, ws["dh"][-1], M=m, N=uL, K=1, lda=4, ldb=uL, ldc=2 * uL, b_layout=GEMM_OUT_CONTIG,
-               b_off=self.wv_off, c_off=uL, epilogue=egrad, aux=aux[-1], ldaux=2 * uL, aux_off=uL)
-        # head weight / bias gradients
-        K.gemm(ws["dmu"], ws["h"][-1], slabs, M=self.actions_num, N=uL, K=m, lda=self.a_pitch, ldb=2 * uL, ldc=uL,
-               a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, c_off=self.wmu_off, split_k=S, split_stride=P)
-        K.gemm(ws["dval"], ws["h"][-1], slabs, M=1, N=uL, K=m, lda=4, ldb=2 * uL, ldc=uL, a_layout=GEMM_OUT_CONTIG,
-               b_layout=GEMM_OUT_CONTIG, b_off=uL, c_off=self.wv_off, split_k=S, split_stride=P)
-        self._bias_grad(ws["dmu"], m, self.actions_num, self.a_pitch, self.bmu_off)
-        self._bias_grad(ws["dval"], m, 1, 4, self.bv_off)
+        p = K.Plan()
+
+        def bias_grad(dz, n, ld, off):
+            # db = column sums: 64 row chunks (enough workgroups to stream at HBM rate) into a scratch, then one
+            # ordered reduce straight into slab 0 (the other slabs stay zero at bias positions)
+            c = self._bias_chunks if m >= 64 * 16 else 1
+            sc = self._bias_scratch
+            p.call("pulse_colsum_partial", dz.data_ptr(), m, n, ld, c, sc.data_ptr(), sc.stride(0))
+            p.call("pulse_reduce_slabs", sc.data_ptr(), c, sc.stride(0), n, slabs.data_ptr() + 4 * off, 1.0)
+
+        dhd = ws["dheads"]
+        # heads -> dH_L for both nets in one launch (activation derivative fused)
+        p.gemm(dhd, f, ws["dh"][-1], M=m, N=uL, K=hr, lda=2 * ap, ldb=uL, ldc=2 * uL, b_layout=GEMM_OUT_CONTIG, batch=2,
+               stride_a=ap, stride_b=hr * uL, stride_c=uL, stride_aux=uL, b_off=self.wh_off, epilogue=egrad, aux=aux[-1],
+               ldaux=2 * uL, algo_k=(self.actions_num + 1) / 2.0)
+        # head weight gradients: tiny outputs (2 x [A][uL]) over a long reduction -> split wide into a scratch
+        hs, HS = self._head_scratch, self._head_split if m >= 32 * self._head_split else 1
+        p.gemm(dhd, ws["h"][-1], hs, M=hr, N=uL, K=m, lda=2 * ap, ldb=2 * uL, ldc=uL, a_layout=GEMM_OUT_CONTIG,
+               b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=ap, stride_b=uL, stride_c=hr * uL, split_k=HS, split_stride=hs.stride(0),
+               algo_k=m * (self.actions_num + 1) / (2.0 * hr))
+        p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), 2 * hr * uL, slabs.data_ptr() + 4 * self.wh_off, 1.0)
+        bias_grad(dhd, 2 * ap, 2 * ap, self.bh_off)
         for l in range(L - 1, -1, -1):
             uu, k = u[l], self.in_w[l]
             dz = ws["dh"][l]
-            self._bias_grad(dz, m, 2 * uu, 2 * uu, self.b_off[l])
+            bias_grad(dz, 2 * uu, 2 * uu, self.b_off[l])
             if l == 0:
-                K.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
+                p.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P, algo_n=self.in_dim)
             else:
                 up = u[l - 1]
-                K.gemm(dz, ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
+                p.gemm(dz, ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],
                        split_k=S, split_stride=P)
-                K.gemm(dz, f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
+                p.gemm(dz, f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
                        batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
                        aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
-        K.reduce_slabs(slabs, S, P, P, self.grad, scale=grad_scale)
+        return p
+
+    def backward(self, ws, m, grad_scale=1.0):
+        """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
+        Deterministic: split-K slabs + ordered reduces."""
+        ws["plan_bwd"].run()
+        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat, self.grad, scale=grad_scale)
         return self.grad

@@ -13,8 +13,8 @@ environments (weak scaling, envs shard with no data-path collective; the one exc
 step is the flat-gradient all-reduce).
 
 Prints ONE JSON line on rank 0.  ``roofline`` is measured live: every launch of the dominant
-kernel (gemm_f32_kernel, the fp32 MFMA GEMM) inside the timed region is bracketed by a HIP event
-pair on the launch stream; achieved = algorithmic FLOPs / summed kernel time.  ``cpu_baseline`` is
+kernel (gemm_f32_kernel, the fp32 MFMA GEMM) inside the LAST step of the timed region is bracketed by
+a HIP event pair on the launch stream; achieved = algorithmic FLOPs / summed kernel time.  ``cpu_baseline`` is
 the PyTorch-CPU oracle agent (oracle/agent_oracle.py, kind "port") timed on the host cores on a
 bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -141,11 +141,11 @@ def main():
     prof = kernels.PROFILER
     dist.barrier()
     torch.cuda.synchronize()
-    if not a.no_roofline:
-        prof.start()
     t0 = time.perf_counter()
     play = upd = 0.0
-    for _ in range(a.steps):
+    for step in range(a.steps):
+        if step == a.steps - 1 and not a.no_roofline:
+            prof.start()      # the LAST timed step carries the HIP-event brackets (an event pair costs ~10 us of stream time per GEMM)
         info = agent.train_epoch()
         play += info["play_time"]
         upd += info["update_time"]
@@ -173,7 +173,8 @@ def main():
         f = sum(v[2] for v in s.values())
         out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": f / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_f32_kernel",
-                           "launches": n, "avg_us": 1e6 * t / max(1, n), "kernel_time_frac_of_step": t / elapsed,
+                           "launches": n, "avg_us": 1e6 * t / max(1, n), "kernel_time_frac_of_step": t / (elapsed / a.steps),
+                           "instrumented_steps": 1,
                            "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in s.items()}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle (subprocess, bounded)")

@@ -340,15 +340,21 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     const size_t lds = sizeof(float) * 4 * TILE_FLOATS;   // 73,728 B -> two workgroups per CU
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
-    hipError_t e;
-#define LAUNCH(AK, BK_)                                                                                          \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BK_>),                              \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_f32: LDS attribute: %s", hipGetErrorString(e)); \
+    // The 72 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling
+    // hipFuncSetAttribute on every launch serialises the host against the stream).
+    static bool attr_done[3] = {false, false, false};
+    hipError_t e = hipSuccess;
+#define LAUNCH(IDX, AK, BK_)                                                                                       \
+    if (!attr_done[IDX]) {                                                                                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BK_>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_f32: LDS attribute: %s", hipGetErrorString(e)); \
+        attr_done[IDX] = true;                                                                                    \
+    }                                                                                                             \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
-    if (akc && bkc) { LAUNCH(true, true); }
-    else if (akc && !bkc) { LAUNCH(true, false); }
-    else { LAUNCH(false, false); }
+    if (akc && bkc) { LAUNCH(0, true, true); }
+    else if (akc && !bkc) { LAUNCH(1, true, false); }
+    else { LAUNCH(2, false, false); }
 #undef LAUNCH
     return check_launch("pulse_gemm_f32");
 }

@@ -96,11 +96,22 @@ class AMPDataset:
         self.generator = generator
         self.special_names = ["rnn_states"]
         self.values_dict = None
+        self._pinned = None
+        self._pin_i = 0
         self._idx_buf = self._randperm()
 
     def _randperm(self):
-        # drawn on the CPU like the reference (torch.randperm(self.batch_size), amp_datasets.py:7) then kept on the device
-        return torch.randperm(self.batch_size, generator=self.generator).to(self.device)
+        """Drawn on the CPU like the reference (torch.randperm(self.batch_size), amp_datasets.py:7) so a shared
+        seed reproduces the oracle's minibatches, then uploaded through a rotating PINNED staging buffer with a
+        non-blocking copy: a pageable .to(device) would stall the host until the GPU drains its queue."""
+        if self.device.type != "cuda":
+            return torch.randperm(self.batch_size, generator=self.generator)
+        if self._pinned is None:
+            self._pinned = [torch.empty(self.batch_size, dtype=torch.int64).pin_memory() for _ in range(3)]
+        buf = self._pinned[self._pin_i % 3]
+        self._pin_i += 1
+        torch.randperm(self.batch_size, generator=self.generator, out=buf)
+        return buf.to(self.device, non_blocking=True)
 
     def set_permutation(self, perm):
         self._idx_buf = perm.to(self.device, torch.int64)

@@ -108,10 +108,19 @@ class AMPDataset:
             return torch.randperm(self.batch_size, generator=self.generator)
         if self._pinned is None:
             self._pinned = [torch.empty(self.batch_size, dtype=torch.int64).pin_memory() for _ in range(3)]
-        buf = self._pinned[self._pin_i % 3]
+            self._pin_done = [None, None, None]
+        i = self._pin_i % 3
         self._pin_i += 1
+        buf = self._pinned[i]
+        if self._pin_done[i] is not None:
+            self._pin_done[i].synchronize()      # the host may run several mini-epochs ahead of the GPU: never overwrite a
+                                                 # staging buffer whose upload has not executed yet
         torch.randperm(self.batch_size, generator=self.generator, out=buf)
-        return buf.to(self.device, non_blocking=True)
+        dev = buf.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pin_done[i] = ev
+        return dev
 
     def set_permutation(self, perm):
         self._idx_buf = perm.to(self.device, torch.int64)

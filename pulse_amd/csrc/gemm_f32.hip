@@ -44,6 +44,7 @@ struct GemmArgs {
     int act;                                   // 0 none, 1 relu, 2 silu (EPI 0 only)
     int epi;                                   // 0 bias+act, 1 relu-grad mask, 2 silu-grad
     int tiles_m, tiles_n;
+    int vec_epi;                               // all epilogue pointers / pitches are 16-byte aligned
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -194,11 +195,83 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     float* C = g.C + bz * g.sC + sp * g.sSplit;
     float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
     const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
     const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+
+    if (g.vec_epi) {
+        // Wide path: the accumulators are transposed through LDS (the staging buffers are free after the main
+        // loop) so every global access of the epilogue -- C stores, aux loads, pre-activation stores -- is a
+        // 16-byte access covering 512 contiguous bytes of one row per half-wave, instead of 64 dword stores and
+        // 64 dword aux loads per lane.
+        constexpr int CP = BN + 4;                     // 132-float pitch: ds_read_b128 lane groups stay conflict-free
+        float* sC = smem;                              // 128 x 132 x 4 B = 67,584 B <= 73,728 B
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        const int c4 = (tid & 31) * 4;
+        const int col = n0 + c4;
+        if (col < g.N) {
+            const bool full = col + 3 < g.N;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) {
+                if (full) bv = *reinterpret_cast<const float4*>(bias + col);
+                else { bv.x = bias[col]; if (col + 1 < g.N) bv.y = bias[col + 1]; if (col + 2 < g.N) bv.z = bias[col + 2]; }
+            }
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int rl = (tid >> 5) + 8 * q;
+                const int row = m0 + rl;
+                if (row >= g.M) continue;
+                float4 v = *reinterpret_cast<const float4*>(sC + rl * CP + c4);
+                float o[4] = {v.x, v.y, v.z, v.w};
+                if (g.epi == 0) {
+                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+                    } else if (g.act == 2) {
+                        if (C2) {
+                            float* p2 = C2 + (long long)row * g.ldc2 + col;
+                            if (full) *reinterpret_cast<float4*>(p2) = make_float4(o[0], o[1], o[2], o[3]);
+                            else for (int k = 0; k < 4 && col + k < g.N; ++k) p2[k] = o[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
+                    }
+                } else {
+                    const float* pa = aux + (long long)row * g.ldaux + col;
+                    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (full) { const float4 t = *reinterpret_cast<const float4*>(pa); a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w; }
+                    else for (int k = 0; k < 4 && col + k < g.N; ++k) a4[k] = pa[k];
+                    if (g.epi == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = a4[k] > 0.f ? o[k] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sg = 1.f / (1.f + __expf(-a4[k]));
+                            o[k] *= sg * (1.f + a4[k] * (1.f - sg));
+                        }
+                    }
+                }
+                float* pc = C + (long long)row * g.ldc + col;
+                if (full) *reinterpret_cast<float4*>(pc) = make_float4(o[0], o[1], o[2], o[3]);
+                else for (int k = 0; k < 4 && col + k < g.N; ++k) pc[k] = o[k];
+            }
+        }
+        return;
+    }
+
+    // Scalar path (unaligned C / aux pitches): one dword per lane per accumulator register.
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
@@ -338,6 +411,9 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.sSplit = d->split_stride;
     g.act = d->activation; g.epi = d->epilogue;
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
+    auto al16 = [](const void* p, long long ld, long long st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0 && (st % 4) == 0; };
+    g.vec_epi = al16(d->C, d->ldc, d->stride_c) && (d->split_stride % 4) == 0 && (!d->aux || al16(d->aux, d->ldaux, d->stride_aux)) &&
+                (!d->C2 || al16(d->C2, d->ldc2, d->stride_c2)) && (!d->bias || al16(d->bias, 4, d->stride_bias));
     const size_t lds = sizeof(float) * 4 * TILE_FLOATS;   // 73,728 B -> two workgroups per CU
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
     // The 72 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling

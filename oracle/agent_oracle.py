@@ -333,3 +333,67 @@ class OracleCommonAgent:
         t2 = time.time()
         self.epoch += 1
         return {"batch_dict": batch_dict, "infos": infos, "play_time": t1 - t0, "update_time": t2 - t1, "minibatches": done}
+
+
+class OracleNetZ(nn.Module):
+    """AMPZBuilder.Network, z_type 'vae' with a learned prior, non-RNN branch
+    (phc/learning/amp_network_z_builder.py:24-69, 79-121, 226-248, 326-339, 422-467, 469-580)."""
+
+    def __init__(self, self_obs_size=358, task_obs_size=576, actions_num=69, units=(3096, 2048, 1024), task_units=(1536, 1024, 512),
+                 embedding_size=32, var_clamp_max=2.0, sigma_val=-2.9):
+        super().__init__()
+        self.self_obs_size, self.task_obs_size, self.embedding_size = self_obs_size, task_obs_size, embedding_size
+        self.var_clamp_max = var_clamp_max
+        E = embedding_size
+
+        def mlp(i, us):
+            layers = []
+            for u in us:
+                layers += [nn.Linear(i, u), nn.SiLU()]
+                i = u
+            return nn.Sequential(*layers)
+        self.actor_mlp = mlp(self_obs_size + E, units)
+        self.critic_mlp = mlp(self_obs_size + E, units)
+        self.value = nn.Linear(units[-1], 1)
+        self.mu = nn.Linear(units[-1], actions_num)
+        self.sigma = nn.Parameter(torch.full((actions_num,), float(sigma_val)), requires_grad=False)
+        self.z_mlp = mlp(self_obs_size + task_obs_size, task_units)
+        self.z_mlp.append(nn.Linear(task_units[-1], 5 * E))
+        self.z_mu = nn.Linear(5 * E, E)
+        self.z_logvar = nn.Linear(5 * E, E)
+        self.z_prior = mlp(self_obs_size, task_units)
+        self.z_prior_mu = nn.Linear(task_units[-1], E)
+        self.z_prior_logvar = nn.Linear(task_units[-1], E)
+        self.critic_z_mlp = mlp(self_obs_size + task_obs_size, task_units)
+        self.critic_z_mlp.append(nn.Linear(task_units[-1], E))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.bias)
+
+    def state_dict_ref(self):
+        return {"a2c_network." + k: v.detach().clone() for k, v in self.state_dict().items()}
+
+    def form_embedding(self, task_out_z, noise):
+        vae_mu = self.z_mu(task_out_z)
+        vae_log_var = torch.clamp(self.z_logvar(task_out_z), min=-5, max=self.var_clamp_max)
+        z = vae_mu + torch.exp(0.5 * vae_log_var) * noise
+        return z, {"vae_mu": vae_mu, "vae_log_var": vae_log_var, "noise": noise}
+
+    def eval_actor(self, obs, noise):
+        self_obs = obs[:, :self.self_obs_size]
+        z, extra = self.form_embedding(self.z_mlp(obs), noise)
+        mu = self.mu(self.actor_mlp(torch.cat([self_obs, z], dim=-1)))
+        return mu, mu * 0.0 + self.sigma, extra
+
+    def compute_prior(self, obs):
+        lat = self.z_prior(obs[:, :self.self_obs_size])
+        return self.z_prior_mu(lat), torch.clamp(self.z_prior_logvar(lat), min=-5, max=self.var_clamp_max)
+
+    def eval_critic(self, obs):
+        self_obs = obs[:, :self.self_obs_size]
+        return self.value(self.critic_mlp(torch.cat([self_obs, self.critic_z_mlp(obs)], dim=-1)))
+
+
+def kl_multi(qm, qv, pm, pv):
+    """phc/learning/loss_functions.py:3-10 (pinned: tests/golden/rms.npz kl_multi)."""
+    return (0.5 * (pv - qv + qv.exp() / pv.exp() + (qm - pm).pow(2) / pv.exp() - 1)).sum(-1)

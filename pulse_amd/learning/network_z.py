@@ -139,7 +139,7 @@ class AMPZNetwork:
     def _logical(self, name, sl, buf=None):
         p = self.book.params[name]
         v = self.book.get(name, buf)
-        if p.rows == 1:                                     # bias row
+        if name.endswith(".bias"):                          # bias row
             v = v.reshape(-1)
             return v[sl] if sl is not None else v
         return v[sl] if sl is not None else v
@@ -166,8 +166,9 @@ class AMPZNetwork:
                 stacked.setdefault(n, {})[sl.start] = v
         for n, parts in stacked.items():
             p = self.book.params[n]
-            full = torch.cat([parts[k].reshape(-1, p.cols) if p.rows > 1 else parts[k].reshape(1, -1) for k in sorted(parts)],
-                             dim=0 if p.rows > 1 else 1)
+            is_bias = n.endswith(".bias")
+            full = torch.cat([parts[k].reshape(1, -1) if is_bias else parts[k].reshape(-1, p.cols) for k in sorted(parts)],
+                             dim=1 if is_bias else 0)
             self.book.set(n, full)
         if "a2c_network.sigma" in sd:
             self.sigma.copy_(sd["a2c_network.sigma"].to(self.device, torch.float32))

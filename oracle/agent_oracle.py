@@ -397,3 +397,38 @@ class OracleNetZ(nn.Module):
 def kl_multi(qm, qv, pm, pv):
     """phc/learning/loss_functions.py:3-10 (pinned: tests/golden/rms.npz kl_multi)."""
     return (0.5 * (pv - qv + qv.exp() / pv.exp() + (qm - pm).pow(2) / pv.exp() - 1)).sum(-1)
+
+
+def oracle_optimize_kin(net, obs, gt_action, progress_buf, noise, horizon, kld_coefficient=0.01, ar1_coefficient=0.005,
+                        use_ar1_prior=True, use_vae_prior_regu=False):
+    """AMPAgent._optimize_kin, phc/learning/amp_agent.py:771-849 (z_type 'vae', use_vae_prior), up to and
+    including kin_loss.backward().  ``obs`` is the already-normalised minibatch, rows ordered env-major
+    (minibatch // horizon sequences of ``horizon`` steps).  Returns the info dict; gradients are left in net."""
+    mb = obs.shape[0]
+    pred_action, _, extra = net.eval_actor(obs, noise)
+    kin_action_loss = torch.norm(pred_action - gt_action, dim=-1).mean()
+    vae_mu, vae_log_var = extra["vae_mu"], extra["vae_log_var"]
+    prior_mu, prior_log_var = net.compute_prior(obs)
+    KLD = kl_multi(vae_mu, vae_log_var, prior_mu, prior_log_var).mean()
+    ar1_prior, regu_prior = 0, 0
+    info = {}
+    if use_ar1_prior:
+        time_zs = vae_mu.view(mb // horizon, horizon, -1)
+        phi = 0.99
+        error = time_zs[:, 1:] - time_zs[:, :-1] * phi
+        idxes = progress_buf.view(mb // horizon, horizon, -1)
+        not_consecs = ((idxes[:, 1:] - idxes[:, :-1]) != 1).view(-1)
+        error = error.reshape(-1, error.shape[-1]).clone()
+        error[not_consecs] = 0
+        starteres = ((idxes <= 2)[:, 1:] + (idxes <= 2)[:, :-1]).view(-1)
+        error[starteres] = 0
+        ar1_prior = torch.norm(error, dim=-1).mean()
+        info["kin_ar1"] = ar1_prior.detach()
+    if use_vae_prior_regu:
+        regu_prior = ((prior_mu ** 2).mean() + (vae_mu ** 2).mean()) * 0.001 + ((prior_log_var ** 2).mean() + (vae_log_var ** 2).mean()) * 0.001
+    kin_loss = kin_action_loss + KLD * kld_coefficient + ar1_prior * ar1_coefficient + regu_prior * 0.005
+    for p in net.parameters():
+        p.grad = None
+    kin_loss.backward()
+    info.update({"kin_action_loss": kin_action_loss.detach(), "kin_KLD": KLD.detach(), "kin_loss": kin_loss.detach()})
+    return info

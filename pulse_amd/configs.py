@@ -23,25 +23,52 @@ PPO_IM = {                # phc/data/cfg/learning/im.yaml:46-91
 ENV_IM = {"obs_v": 6, "self_obs_v": 1, "power_reward": True, "local_root_obs": True, "root_height_obs": True,
           "enableEarlyTermination": True, "terminationDistance": 0.25, "episode_length": 300}
 
+NETWORK_Z = {             # phc/data/cfg/learning/im_z_fit.yaml:12-50 (network: amp_z)
+    "name": "amp_z", "separate": True,
+    "space": {"continuous": {"mu_activation": "None", "sigma_activation": "None", "mu_init": {"name": "default"},
+                             "sigma_init": {"name": "const_initializer", "val": -2.9}, "fixed_sigma": True, "learn_sigma": False}},
+    "mlp": {"units": [3096, 2048, 1024], "activation": "silu", "d2rl": False, "initializer": {"name": "default"}},
+    "task_mlp": {"units": [1536, 1024, 512], "activation": "silu", "d2rl": False, "initializer": {"name": "default"}},
+}
+
+ENV_IM_VAE = dict(ENV_IM, **{   # phc/data/cfg/env/env_im_vae.yaml:19-55 (PULSE distillation)
+    "embedding_norm": 1, "embedding_size": 32, "z_type": "vae", "use_vae_prior": True, "use_ar1_prior": True,
+    "use_vae_clamped_prior": True, "vae_var_clamp_max": 2, "kld_coefficient": 0.01, "kld_coefficient_min": 0.001, "kld_anneal": True,
+    "ar1_coefficient": 0.005, "only_kin_loss": True, "distill": True, "save_kin_info": True, "cycle_motion": True})
+
 CONFIGS = {
     # BASELINE.json configs[0]: 64-env synthetic rollout (horizon 16), 2x512 MLP, one PPO+GAE epoch
     "cfg1": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "units": [512, 512]},
     # BASELINE.json configs[1]: 4096 SMPL humanoids, horizon 32, imitation reward/obs + PPO
     "cfg2": {"num_envs": 4096, "horizon_length": 32, "minibatch_size": 16384, "units": [1024, 512]},
+    # BASELINE.json configs[2]: 8192 envs, PULSE VAE encoder/decoder in the policy head (latent 32); kin/VAE loss (PULSE training)
+    "cfg3": {"num_envs": 8192, "horizon_length": 32, "minibatch_size": 16384, "network": "amp_z", "env": "vae", "agent": "amp",
+             "extra": {"use_seq_rl": True}},
+    # same network trained with the PPO loss (SURVEY.md 8d cfg 3, first variant)
+    "cfg3_ppo": {"num_envs": 8192, "horizon_length": 32, "minibatch_size": 16384, "network": "amp_z", "env": "vae_ppo", "agent": "amp"},
+    # small shapes of the same graphs for tests
+    "cfg3_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_z", "env": "vae", "agent": "amp",
+                   "extra": {"use_seq_rl": True}},
+    "cfg3_ppo_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_z", "env": "vae_ppo", "agent": "amp"},
 }
 
 
 def agent_config(name, **overrides):
     c = CONFIGS[name]
-    net = copy.deepcopy(NETWORK_IM)
-    net["mlp"]["units"] = list(c["units"])
+    if c.get("network") == "amp_z":
+        net = copy.deepcopy(NETWORK_Z)
+    else:
+        net = copy.deepcopy(NETWORK_IM)
+        net["mlp"]["units"] = list(c["units"])
     cfg = copy.deepcopy(PPO_IM)
     cfg.update({"horizon_length": c["horizon_length"], "minibatch_size": c["minibatch_size"], "network": net})
+    cfg.update(c.get("extra", {}))
     cfg.update(overrides)
+    cfg["_env_kind"], cfg["_agent_kind"] = c.get("env", "im"), c.get("agent", "common")
     return cfg, c["num_envs"]
 
 
-def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None):
+def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kind="im"):
     from .env.humanoid_im import HumanoidIm, VecTaskPythonWrapper
     from .env.sim import RecordedMotion, RecordedRollout, RecordedSim
     if rollout is None:
@@ -49,14 +76,19 @@ def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None):
     rollout.to(device)
     sim = RecordedSim(rollout)
     motion = RecordedMotion(rollout, sim)
-    task = HumanoidIm({"env": dict(ENV_IM)}, sim, motion, device=device)
+    env_cfg = dict(ENV_IM_VAE) if env_kind in ("vae", "vae_ppo") else dict(ENV_IM)
+    if env_kind == "vae_ppo":
+        env_cfg.update({"only_kin_loss": False, "save_kin_info": False, "distill": False})
+    task = HumanoidIm({"env": env_cfg}, sim, motion, device=device)
     task.progress_buf.copy_(rollout.init_progress)
     return VecTaskPythonWrapper(task, rl_device=device), rollout
 
 
 def make_agent(name="cfg2", device="cuda:0", seed=1234, rank=0, rollout=None, **overrides):
+    from .learning.amp_agent import AMPAgent
     from .learning.common_agent import CommonAgent
     cfg, num_envs = agent_config(name, **overrides)
-    vec_env, rollout = make_env(num_envs, cfg["horizon_length"], device, seed=seed, rank=rank, rollout=rollout)
+    vec_env, rollout = make_env(num_envs, cfg["horizon_length"], device, seed=seed, rank=rank, rollout=rollout, env_kind=cfg["_env_kind"])
     cfg.update({"vec_env": vec_env, "device": device, "seed": seed})
-    return CommonAgent("pulse_amd", cfg), rollout
+    cls = AMPAgent if cfg["_agent_kind"] == "amp" else CommonAgent
+    return cls("pulse_amd", cfg), rollout

@@ -96,11 +96,27 @@ class HumanoidIm:
         self._pass_time = torch.zeros(n, dtype=torch.bool, device=dev)
         self.extras = {}
         self.actions = None
-        # attributes the agent reaches for (amp_agent.py:59-63; common_agent.py:54)
-        self.temp_running_mean = True
-        self.kin_lr = 5e-4
+        # attributes the agent reaches for (amp_agent.py:59-63; common_agent.py:54); defaults of humanoid.py:105,296-345
+        self.temp_running_mean = bool(env.get("temp_running_mean", True))
+        self.kin_lr = float(env.get("kin_lr", 5e-4))
         self.fitting = False
-        self.z_type = None
+        self.save_kin_info = bool(env.get("save_kin_info", False))
+        self.only_kin_loss = bool(env.get("only_kin_loss", False))
+        self.distill = bool(env.get("distill", False))
+        self.z_type = env.get("z_type", None)
+        self.kld_coefficient = float(env.get("kld_coefficient", 0.01))
+        self.kld_coefficient_min = float(env.get("kld_coefficient_min", 0.001))
+        self.ar1_coefficient = float(env.get("ar1_coefficient", 0.005))
+        self.kld_anneal = bool(env.get("kld_anneal", True))
+        self.use_ar1_prior = bool(env.get("use_ar1_prior", False))
+        self.use_vae_prior = bool(env.get("use_vae_prior", False))
+        self.use_vae_prior_regu = bool(env.get("use_vae_prior_regu", False))
+        self._task_obs_size_detail = {k: env[k] for k in ("embedding_size", "embedding_norm", "z_type", "use_vae_prior",
+                                                          "use_vae_clamped_prior", "vae_var_clamp_max") if k in env}
+        self._task_obs_size_detail.setdefault("proj_norm", True)
+        if self.save_kin_info:        # HumanoidImDistill.kin_dict (humanoid_im_distill.py:73-80, 204-205)
+            self.kin_dict = {"gt_action": torch.zeros(n, self.num_actions, device=dev),
+                             "progress_buf": torch.zeros(n, dtype=torch.int64, device=dev)}
         self.humanoid_type = "smpl"
         self.has_task = True
         self.viewer = None
@@ -122,10 +138,16 @@ class HumanoidIm:
         return (self.get_obs_size(),)
 
     def get_task_obs_size_detail(self):
-        return []
+        return self._task_obs_size_detail
 
     # ------------------------------------------------------------------ step phases
     def step(self, actions):
+        if self.save_kin_info:
+            # the distillation target for THIS observation is produced before physics advances
+            # (HumanoidImDistill.step, humanoid_im_distill.py:143-231; the teacher itself is out of scope)
+            self.kin_dict["gt_action"] = self.sim.gt_action
+            self.kin_dict["progress_buf"] = self.progress_buf.clone()
+            self.extras["kin_dict"] = self.kin_dict
         self.pre_physics_step(actions)
         self._physics_step()
         self.post_physics_step()

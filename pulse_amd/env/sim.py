@@ -21,7 +21,7 @@ class RecordedRollout:
         g = syn.make_generator(seed, rank)
         self.num_envs, self.num_frames = num_envs, num_frames
         n = num_envs
-        keys = ("rb", "reset_rb", "dof_force", "dof_vel")
+        keys = ("rb", "reset_rb", "dof_force", "dof_vel", "gt_action")
         self.data = {k: [] for k in keys}
         self.ref_now = {k: [] for k in ("pos", "rot", "vel", "ang")}
         self.ref_next = {k: [] for k in ("pos", "rot", "vel", "ang")}
@@ -34,6 +34,9 @@ class RecordedRollout:
             for k in self.ref_now:
                 self.ref_now[k].append(d["ref_now"][k])
                 self.ref_next[k].append(d["ref_next"][k])
+            # stand-in for the frozen PHC teacher's action on this frame (humanoid_im_distill.py:143-231; needs released
+            # checkpoints, so the distillation target is synthetic)
+            self.data["gt_action"].append((0.4 * torch.randn(n, syn.NUM_DOF, generator=g)).clamp(-1, 1))
             rrb = syn.rigid_body_state(g, n)
             self.data["reset_rb"].append(rrb)
             rr = syn.reference_frame(g, rrb)
@@ -76,6 +79,10 @@ class RecordedSim:
         self.dof_force = rollout.data["dof_force"][0].clone()
         self.dof_vel = rollout.data["dof_vel"][0].clone()
         self.pd_targets = torch.zeros(n, syn.NUM_DOF, device=dev)
+
+    @property
+    def gt_action(self):
+        return self.rollout.data["gt_action"][self.frame]
 
     def rewind(self):
         self.frame = 0

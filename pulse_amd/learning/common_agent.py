@@ -109,6 +109,9 @@ class CommonAgent:
         else:
             raise NotImplementedError("normalize_input: False (every shipped config sets True; amp_agent.py:594-603 requires it)")
         self.value_mean_std = RunningMeanStd((1,), device=self.ppo_device) if self.normalize_value else None
+        seed = int(config.get("seed", 0)) + self.rank                       # run_hydra.py:124
+        self.noise_generator = torch.Generator(device=self.ppo_device)
+        self.noise_generator.manual_seed(seed)
         self.model = self._build_model(net_config)
         self.last_lr = float(self.last_lr)
         # Adam(lr, eps=1e-8) over the flat parameter buffer (common_agent.py:66)
@@ -120,9 +123,6 @@ class CommonAgent:
         self._grad_norm = torch.zeros(1, device=self.ppo_device)
         self._loss_partials = torch.zeros(max(1, min(512, self.minibatch_size // 16)), 8, device=self.ppo_device)
         self._adv_partials = torch.zeros(128, 2, dtype=torch.float64, device=self.ppo_device)
-        seed = int(config.get("seed", 0)) + self.rank                       # run_hydra.py:124
-        self.noise_generator = torch.Generator(device=self.ppo_device)
-        self.noise_generator.manual_seed(seed)
         perm_gen = torch.Generator()
         perm_gen.manual_seed(seed)
         self.dataset = rlg.AMPDataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn, self.ppo_device, self.seq_len,
@@ -151,6 +151,12 @@ class CommonAgent:
 
     def _build_model(self, net_config):
         params = self.config["network"]
+        if params.get("name", "amp") == "amp_z":
+            from .model_z import AMPZModel
+            task = self.vec_env.env.task
+            return AMPZModel(params, actions_num=net_config["actions_num"], self_obs_size=task.get_self_obs_size(),
+                             task_obs_size=task.get_task_obs_size(), task_obs_size_detail=task.get_task_obs_size_detail(),
+                             device=self.ppo_device, split_k=int(self.config.get("split_k", 8)), generator=self.noise_generator)
         return A2CNetwork(params, actions_num=net_config["actions_num"], input_shape=net_config["input_shape"],
                           value_size=net_config["value_size"], device=self.ppo_device, split_k=int(self.config.get("split_k", 8)))
 
@@ -236,9 +242,9 @@ class CommonAgent:
         else:
             noise = torch.randn(n, self.actions_num, device=self.ppo_device, generator=self.noise_generator)
         vm = self.value_mean_std
-        K.policy_sample(ws["heads"], 2 * ap, net.sigma, noise, self.actions_num, n, self.actions_num,
+        K.policy_sample(ws["mu"], ws["mu"].stride(0), net.sigma, noise, self.actions_num, n, self.actions_num,
                         eb.phys["actions"], t * ap, eb.phys["neglogpacs"], t, sigmas=eb.phys["sigmas"], sigmas_stride=t * ap,
-                        value_raw=ws["val"], value_stride=2 * ap, value_mean=vm.running_mean if vm else None,
+                        value_raw=ws["val"], value_stride=ws["val"].stride(0), value_mean=vm.running_mean if vm else None,
                         value_var=vm.running_var if vm else None, values=eb.phys["values"], values_stride=t,
                         mus_out=eb.phys["mus"], mus_out_stride=t * ap, mus_out_off=s * ap,
                         actions_off=s * ap, sigmas_off=s * ap, neglogp_off=s, values_off=s)
@@ -271,11 +277,12 @@ class CommonAgent:
             res_dict = self.get_action_values(self.obs, slot=n)
             for k in self.update_list:
                 eb.update_data(k, n, res_dict[k])
-            self.obs, rewards, self.dones, infos = self.env_step(res_dict["actions"])
+            self.obs, rewards, self.dones, infos = self.env_step(self._action_for_env(res_dict))
             shaped_rewards = self.rewards_shaper(rewards)
             eb.update_data("rewards", n, shaped_rewards)
             eb.update_data("next_obses", n, self.obs["obs"])
             eb.update_data("dones", n, self.dones)
+            self._after_env_step(n, infos)
             terminated = infos["terminate"].float().unsqueeze(-1)
             next_vals = self._eval_critic(self.obs)
             next_vals *= (1.0 - terminated)
@@ -299,6 +306,12 @@ class CommonAgent:
         batch_dict["advs_raw"] = rlg.swap_and_flatten01(mb_advs)
         batch_dict["played_frames"] = self.batch_size
         return batch_dict
+
+    def _action_for_env(self, res_dict):
+        return res_dict["actions"]
+
+    def _after_env_step(self, n, infos):
+        return
 
     def discount_values(self, mb_fdones, mb_values, mb_rewards, mb_next_values):
         return ops.discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, self.gamma, self.tau)
@@ -362,16 +375,19 @@ class CommonAgent:
         net = self.model
         ws = net.workspace(mb, train=True)
         norm, live = self._obs_normalizer_for_update()
-        norm.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch)
-        if live is not None:      # AMPAgent: normalise with the frozen copy, still update the live stats
-            live.update_only(obs_store, idx)
+        if live is not None:      # AMPAgent: output from the frozen copy, live statistics still updated (one pass)
+            live.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch, norm_with=norm)
+        else:
+            norm.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch)
         net.forward(ws, mb)
         ap = net.a_pitch
-        K.ppo_loss(mu=ws["heads"], mu_stride=2 * ap, value=ws["val"], value_stride=2 * ap, logstd=net.sigma, old_logstd=net.sigma, idx=idx,
+        K.ppo_loss(mu=ws["mu"], mu_stride=ws["mu"].stride(0), value=ws["val"], value_stride=ws["val"].stride(0), logstd=net.sigma,
+                   old_logstd=net.sigma, idx=idx,
                    actions=act_store, actions_stride=act_store.stride(0), old_mu=mu_store, old_mu_stride=mu_store.stride(0),
                    old_neglogp=old_nlp, advantages=adv, old_values=old_val, returns=ret, rows=mb, num_actions=self.actions_num,
                    e_clip=self.e_clip, critic_coef=self.critic_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
-                   dmu=ws["dheads"], dmu_stride=2 * ap, dvalue=ws["dheads"][:, ap:], dvalue_stride=2 * ap, partials=self._loss_partials)
+                   dmu=ws["dmu"], dmu_stride=ws["dmu"].stride(0), dvalue=ws["dval"], dvalue_stride=ws["dval"].stride(0),
+                   partials=self._loss_partials)
         net.backward(ws, mb, grad_scale=1.0 / self.world_size)
         if self.multi_gpu:
             self.dist.sync_gradients(net.grad)                          # optimizer.synchronize()

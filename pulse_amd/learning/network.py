@@ -205,8 +205,8 @@ class A2CNetwork:
         dev, u = self.device, self.units
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         ws = {"x": e(m, self.in_pitch), "h": [e(m, 2 * uu) for uu in u], "heads": torch.zeros(m, 2 * self.a_pitch, device=dev)}
-        ws["mu"] = ws["heads"][:, :self.actions_num]
-        ws["val"] = ws["heads"][:, self.a_pitch:self.a_pitch + 1]
+        ws["mu"] = ws["heads"][:, :self.actions_num]                        # (m, A) view, row pitch 2*a_pitch
+        ws["val"] = ws["heads"][:, self.a_pitch:self.a_pitch + 1]           # (m, 1) view
         if self.act == ACT_SILU:
             ws["z"] = [e(m, 2 * uu) for uu in u]
         ws["plan_fwd"] = self._plan_forward(ws, m, 0, 2)
@@ -214,6 +214,8 @@ class A2CNetwork:
         if train:
             ws["dh"] = [e(m, 2 * uu) for uu in u]
             ws["dheads"] = torch.zeros(m, 2 * self.a_pitch, dtype=torch.float32, device=dev)
+            ws["dmu"] = ws["dheads"][:, :self.actions_num]
+            ws["dval"] = ws["dheads"][:, self.a_pitch:self.a_pitch + 1]
             if self._slabs is None:
                 self._slabs = torch.zeros(self.split_k, self.n_flat, dtype=torch.float32, device=dev)
                 self._bias_chunks = 64

@@ -88,8 +88,8 @@ class AMPDataset:
     kernels (normaliser, PPO loss).  ``gather(i)`` materialises the reference-style dict."""
 
     def __init__(self, batch_size, minibatch_size, is_discrete, is_rnn, device, seq_len, generator=None):
-        if is_rnn:
-            raise NotImplementedError("sequence minibatches (use_seq_rl) are part of the PULSE-VAE row")
+        self.is_rnn = bool(is_rnn)          # use_seq_rl: minibatches are whole env sequences (amp_datasets.py:36-79)
+        self.horizon_length, self.num_envs = 1, batch_size
         self.batch_size, self.minibatch_size = batch_size, minibatch_size
         self.device = torch.device(device)
         self.length = batch_size // minibatch_size
@@ -100,22 +100,23 @@ class AMPDataset:
         self._pin_i = 0
         self._idx_buf = self._randperm()
 
-    def _randperm(self):
+    def _randperm(self, n=None):
         """Drawn on the CPU like the reference (torch.randperm(self.batch_size), amp_datasets.py:7) so a shared
         seed reproduces the oracle's minibatches, then uploaded through a rotating PINNED staging buffer with a
         non-blocking copy: a pageable .to(device) would stall the host until the GPU drains its queue."""
+        n = self.batch_size if n is None else n
         if self.device.type != "cuda":
-            return torch.randperm(self.batch_size, generator=self.generator)
+            return torch.randperm(n, generator=self.generator)
         if self._pinned is None:
             self._pinned = [torch.empty(self.batch_size, dtype=torch.int64).pin_memory() for _ in range(3)]
             self._pin_done = [None, None, None]
         i = self._pin_i % 3
         self._pin_i += 1
-        buf = self._pinned[i]
+        buf = self._pinned[i][:n]
         if self._pin_done[i] is not None:
             self._pin_done[i].synchronize()      # the host may run several mini-epochs ahead of the GPU: never overwrite a
                                                  # staging buffer whose upload has not executed yet
-        torch.randperm(self.batch_size, generator=self.generator, out=buf)
+        torch.randperm(n, generator=self.generator, out=buf)
         dev = buf.to(self.device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -125,17 +126,37 @@ class AMPDataset:
     def set_permutation(self, perm):
         self._idx_buf = perm.to(self.device, torch.int64)
 
-    def update_values_dict(self, values_dict, **_):
+    def update_values_dict(self, values_dict, rnn_format=False, horizon_length=1, num_envs=1):
         self.values_dict = values_dict
+        self.horizon_length, self.num_envs = horizon_length, num_envs
+        if rnn_format and self.is_rnn:
+            # rows are already env-major (row = env * T + t), so "view(num_envs, T, -1)" is implicit; only the
+            # permutation changes: it shuffles ENVS (amp_datasets.py:47)
+            self._perm_n = num_envs
+            self._idx_buf = self._randperm(num_envs)
+            self._t_range = torch.arange(horizon_length, device=self.device)
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, idx):
+        if self.is_rnn:
+            return self._get_item_rnn(idx)
         start, end = idx * self.minibatch_size, (idx + 1) * self.minibatch_size
         out = {"idx": self._idx_buf[start:end], "dataset": self.values_dict}
         if end >= self.batch_size:
             self._shuffle_idx_buf()
+        return out
+
+    def _get_item_rnn(self, idx):
+        """amp_datasets.py:54-79: step_size = minibatch // T env sequences, rows of each env kept in time order."""
+        t = self.horizon_length
+        step = self.minibatch_size // t
+        envs = self._idx_buf[idx * step:(idx + 1) * step]
+        rows = (envs[:, None] * t + self._t_range[None, :]).reshape(-1)
+        out = {"idx": rows, "dataset": self.values_dict, "num_seqs": step}
+        if (idx + 1) * step * t >= self.batch_size:
+            self._idx_buf = self._randperm(self._perm_n)
         return out
 
     def gather(self, idx):

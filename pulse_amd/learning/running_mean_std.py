@@ -83,7 +83,7 @@ class RunningMeanStd:
             self._partials = torch.empty(nblk, 2, self.mean_size, dtype=torch.float64, device=self.device)
         return self._partials
 
-    def forward(self, input, unnorm=False, *, row_idx=None, out=None, out_cols=None, update=None):
+    def forward(self, input, unnorm=False, *, row_idx=None, out=None, out_cols=None, update=None, norm_with=None):
         """input: (rows, >=mean_size) float32 with unit inner stride.  Returns ``out`` (allocated
         (rows, mean_size) when not given).  ``update`` overrides the training/frozen rule."""
         x = input
@@ -96,7 +96,8 @@ class RunningMeanStd:
         do_update = (self.training and not self.forzen) if update is None else update
         do_update = do_update and not unnorm
         part = self._moment_buffer(rows) if do_update else None
-        K.rms_normalize(x, self.running_mean, self.running_var, rows=rows, cols=f, x_stride=x.stride(0), y=out,
+        src = self if norm_with is None else norm_with       # AMPAgent._preproc_obs(use_temp): output from the frozen copy,
+        K.rms_normalize(x, src.running_mean, src.running_var, rows=rows, cols=f, x_stride=x.stride(0), y=out,  # update of the live stats
                         y_stride=out.stride(0), y_cols=out.shape[1] if out_cols is None else out_cols, row_idx=row_idx,
                         eps=self.epsilon, unnorm=unnorm, moment_partials=part,
                         num_blocks=None if part is None else part.shape[0])

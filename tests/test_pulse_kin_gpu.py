@@ -1,0 +1,71 @@
+"""GPU: PULSE distillation step (AMPAgent._optimize_kin: action RMSE + KL(q || learned prior) + AR(1)) and the
+amp_z PPO path, against the torch-CPU restatement; plus end-to-end epochs of both agent modes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import agent_oracle as AO
+from pulse_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_close(a, b, tol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_optimize_kin_matches_reference_formulas(dev):
+    torch.manual_seed(5)
+    agent, _ = configs.make_agent("cfg3_small", device=str(dev), seed=5)
+    agent.init_tensors()
+    ref = AO.OracleNetZ()
+    agent.model.load_state_dict(ref.state_dict_ref())
+    t, mb = agent.horizon_length, agent.minibatch_size
+    obs = torch.randn(mb, 934).clamp(-5, 5)
+    gt = (0.4 * torch.randn(mb, 69)).clamp(-1, 1)
+    prog = (torch.randint(0, 40, (mb // t, 1)) + torch.arange(t)[None, :]).reshape(-1, 1)
+    prog[3 * t + 5:3 * t + t] = torch.arange(t - 5)[:, None]                  # an episode seam inside sequence 3 (reset -> progress restarts)
+    noise = torch.randn(mb, 32)
+    info_ref = AO.oracle_optimize_kin(ref, obs, gt, prog, noise, t)
+    ws = agent.model.workspace(mb, train=True)
+    ws["x"].zero_()
+    ws["x"][:, :934] = obs.to(dev)
+    agent.z_noise_provider = lambda m: noise.to(dev)
+    agent.set_train()
+    info = agent._optimize_kin(ws, mb, {"gt_action": gt.to(dev), "progress_buf": prog.to(dev)})
+    for k in ("kin_action_loss", "kin_KLD", "kin_ar1", "kin_loss"):
+        np.testing.assert_allclose(info[k].item(), info_ref[k].item(), rtol=2e-5, err_msg=k)
+    grads = agent.model.net.gradients()
+    total_sq = 0.0
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            assert torch.count_nonzero(grads["a2c_network." + name]) == 0, f"{name} must get no gradient in kin mode"
+            continue
+        rel_close(grads["a2c_network." + name], p.grad, 3e-4, f"grad {name}")
+        total_sq += p.grad.double().pow(2).sum().item()
+    np.testing.assert_allclose(info["grad_norm"].item(), total_sq ** 0.5, rtol=1e-4)     # grad-norm within 1e-4
+
+
+@pytest.mark.parametrize("name", ["cfg3_small", "cfg3_ppo_small"])
+def test_amp_z_agent_epochs_run_and_learn(dev, name):
+    agent, _ = configs.make_agent(name, device=str(dev), seed=3)
+    before = agent.model.flat.clone()
+    first = None
+    for e in range(3):
+        info = agent.train_epoch()
+        key = "kin_loss" if "kin_loss" in info else "critic_loss"
+        val = torch.stack(info[key]).mean().item()
+        assert np.isfinite(val)
+        first = val if first is None else first
+    assert val < first, f"{key} should decrease over 3 epochs ({first} -> {val})"
+    assert not torch.equal(before, agent.model.flat)
+    eb = agent.experience_buffer
+    assert torch.isfinite(eb.tensor_dict["mus"]).all() and torch.isfinite(eb.tensor_dict["values"]).all()
+    if name == "cfg3_small":
+        # kin mode: the env was stepped with mus; the critic never receives a gradient
+        g = agent.model.net.gradients()
+        assert torch.count_nonzero(g["a2c_network.critic_mlp.0.weight"]) == 0
+        assert eb.tensor_dict["kin_dict"].shape[-1] == 70                      # gt_action (69) + progress_buf (1)

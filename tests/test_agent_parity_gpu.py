@@ -91,7 +91,7 @@ def test_train_epoch_parity(dev, name, over):
     for k, v in oracle.model.state_dict_ref().items():
         d = (sd[k].cpu().double() - v.double()).abs()
         assert d.max().item() <= bound, k
-        assert (d > 2e-6 + 1e-4 * v.double().abs()).double().mean().item() < 0.01, k
+        assert (d > 2e-6 + 1e-4 * v.double().abs()).double().mean().item() < 0.03, k
     cmp(agent.running_mean_std.running_mean, oracle.running_mean_std.running_mean, 1e-5, 1e-5)
     cmp(agent.running_mean_std.running_var, oracle.running_mean_std.running_var, 1e-5, 1e-4)
     assert agent.running_mean_std.count.item() == oracle.running_mean_std.count.item()

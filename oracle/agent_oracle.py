@@ -432,3 +432,15 @@ def oracle_optimize_kin(net, obs, gt_action, progress_buf, noise, horizon, kld_c
     kin_loss.backward()
     info.update({"kin_action_loss": kin_action_loss.detach(), "kin_KLD": KLD.detach(), "kin_loss": kin_loss.detach()})
     return info
+
+
+def oracle_compute_z_actions(net, obs_buf, running_mean, running_var, action_z):
+    """HumanoidZ.compute_z_actions, phc/env/tasks/humanoid_z.py:81-155 (z_type 'vae', use_vae_prior, not z_all),
+    with the frozen sub-networks of network_loader.load_z_decoder (:139-176)."""
+    with torch.no_grad():
+        s = net.self_obs_size
+        self_obs = (obs_buf[:, :s] - running_mean.float()[:s]) / torch.sqrt(running_var.float()[:s] + 1e-05)
+        prior_mu = net.z_prior_mu(net.z_prior(self_obs))
+        z = prior_mu + action_z
+        self_obs = torch.clamp(self_obs, min=-5.0, max=5.0)
+        return net.mu(net.actor_mlp(torch.cat([self_obs, z], dim=-1)))

@@ -71,3 +71,25 @@ def test_amp_z_agent_epochs_run_and_learn(dev, name):
         g = agent.model.net.gradients()
         assert torch.count_nonzero(g["a2c_network.critic_mlp.0.weight"]) == 0
         assert eb.tensor_dict["kin_dict"].shape[-1] == 70                      # gt_action (69) + progress_buf (1)
+
+
+def test_humanoid_z_decoder_in_env(dev):
+    """Downstream mode: latent action -> frozen prior + decoder -> 69-d PD action inside env.step."""
+    from pulse_amd.env.humanoid_z import HumanoidImZ
+    from pulse_amd.env.sim import RecordedMotion, RecordedRollout, RecordedSim
+    torch.manual_seed(9)
+    n = 130
+    rollout = RecordedRollout(n, 3, seed=21).to(dev)
+    sim = RecordedSim(rollout)
+    task = HumanoidImZ({"env": dict(configs.ENV_IM, embedding_size=32)}, sim, RecordedMotion(rollout, sim), device=dev)
+    assert task.num_actions == 32
+    ref = AO.OracleNetZ()
+    rm, rv = torch.randn(934).double() * 0.3, (torch.rand(934) + 0.5).double()
+    task.initialize_z_models({"model": ref.state_dict_ref(), "running_mean_std": {"running_mean": rm, "running_var": rv}}, configs.NETWORK_Z)
+    task.reset()
+    az = 0.5 * torch.randn(n, 32)
+    act = task.compute_z_actions(az.to(dev)).clone()
+    want = AO.oracle_compute_z_actions(ref, task.obs_buf.cpu(), rm, rv, az)
+    rel_close(act, want, 5e-5, "z -> action")
+    task.step(az.to(dev))                                                       # full step with the latent action
+    assert torch.isfinite(task.obs_buf).all() and task.rew_buf.shape == (n,)

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 3
+#define PULSE_ABI_VERSION 4
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -153,6 +153,23 @@ int pulse_sizeof_im_step_args(void);
 int pulse_self_obs_width(int num_bodies, int root_height_obs);
 int pulse_task_obs_width(int obs_version, int num_track, int time_steps);
 int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s);
+
+/* AMP per-frame observation: build_amp_observations_smpl (phc/env/tasks/humanoid_amp.py:925-969) +
+ * dof_to_obs_smpl (phc/env/tasks/humanoid.py:1436-1446). */
+typedef struct pulse_amp_obs_args {
+    const float* rb; int64_t rb_env_stride;  /* (num_envs, bodies, 13); root = body 0 */
+    const float* dof_pos; const float* dof_vel; int32_t num_dof;   /* (num_envs, num_dof) exp-map dofs, 3 per joint */
+    int32_t num_envs;
+    const int64_t* env_ids; int32_t num_ids; const uint8_t* env_mask;   /* optional subset (as pulse_im_step) */
+    const int32_t* joint_ids; int32_t num_joints;     /* dof joints entering the obs (NULL = 0..num_joints-1); dof_subset */
+    uint32_t zero_joint_mask;                          /* bit j: joint j's dof pos / vel read as zero (humanoid_amp.py:636-639) */
+    const int32_t* key_body_ids; int32_t num_key_bodies;
+    int32_t local_root_obs, root_height_obs;
+    float* out; int64_t out_stride;                    /* (num_envs, out_stride), first W columns written */
+} pulse_amp_obs_args;
+int pulse_sizeof_amp_obs_args(void);
+int pulse_amp_obs_width(int num_joints, int num_key_bodies, int root_height_obs);
+int pulse_amp_obs(const pulse_amp_obs_args* args, pulse_stream_t s);
 
 /* ------------------------------------------------------------------------- *
  * 3. GAE: CommonAgent.discount_values + returns, phc/learning/common_agent.py:493-505,

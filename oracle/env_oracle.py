@@ -201,3 +201,28 @@ def post_physics(rb, ref_now, ref_next, dof_force, dof_vel, progress, pass_time,
     else:
         raise NotImplementedError(obs_v)
     return {"obs": torch.cat([so, to], dim=-1), "rew": rew, "raw": raw, "reset": reset, "terminate": term}
+
+
+def dof_to_obs_smpl(pose):
+    """dof_to_obs_smpl, phc/env/tasks/humanoid.py:1436-1446: exp-map dofs (B, 3 Jd) -> 6-D rotations (B, 6 Jd)."""
+    b = pose.shape[0]
+    return R.q_to_tan_norm(R.exp_map_to_q(pose.reshape(-1, 3))).reshape(b, -1)
+
+
+def amp_obs_smpl(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_body_pos, dof_subset=None,
+                 local_root_obs=True, root_height_obs=True):
+    """build_amp_observations_smpl, phc/env/tasks/humanoid_amp.py:925-969 (upright, no shape / limb obs)."""
+    h_inv = R.heading_q_inv(root_rot)
+    rot6 = R.q_to_tan_norm(R.qmul(h_inv, root_rot) if local_root_obs else root_rot)
+    lvel = R.qrot(h_inv, root_vel)
+    lang = R.qrot(h_inv, root_ang_vel)
+    rel = key_body_pos - root_pos.unsqueeze(-2)
+    nk = rel.shape[1]
+    h_e = h_inv.unsqueeze(-2).repeat((1, nk, 1))
+    lkey = R.qrot(h_e.view(-1, 4), rel.view(-1, 3)).view(rel.shape[0], nk * 3)
+    if dof_subset is not None:
+        dof_vel = dof_vel[:, dof_subset]
+        dof_pos = dof_pos[:, dof_subset]
+    parts = [root_pos[:, 2:3]] if root_height_obs else []
+    parts += [rot6, lvel, lang, dof_to_obs_smpl(dof_pos), dof_vel, lkey]
+    return torch.cat(parts, dim=-1)

@@ -11,6 +11,7 @@ outputs are stored side by side so the fixtures are self-contained.
 Fixtures (all small, < 1 MB each):
   rotations.npz   every quaternion / exp-map / 6-D op on the path + edge cases
   env_im.npz      self-obs, task-obs v6 / v7, imitation reward (+power), im-reset
+  env_amp.npz     AMP per-frame observation (full 23 joints, 19-joint dof subset, global root)
   agent_math.npz  GAE discount_values, PPO actor/critic/bound losses, _calc_advs
   rms.npz         RunningMeanStd forward sequences (fp64 state), kl_multi
 """
@@ -139,6 +140,33 @@ def gen_env_im(n=67):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "env_im.npz"), **_np(out))
 
 
+def gen_env_amp(n=67):
+    """AMP per-frame observation from the reference's build_amp_observations_smpl (+ dof_to_obs_smpl)."""
+    fn = refload.env_functions()
+    g = syn.make_generator(4242)
+    rb = syn.rigid_body_state(g, n)
+    dof_pos = torch.randn(n, 69, generator=g) * 0.7
+    dof_pos[0, 0:3] = 0.0                                   # zero exp-map -> masked branch
+    dof_pos[1, 3:6] = torch.tensor([0.0, 0.0, 1e-6])
+    dof_vel = torch.randn(n, 69, generator=g)
+    key = [7, 3, 22, 17]                                    # R_Ankle, L_Ankle, R_Wrist, L_Wrist (env_im.yaml:35)
+    bp, br, bv, ba = rb[..., 0:3], rb[..., 3:7], rb[..., 7:10], rb[..., 10:13]
+    empty = torch.zeros(n, 0)
+    none_subset = torch.zeros(0, dtype=torch.long)
+    full = fn["build_amp_observations_smpl"](bp[:, 0], br[:, 0], bv[:, 0], ba[:, 0], dof_pos, dof_vel, bp[:, key], empty, empty,
+                                             none_subset, True, True, False, False, False, True)
+    joints19 = [j for j in range(23) if j not in (3, 7, 17, 22)]        # drop toes / hands (dofs 9:12, 21:24, 51:54, 66:69)
+    subset = torch.tensor([3 * j + k for j in joints19 for k in range(3)], dtype=torch.long)
+    sub = fn["build_amp_observations_smpl"](bp[:, 0], br[:, 0], bv[:, 0], ba[:, 0], dof_pos, dof_vel, bp[:, key], empty, empty,
+                                            subset, True, False, True, False, False, True)
+    glob = fn["build_amp_observations_smpl"](bp[:, 0], br[:, 0], bv[:, 0], ba[:, 0], dof_pos, dof_vel, bp[:, key], empty, empty,
+                                             none_subset, False, True, False, False, False, True)
+    out = {"rb": rb, "dof_pos": dof_pos, "dof_vel": dof_vel, "key_body_ids": np.array(key), "joints19": np.array(joints19),
+           "amp_obs_full": full, "amp_obs_subset19_noheight": sub, "amp_obs_global_root": glob,
+           "dof_to_obs": fn["dof_to_obs_smpl"](dof_pos)}
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "env_amp.npz"), **_np(out))
+
+
 def gen_agent_math():
     m = refload.agent_methods()
     g = syn.make_generator(4321)
@@ -226,6 +254,7 @@ def main():
     torch.set_num_threads(1)
     gen_rotations()
     gen_env_im()
+    gen_env_amp()
     gen_agent_math()
     gen_rms()
     for f in sorted(os.listdir(GOLDEN_DIR)):

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -45,6 +45,14 @@ class ImStepArgs(Structure):
         ("obs", c_void_p), ("obs_stride", c_int64), ("obs_cols", c_int32),
         ("rew", c_void_p), ("rew_raw", c_void_p), ("reset", c_void_p), ("terminate", c_void_p),
     ]
+
+
+class AmpObsArgs(Structure):
+    _fields_ = [("rb", c_void_p), ("rb_env_stride", c_int64), ("dof_pos", c_void_p), ("dof_vel", c_void_p), ("num_dof", c_int32),
+                ("num_envs", c_int32), ("env_ids", c_void_p), ("num_ids", c_int32), ("env_mask", c_void_p),
+                ("joint_ids", c_void_p), ("num_joints", c_int32), ("zero_joint_mask", c_uint32),
+                ("key_body_ids", c_void_p), ("num_key_bodies", c_int32), ("local_root_obs", c_int32), ("root_height_obs", c_int32),
+                ("out", c_void_p), ("out_stride", c_int64)]
 
 
 class GemmDesc(Structure):
@@ -96,6 +104,9 @@ SIGNATURES = {
     "pulse_self_obs_width": (c_int, [c_int, c_int]),
     "pulse_task_obs_width": (c_int, [c_int, c_int, c_int]),
     "pulse_im_step": (c_int, [POINTER(ImStepArgs), P]),
+    "pulse_sizeof_amp_obs_args": (c_int, []),
+    "pulse_amp_obs_width": (c_int, [c_int, c_int, c_int]),
+    "pulse_amp_obs": (c_int, [POINTER(AmpObsArgs), P]),
     "pulse_gae": (c_int, [P, P, P, P, c_int32, c_int32, c_int64, c_int64, c_float, c_float, P, P, P]),
     "pulse_sizeof_gemm_desc": (c_int, []),
     "pulse_gemm_f32": (c_int, [POINTER(GemmDesc), P]),

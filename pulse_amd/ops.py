@@ -19,7 +19,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS, ImStepArgs, RewardSpecs
+from ._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS, AmpObsArgs, ImStepArgs, RewardSpecs
 
 DEFAULT_REWARD_SPECS = {"k_pos": 100.0, "k_rot": 10.0, "k_vel": 0.1, "k_ang_vel": 0.1,
                         "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1}
@@ -371,6 +371,51 @@ def compute_humanoid_im_reset(reset_buf, progress_buf, contact_buf, contact_body
     out = im_step(rb, what=PULSE_IM_RESET, ref_now=ref, progress=progress_buf, pass_time=pass_time,
                   reset_ids=list(range(jr)), term_dist=td.contiguous(), reset_use_mean=use_mean)
     return out["reset"], out["terminate"]
+
+
+# --------------------------------------------------------------------------- #
+# AMP observation
+# --------------------------------------------------------------------------- #
+def amp_obs_width(num_joints, num_key_bodies, root_height_obs=True):
+    return _lib.load().pulse_amp_obs_width(num_joints, num_key_bodies, int(root_height_obs))
+
+
+def build_amp_observations_smpl(rb, dof_pos, dof_vel, key_body_ids, *, joint_ids=None, zero_joints=(), local_root_obs=True,
+                                root_height_obs=True, out=None, env_ids=None, env_mask=None):
+    """phc/env/tasks/humanoid_amp.py:925-969 on the (N, bodies, 13) rigid-body records (root = body 0) and the
+    (N, num_dof) dof tensors.  ``joint_ids`` = dof_subset expressed in joints; ``zero_joints`` = joints whose dofs
+    read as zero (:636-639).  Writes the first W columns of ``out`` rows (any row pitch) and returns ``out``."""
+    lib = _lib.load()
+    rb = _dev(rb, "rb")
+    n = rb.shape[0]
+    dev = rb.device
+    dof_pos, dof_vel = _c(dof_pos, "dof_pos"), _c(dof_vel, "dof_vel")
+    kb = _ids32(key_body_ids, dev)
+    ji = _ids32(joint_ids, dev) if joint_ids is not None else None
+    nj = ji.numel() if ji is not None else dof_pos.shape[-1] // 3
+    w = lib.pulse_amp_obs_width(nj, kb.numel(), int(root_height_obs))
+    if out is None:
+        out = torch.empty(n, w, dtype=torch.float32, device=dev)
+    a = AmpObsArgs()
+    a.rb, a.rb_env_stride = rb.data_ptr(), rb.stride()[0]
+    a.dof_pos, a.dof_vel, a.num_dof, a.num_envs = dof_pos.data_ptr(), dof_vel.data_ptr(), dof_pos.shape[-1], n
+    keep = [kb, ji, dof_pos, dof_vel]
+    if env_ids is not None:
+        env_ids = _c(env_ids, "env_ids", torch.int64)
+        keep.append(env_ids)
+        a.env_ids, a.num_ids = env_ids.data_ptr(), env_ids.numel()
+    if env_mask is not None:
+        m = env_mask.view(torch.uint8) if env_mask.dtype == torch.bool else env_mask
+        m = _c(m, "env_mask", torch.uint8)
+        keep.append(m)
+        a.env_mask = m.data_ptr()
+    a.joint_ids, a.num_joints = (ji.data_ptr() if ji is not None else None), nj
+    a.zero_joint_mask = sum(1 << int(j) for j in zero_joints)
+    a.key_body_ids, a.num_key_bodies = kb.data_ptr(), kb.numel()
+    a.local_root_obs, a.root_height_obs = int(local_root_obs), int(root_height_obs)
+    a.out, a.out_stride = out.data_ptr(), out.stride()[0]
+    _lib.check(lib.pulse_amp_obs(ctypes.byref(a), _stream()), "pulse_amp_obs")
+    return out
 
 
 # --------------------------------------------------------------------------- #

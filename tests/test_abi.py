@@ -50,4 +50,5 @@ def test_struct_layout_matches_c():
     assert ctypes.sizeof(_lib.RewardSpecs) == 40
     assert ctypes.sizeof(_lib.ImStepArgs) == _lib.load().pulse_sizeof_im_step_args()
     assert ctypes.sizeof(_lib.GemmDesc) == _lib.load().pulse_sizeof_gemm_desc()
+    assert ctypes.sizeof(_lib.AmpObsArgs) == _lib.load().pulse_sizeof_amp_obs_args()
     assert ctypes.sizeof(_lib.PpoLossArgs) == _lib.load().pulse_sizeof_ppo_loss_args()

@@ -273,3 +273,34 @@ def test_gae_env_major_layout_and_properties(dev):
     ones = torch.ones(t, n, dtype=torch.uint8, device=dev)
     adv3 = ops.discount_values(ones, v.to(dev), r.to(dev), nv.to(dev), 0.99, 0.95)
     close(adv3, r + 0.99 * nv - v)
+
+
+# ------------------------------------------------------------------ AMP observation
+def test_amp_obs_vs_golden(golden, dev):
+    g = golden("env_amp.npz")
+    rb, dp, dv = g.t("rb", dev), g.t("dof_pos", dev), g.t("dof_vel", dev)
+    key = list(g.np("key_body_ids"))
+    close(ops.build_amp_observations_smpl(rb, dp, dv, key), g.np("amp_obs_full"))
+    j19 = list(g.np("joints19"))
+    close(ops.build_amp_observations_smpl(rb, dp, dv, key, joint_ids=j19, root_height_obs=False), g.np("amp_obs_subset19_noheight"))
+    close(ops.build_amp_observations_smpl(rb, dp, dv, key, local_root_obs=False), g.np("amp_obs_global_root"))
+    # written straight into slot 0 of an (N, 10, W) history buffer; other slots untouched
+    hist = torch.full((67, 10, 232), 4.0, device=dev)
+    ops.build_amp_observations_smpl(rb, dp, dv, key, out=hist[:, 0])
+    close(hist[:, 0], g.np("amp_obs_full"))
+    assert torch.equal(hist[:, 1:].cpu(), torch.full((67, 9, 232), 4.0))
+    # the "zeroed toes / hands" variant equals the reference on inputs whose dofs were zeroed beforehand
+    zj = (3, 7, 17, 22)
+    dp0, dv0 = dp.clone(), dv.clone()
+    for j in zj:
+        dp0[:, 3 * j:3 * j + 3] = 0
+        dv0[:, 3 * j:3 * j + 3] = 0
+    a = ops.build_amp_observations_smpl(rb, dp, dv, key, zero_joints=zj)
+    b = ops.build_amp_observations_smpl(rb, dp0, dv0, key)
+    assert torch.equal(a, b)
+    # env subset
+    ids = torch.tensor([66, 2, 31], dtype=torch.int64, device=dev)
+    out = torch.full((67, 232), -1.0, device=dev)
+    ops.build_amp_observations_smpl(rb, dp, dv, key, out=out, env_ids=ids)
+    close(out[ids], g.np("amp_obs_full")[ids.cpu().numpy()])
+    assert (out[0] == -1).all()

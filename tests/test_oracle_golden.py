@@ -84,3 +84,18 @@ def test_gae_bit_exact(golden, tag):
     adv = E.gae(g.t(f"gae_{tag}_dones").float(), g.t(f"gae_{tag}_values"), g.t(f"gae_{tag}_rewards"),
                 g.t(f"gae_{tag}_next_values"), 0.99, 0.95)
     assert same(adv, g.np(f"gae_{tag}_advs"))
+
+
+def test_amp_observation_bit_exact(golden):
+    g = golden("env_amp.npz")
+    rb = g.t("rb")
+    bp, br, bv, ba = E.split_rb(rb)
+    key = list(g.np("key_body_ids"))
+    args = (bp[:, 0], br[:, 0], bv[:, 0], ba[:, 0], g.t("dof_pos"), g.t("dof_vel"), bp[:, key])
+    assert same(E.amp_obs_smpl(*args), g.np("amp_obs_full"))
+    assert g.np("amp_obs_full").shape[1] == 232                               # 13 + 23*6 + 69 + 12 (humanoid_amp.py:299-303)
+    sub = [3 * j + k for j in g.np("joints19") for k in range(3)]
+    assert same(E.amp_obs_smpl(*args, dof_subset=sub, root_height_obs=False), g.np("amp_obs_subset19_noheight"))
+    assert g.np("amp_obs_subset19_noheight").shape[1] == 195                  # env_pulse_amp.yaml:61 width
+    assert same(E.amp_obs_smpl(*args, local_root_obs=False), g.np("amp_obs_global_root"))
+    assert same(E.dof_to_obs_smpl(g.t("dof_pos")), g.np("dof_to_obs"))

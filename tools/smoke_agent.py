@@ -10,8 +10,8 @@ print("setup", time.time() - t0, flush=True)
 for e in range(epochs):
     info = agent.train_epoch()
     n = agent.batch_size
+    keys = [k for k in ("actor_loss", "critic_loss", "kl", "kin_loss", "kin_action_loss", "kin_KLD", "kin_ar1", "grad_norm") if k in info]
+    stats = " ".join(f"{k} {torch.stack([torch.as_tensor(v).float().reshape(-1)[0] for v in info[k]]).mean().item():.5f}" for k in keys)
     print(f"epoch {e}: play {info['play_time']*1e3:.1f} ms update {info['update_time']*1e3:.1f} ms total {info['total_time']*1e3:.1f} ms "
-          f"-> {n / info['total_time']:.0f} env-steps/s | a_loss {torch.stack(info['actor_loss']).mean().item():.5f} "
-          f"c_loss {torch.stack(info['critic_loss']).mean().item():.5f} b_loss {torch.stack(info['b_loss']).mean().item():.5f} "
-          f"kl {torch.stack(info['kl']).mean().item():.6f} gnorm {torch.stack(info['grad_norm']).mean().item():.4f}", flush=True)
-print("reward mean", agent.experience_buffer.tensor_dict['rewards'].mean().item(), "dones", agent.experience_buffer.tensor_dict['dones'].float().mean().item())
+          f"-> {n / info['total_time']:.0f} env-steps/s | {stats}", flush=True)
+print("mem GB", torch.cuda.max_memory_allocated() / 2**30)

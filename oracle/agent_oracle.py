@@ -444,3 +444,53 @@ def oracle_compute_z_actions(net, obs_buf, running_mean, running_var, action_z):
         z = prior_mu + action_z
         self_obs = torch.clamp(self_obs, min=-5.0, max=5.0)
         return net.mu(net.actor_mlp(torch.cat([self_obs, z], dim=-1)))
+
+
+class OracleDisc(nn.Module):
+    """AMPBuilder.Network._build_disc / eval_disc, phc/learning/amp_network_builder.py:213-249."""
+
+    def __init__(self, amp_dim, units=(1024, 512)):
+        super().__init__()
+        layers, i = [], amp_dim
+        for u in units:
+            layers += [nn.Linear(i, u), nn.ReLU()]
+            i = u
+        self._disc_mlp = nn.Sequential(*layers)
+        self._disc_logits = nn.Linear(i, 1)
+        for m in self._disc_mlp.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.bias)
+        nn.init.uniform_(self._disc_logits.weight, -1.0, 1.0)
+        nn.init.zeros_(self._disc_logits.bias)
+
+    def eval_disc(self, amp_obs):
+        return self._disc_logits(self._disc_mlp(amp_obs))
+
+    def state_dict_ref(self):
+        return {"a2c_network." + k: v.detach().clone() for k, v in self.state_dict().items()}
+
+
+def oracle_disc_loss(disc, amp_obs, amp_obs_replay, amp_obs_demo, disc_logit_reg=0.01, disc_grad_penalty=5.0, disc_weight_decay=0.0001):
+    """AMPAgent._disc_loss, phc/learning/amp_agent.py:895-952 (inputs already normalised)."""
+    amp_obs_demo = amp_obs_demo.clone().requires_grad_(True)
+    disc_agent_logit = torch.cat([disc.eval_disc(amp_obs), disc.eval_disc(amp_obs_replay)], dim=0)
+    disc_demo_logit = disc.eval_disc(amp_obs_demo)
+    bce = torch.nn.BCEWithLogitsLoss()
+    disc_loss_agent = bce(disc_agent_logit, torch.zeros_like(disc_agent_logit))
+    disc_loss_demo = bce(disc_demo_logit, torch.ones_like(disc_demo_logit))
+    disc_loss = 0.5 * (disc_loss_agent + disc_loss_demo)
+    logit_weights = torch.flatten(disc._disc_logits.weight)
+    disc_logit_loss = torch.sum(torch.square(logit_weights))
+    disc_loss = disc_loss + disc_logit_reg * disc_logit_loss
+    disc_demo_grad = torch.autograd.grad(disc_demo_logit, amp_obs_demo, grad_outputs=torch.ones_like(disc_demo_logit), create_graph=True,
+                                         retain_graph=True, only_inputs=True)[0]
+    disc_grad_penalty_v = torch.mean(torch.sum(torch.square(disc_demo_grad), dim=-1))
+    disc_loss = disc_loss + disc_grad_penalty * disc_grad_penalty_v
+    if disc_weight_decay != 0:
+        ws = [torch.flatten(m.weight) for m in disc._disc_mlp.modules() if isinstance(m, nn.Linear)] + [torch.flatten(disc._disc_logits.weight)]
+        disc_loss = disc_loss + disc_weight_decay * torch.sum(torch.square(torch.cat(ws, dim=-1)))
+    agent_acc = torch.mean((disc_agent_logit < 0).float())
+    demo_acc = torch.mean((disc_demo_logit > 0).float())
+    return {"disc_loss": disc_loss, "disc_grad_penalty": disc_grad_penalty_v.detach(), "disc_logit_loss": disc_logit_loss.detach(),
+            "disc_agent_acc": agent_acc, "disc_demo_acc": demo_acc, "disc_agent_logit": disc_agent_logit.detach(),
+            "disc_demo_logit": disc_demo_logit.detach()}

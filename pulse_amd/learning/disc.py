@@ -1,0 +1,185 @@
+"""AMP discriminator on the gfx950 kernels, including the gradient penalty's double backward by hand.
+
+Mirrors AMPBuilder.Network._build_disc / eval_disc (phc/learning/amp_network_builder.py:213-249) and
+AMPAgent._disc_loss (phc/learning/amp_agent.py:895-952):
+
+    D(x) = w3 . relu(W2 relu(W1 x + b1) + b2) + b3
+    disc_loss = 0.5 (BCE(D(agent U replay), 0) + BCE(D(demo), 1))
+              + disc_logit_reg * ||w3||^2 + disc_grad_penalty * mean_demo || dD/dx ||^2
+              + disc_weight_decay * (||W1||^2 + ||W2||^2 + ||w3||^2)
+
+The reference gets the penalty's parameter gradient from autograd with create_graph=True.  For a ReLU MLP the
+input gradient is itself a (mask-gated) linear chain,   dD/dx = W1^T (m1 * (W2^T (m2 * w3))),   so its
+parameter gradients are ordinary GEMMs (masks are piecewise constant):
+    u2 = m2 * w3,  u1 = m1 * (u2 W2),  g = u1 W1,  P = mean ||g||^2,  dg = 2 c g / B
+    dW1 += u1^T dg ;  dt1 = m1 * (dg W1^T) ;  dW2 += u2^T dt1 ;  dw3 += sum_B m2 * (dt1 W2^T)
+Both gradient paths of a weight are accumulated by STACKING them along the reduction (batch) dimension:
+rows [0, 3B) of the operand buffers hold the BCE path (dz, activations), rows [3B, 4B) the penalty path
+(u, d-terms), and one batch-split GEMM per weight reduces over all 4B rows.  Every product above is one of
+the three layouts of gemm_f32_kernel with the ReLU-mask epilogue; no autograd graph, no second-order tape.
+"""
+import torch
+
+from .. import kernels as K
+from .._lib import ACT_NONE, ACT_RELU, EPI_BIAS_ACT, EPI_RELU_GRAD, GEMM_OUT_CONTIG
+from .graph import Linear, ParamBook, init_linear_, r4
+
+
+class DiscNetwork:
+    def __init__(self, params, amp_input_dim, device="cuda:0", split_k=8):
+        self.device = torch.device(device)
+        units = [int(u) for u in params["disc"]["units"]]
+        if len(units) != 2 or params["disc"]["activation"] != "relu":
+            raise NotImplementedError("discriminator: two ReLU hidden layers (every shipped config)")
+        self.u1, self.u2 = units
+        self.k0 = int(amp_input_dim)
+        self.k0p = r4(self.k0)
+        self.book = ParamBook(self.device, split_k)
+        self.l1 = Linear(self.book, "a2c_network._disc_mlp.0", self.k0, self.u1, ACT_RELU)
+        self.l2 = Linear(self.book, "a2c_network._disc_mlp.2", self.u1, self.u2, ACT_RELU)
+        self.l3 = Linear(self.book, "a2c_network._disc_logits", self.u2, 1, ACT_NONE)
+        self.book.finalize()
+        self.flat, self.grad, self.n_flat = self.book.flat, self.book.grad, self.book.n_flat
+        self._ws = {}
+        self.reset_parameters()
+
+    def reset_parameters(self, generator=None):
+        init_linear_(self.book, self.l1, generator)
+        init_linear_(self.book, self.l2, generator)
+        # torch.nn.init.uniform_(_disc_logits.weight, -1, 1); zero bias (amp_network_builder.py:246-247)
+        self.book.set(self.l3.w.name, torch.empty(1, self.u2).uniform_(-1.0, 1.0, generator=generator))
+        self.book.set(self.l3.b.name, torch.zeros(1))
+
+    # ---- reference-named parameters
+    def state_dict(self, buf=None):
+        out = {}
+        for lin in (self.l1, self.l2, self.l3):
+            out[lin.w.name] = self.book.get(lin.w.name, buf).clone()
+            out[lin.b.name] = self.book.get(lin.b.name, buf).reshape(-1).clone()
+        return out
+
+    def gradients(self):
+        return self.state_dict(self.book.grad)
+
+    def load_state_dict(self, sd, strict=True):
+        for lin in (self.l1, self.l2, self.l3):
+            for p in (lin.w, lin.b):
+                if p.name in sd:
+                    self.book.set(p.name, sd[p.name])
+                elif strict:
+                    raise KeyError(p.name)
+
+    def get_disc_logit_weights(self):
+        return self.book.get(self.l3.w.name).reshape(-1)
+
+    # ---- workspaces: b rows per stream (agent / replay / demo), 4b stacked rows
+    def workspace(self, b):
+        ws = self._ws.get(b)
+        if ws is not None:
+            return ws
+        dev = self.device
+        z = lambda r, c: torch.zeros(r, c, dtype=torch.float32, device=dev)
+        m = 4 * b
+        ws = {"b": b, "X": z(m, self.k0p), "H1": z(m, self.u1), "H2": z(m, self.u2), "Z1": z(m, self.u1), "Z2": z(m, self.u2),
+              "L": z(m, 4), "dL": z(m, 4), "G": z(b, self.k0p)}
+        ws["dL"][3 * b:, 0] = 1.0                      # the penalty path's "ones" column for dw3
+        ws["logits"] = ws["L"][:3 * b, :1]
+        ws["dlogits"] = ws["dL"][:3 * b, :1]
+        ws["fwd"] = self._plan_forward(ws, 3 * b)
+        ws["bwd_bce"], ws["pen_fwd"], ws["pen_bwd"], ws["wgrad"] = self._plans_backward(ws)
+        self._ws[b] = ws
+        return ws
+
+    def _plan_forward(self, ws, m, x=None, logits=None):
+        f = self.flat
+        p = K.Plan()
+        x = ws["X"] if x is None else x
+        p.gemm(x, f, ws["H1"], M=m, N=self.u1, K=self.k0, lda=x.stride(0), ldb=self.l1.w.pitch, ldc=self.u1, bias=f, activation=ACT_RELU,
+               b_off=self.l1.w.off, bias_off=self.l1.b.off)
+        p.gemm(ws["H1"], f, ws["H2"], M=m, N=self.u2, K=self.u1, lda=self.u1, ldb=self.l2.w.pitch, ldc=self.u2, bias=f, activation=ACT_RELU,
+               b_off=self.l2.w.off, bias_off=self.l2.b.off)
+        p.gemm(ws["H2"], f, ws["L"], M=m, N=1, K=self.u2, lda=self.u2, ldb=self.l3.w.pitch, ldc=4, bias=f, b_off=self.l3.w.off,
+               bias_off=self.l3.b.off)
+        return p
+
+    def _plans_backward(self, ws):
+        f, b = self.flat, ws["b"]
+        u1, u2, k0, k0p = self.u1, self.u2, self.k0, self.k0p
+        S, P, slabs = self.book.split_k, self.book.n_flat, self.book.slabs
+        w1, w2, w3 = self.l1.w, self.l2.w, self.l3.w
+        r3, demo = 3 * b, 2 * b                                     # first penalty row / first demo row
+        # (1) BCE path: dz2 = (dL w3) * m2 ; dz1 = (dz2 W2) * m1   over the 3b forward rows
+        bce = K.Plan()
+        bce.gemm(ws["dL"], f, ws["Z2"], M=r3, N=u2, K=1, lda=4, ldb=w3.pitch, ldc=u2, b_layout=GEMM_OUT_CONTIG, b_off=w3.off,
+                 epilogue=EPI_RELU_GRAD, aux=ws["H2"], ldaux=u2)
+        bce.gemm(ws["Z2"], f, ws["Z1"], M=r3, N=u1, K=u2, lda=u2, ldb=w2.pitch, ldc=u1, b_layout=GEMM_OUT_CONTIG, b_off=w2.off,
+                 epilogue=EPI_RELU_GRAD, aux=ws["H1"], ldaux=u1)
+        # (2a) penalty forward on the demo rows: u2, u1, g = dD/dx
+        pf = K.Plan()
+        pf.gemm(ws["dL"], f, ws["Z2"], M=b, N=u2, K=1, lda=4, ldb=w3.pitch, ldc=u2, b_layout=GEMM_OUT_CONTIG, a_off=r3 * 4, b_off=w3.off,
+                c_off=r3 * u2, epilogue=EPI_RELU_GRAD, aux=ws["H2"], ldaux=u2, aux_off=demo * u2)
+        pf.gemm(ws["Z2"], f, ws["Z1"], M=b, N=u1, K=u2, lda=u2, ldb=w2.pitch, ldc=u1, b_layout=GEMM_OUT_CONTIG, a_off=r3 * u2, b_off=w2.off,
+                c_off=r3 * u1, epilogue=EPI_RELU_GRAD, aux=ws["H1"], ldaux=u1, aux_off=demo * u1)
+        pf.gemm(ws["Z1"], f, ws["G"], M=b, N=k0, K=u1, lda=u1, ldb=w1.pitch, ldc=k0p, b_layout=GEMM_OUT_CONTIG, a_off=r3 * u1, b_off=w1.off)
+        # (2b) penalty backward: dt1 = (dg W1^T) * m1 -> H1[3b:] ;  m2 * (dt1 W2^T) -> H2[3b:]      (dg lives in X[3b:])
+        pb = K.Plan()
+        pb.gemm(ws["X"], f, ws["H1"], M=b, N=u1, K=k0, lda=k0p, ldb=w1.pitch, ldc=u1, a_off=r3 * k0p, b_off=w1.off, c_off=r3 * u1,
+                epilogue=EPI_RELU_GRAD, aux=ws["H1"], ldaux=u1, aux_off=demo * u1)
+        pb.gemm(ws["H1"], f, ws["H2"], M=b, N=u2, K=u1, lda=u1, ldb=w2.pitch, ldc=u2, a_off=r3 * u1, b_off=w2.off, c_off=r3 * u2,
+                epilogue=EPI_RELU_GRAD, aux=ws["H2"], ldaux=u2, aux_off=demo * u2)
+        # (3) weight gradients over all 4b stacked rows, bias gradients over the 3b BCE rows
+        wg = K.Plan()
+        m = 4 * b
+        wg.gemm(ws["Z1"], ws["X"], slabs, M=u1, N=k0, K=m, lda=u1, ldb=k0p, ldc=w1.pitch, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
+                c_off=w1.off, split_k=S, split_stride=P)
+        wg.gemm(ws["Z2"], ws["H1"], slabs, M=u2, N=u1, K=m, lda=u2, ldb=u1, ldc=w2.pitch, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
+                c_off=w2.off, split_k=S, split_stride=P)
+        wg.gemm(ws["dL"], ws["H2"], slabs, M=1, N=u2, K=m, lda=4, ldb=u2, ldc=w3.pitch, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
+                c_off=w3.off, split_k=S, split_stride=P)
+        sc = torch.zeros(64, max(u1, u2) + 8, dtype=torch.float32, device=self.device)
+        ws["_bias_scratch"] = sc
+        chunks = 64 if r3 >= 1024 else 1
+        for buf, n, ld, off in ((ws["Z1"], u1, u1, self.l1.b.off), (ws["Z2"], u2, u2, self.l2.b.off), (ws["dL"], 1, 4, self.l3.b.off)):
+            wg.call("pulse_colsum_partial", buf.data_ptr(), r3, n, ld, chunks, sc.data_ptr(), sc.stride(0))
+            wg.call("pulse_reduce_slabs", sc.data_ptr(), chunks, sc.stride(0), n, slabs.data_ptr() + 4 * off, 1.0)
+        return bce, pf, pb, wg
+
+    # ---- API ------------------------------------------------------------------------------------------
+    def eval_disc(self, amp_obs_norm, out=None):
+        """Inference on (m, k0p)-pitched normalised AMP observations (rollout reward): returns logits (m, 1)."""
+        m = amp_obs_norm.shape[0]
+        key = ("eval", m, amp_obs_norm.data_ptr())
+        ws = self._ws.get(key)
+        if ws is None:
+            z = lambda r, c: torch.zeros(r, c, dtype=torch.float32, device=self.device)
+            ws = {"X": amp_obs_norm, "H1": z(m, self.u1), "H2": z(m, self.u2), "L": z(m, 4)}
+            ws["plan"] = self._plan_forward(ws, m, x=amp_obs_norm)
+            self._ws[key] = ws
+        ws["plan"].run()
+        return ws["L"][:, :1]
+
+    def forward(self, ws):
+        """Logits of the 3b stacked rows [agent | replay | demo] already normalised into ws['X'][:3b]."""
+        ws["fwd"].run()
+        return ws["logits"]
+
+    def backward(self, ws, grad_penalty_coef, logit_reg, weight_decay, scale=1.0):
+        """ws['dlogits'] holds d(total loss)/d logit for the 3b rows.  Adds the gradient penalty, logit regulariser
+        and weight decay (each times ``scale`` = disc_coef) and leaves the flat gradient in self.grad.
+        Returns the penalty value mean_demo ||dD/dx||^2 (device scalar)."""
+        b = ws["b"]
+        ws["bwd_bce"].run()
+        ws["pen_fwd"].run()
+        g = ws["G"][:, :self.k0]
+        penalty = (g * g).sum(dim=-1).mean()
+        torch.mul(ws["G"], 2.0 * grad_penalty_coef * scale / b, out=ws["X"][3 * b:])      # dg
+        ws["pen_bwd"].run()
+        ws["wgrad"].run()
+        self.book.reduce_grads()
+        gw = self.book.get
+        if logit_reg:
+            gw(self.l3.w.name, self.grad).add_(gw(self.l3.w.name), alpha=2.0 * logit_reg * scale)
+        if weight_decay:
+            for lin in (self.l1, self.l2, self.l3):
+                gw(lin.w.name, self.grad).add_(gw(lin.w.name), alpha=2.0 * weight_decay * scale)
+        return penalty

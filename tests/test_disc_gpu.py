@@ -1,0 +1,67 @@
+"""GPU: AMP discriminator forward, BCE gradients and the hand-derived gradient-penalty double backward vs
+torch autograd (create_graph=True) on the CPU restatement of AMPAgent._disc_loss."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import agent_oracle as AO
+from pulse_amd import configs
+from pulse_amd.learning.disc import DiscNetwork
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_close(a, b, tol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("amp_dim,b", [(1960, 300), (2320, 128)])
+def test_disc_loss_gradients_with_penalty(dev, amp_dim, b):
+    torch.manual_seed(amp_dim + b)
+    ref = AO.OracleDisc(amp_dim)
+    with torch.no_grad():
+        ref._disc_logits.weight.mul_(0.2)
+        ref._disc_logits.bias.fill_(0.05)
+    net_cfg = {"disc": {"units": [1024, 512], "activation": "relu"}}
+    disc = DiscNetwork(net_cfg, amp_dim, device=dev)
+    disc.load_state_dict(ref.state_dict_ref())
+    xa, xr, xd = (torch.randn(b, amp_dim).clamp(-5, 5) for _ in range(3))
+    reg, pen, wd, coef = 0.01, 5.0, 0.0001, 5.0
+    info = AO.oracle_disc_loss(ref, xa, xr, xd, reg, pen, wd)
+    for p in ref.parameters():
+        p.grad = None
+    (coef * info["disc_loss"]).backward()
+    ws = disc.workspace(b)
+    for i, x in enumerate((xa, xr, xd)):
+        ws["X"][i * b:(i + 1) * b, :amp_dim] = x.to(dev)
+    logits = disc.forward(ws)
+    rel_close(logits[:2 * b], info["disc_agent_logit"], 3e-5, "agent/replay logits")
+    rel_close(logits[2 * b:], info["disc_demo_logit"], 3e-5, "demo logits")
+    # d(0.5 (BCE(agent,0) + BCE(demo,1))) / d logit, times disc_coef  (tiny head algebra, left to the caller)
+    lg = logits.detach().clone().requires_grad_(True)
+    bce = torch.nn.BCEWithLogitsLoss()
+    small = 0.5 * (bce(lg[:2 * b], torch.zeros_like(lg[:2 * b])) + bce(lg[2 * b:], torch.ones_like(lg[2 * b:])))
+    (coef * small).backward()
+    ws["dlogits"].copy_(lg.grad)
+    penalty = disc.backward(ws, pen, reg, wd, scale=coef)
+    np.testing.assert_allclose(penalty.item(), info["disc_grad_penalty"].item(), rtol=2e-5)
+    grads = disc.gradients()
+    for name, p in ref.named_parameters():
+        rel_close(grads["a2c_network." + name].reshape(p.shape), p.grad, 3e-4, f"grad {name}")
+    # determinism of the stacked split-K reduction
+    g1 = disc.grad.clone()
+    disc.forward(ws)
+    ws["dlogits"].copy_(lg.grad)
+    disc.backward(ws, pen, reg, wd, scale=coef)
+    assert torch.equal(g1, disc.grad)
+
+
+def test_disc_eval_rollout_batch(dev):
+    ref = AO.OracleDisc(1960)
+    disc = DiscNetwork({"disc": {"units": [1024, 512], "activation": "relu"}}, 1960, device=dev)
+    disc.load_state_dict(ref.state_dict_ref())
+    x = torch.randn(1000, 1960)
+    rel_close(disc.eval_disc(x.to(dev).contiguous()), ref.eval_disc(x), 3e-5, "eval_disc")

@@ -494,3 +494,51 @@ def oracle_disc_loss(disc, amp_obs, amp_obs_replay, amp_obs_demo, disc_logit_reg
     return {"disc_loss": disc_loss, "disc_grad_penalty": disc_grad_penalty_v.detach(), "disc_logit_loss": disc_logit_loss.detach(),
             "disc_agent_acc": agent_acc, "disc_demo_acc": demo_acc, "disc_agent_logit": disc_agent_logit.detach(),
             "disc_demo_logit": disc_demo_logit.detach()}
+
+
+class OracleReplayBuffer:
+    """phc/learning/replay_buffer.py:3-88 restated (single tensor per key, same RNG draws: torch.randperm on the CPU
+    default generator at construction and whenever the sampling cursor wraps)."""
+
+    def __init__(self, buffer_size, device="cpu"):
+        self.size, self.device = buffer_size, device
+        self.head, self.total, self.buf = 0, 0, None
+        self.perm = torch.randperm(buffer_size)
+        self.cursor = 0
+
+    def store(self, data):
+        if self.buf is None:
+            self.buf = {k: torch.zeros((self.size,) + tuple(v.shape[1:]), device=self.device) for k, v in data.items()}
+        n = next(iter(data.values())).shape[0]
+        assert n <= self.size
+        for k, dst in self.buf.items():
+            first = min(n, self.size - self.head)
+            dst[self.head:self.head + first] = data[k][:first]
+            if n > first:
+                dst[0:n - first] = data[k][first:]
+        self.head = (self.head + n) % self.size
+        self.total += n
+
+    def sample(self, n):
+        pos = torch.arange(self.cursor, self.cursor + n) % self.size
+        rows = self.perm[pos]
+        if self.total < self.size:
+            rows = rows % self.head
+        out = {k: v[rows] for k, v in self.buf.items()}
+        self.cursor += n
+        if self.cursor >= self.size:
+            self.perm[:] = torch.randperm(self.size)
+            self.cursor = 0
+        return out
+
+
+def oracle_disc_rewards(disc, amp_rms, amp_obs, disc_reward_scale=2.0):
+    """AMPAgent._calc_disc_rewards, phc/learning/amp_agent.py:1027-1041 (norm_disc_reward False; normaliser in eval mode)."""
+    was = amp_rms.training
+    amp_rms.eval()
+    with torch.no_grad():
+        logits = disc.eval_disc(amp_rms(amp_obs))
+        prob = 1 / (1 + torch.exp(-logits))
+        r = -torch.log(torch.maximum(1 - prob, torch.tensor(0.0001))) * disc_reward_scale
+    amp_rms.train(was)
+    return r

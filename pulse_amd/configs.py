@@ -10,6 +10,7 @@ NETWORK_IM = {            # phc/data/cfg/learning/im.yaml:12-44
     "space": {"continuous": {"mu_activation": "None", "sigma_activation": "None", "mu_init": {"name": "default"},
                              "sigma_init": {"name": "const_initializer", "val": -2.9}, "fixed_sigma": True, "learn_sigma": False}},
     "mlp": {"units": [1024, 512], "activation": "relu", "d2rl": False, "initializer": {"name": "default"}},
+    "disc": {"units": [1024, 512], "activation": "relu", "initializer": {"name": "default"}},
 }
 
 PPO_IM = {                # phc/data/cfg/learning/im.yaml:46-91
@@ -18,6 +19,10 @@ PPO_IM = {                # phc/data/cfg/learning/im.yaml:46-91
     "learning_rate": 2e-5, "lr_schedule": "constant", "entropy_coef": 0.0, "truncate_grads": True, "grad_norm": 50.0,
     "e_clip": 0.2, "horizon_length": 32, "minibatch_size": 16384, "mini_epochs": 6, "critic_coef": 5, "clip_value": False,
     "bounds_loss_coef": 10,
+    # AMP (learning/im.yaml:78-91)
+    "amp_obs_demo_buffer_size": 200000, "amp_replay_buffer_size": 200000, "amp_replay_keep_prob": 0.01, "amp_batch_size": 512,
+    "amp_minibatch_size": 4096, "disc_coef": 5, "disc_logit_reg": 0.01, "disc_grad_penalty": 5, "disc_reward_scale": 2,
+    "disc_weight_decay": 0.0001, "normalize_amp_input": True, "task_reward_w": 0.5, "disc_reward_w": 0.5,
 }
 
 ENV_IM = {"obs_v": 6, "self_obs_v": 1, "power_reward": True, "local_root_obs": True, "root_height_obs": True,
@@ -46,6 +51,12 @@ CONFIGS = {
              "extra": {"use_seq_rl": True}},
     # same network trained with the PPO loss (SURVEY.md 8d cfg 3, first variant)
     "cfg3_ppo": {"num_envs": 8192, "horizon_length": 32, "minibatch_size": 16384, "network": "amp_z", "env": "vae_ppo", "agent": "amp"},
+    # BASELINE.json configs[4]: AMP discriminator + PPO, 8192 envs (fp32 here: the reference's "mixed precision" is fp16 autocast)
+    "cfg5": {"num_envs": 8192, "horizon_length": 32, "minibatch_size": 16384, "units": [1024, 512], "env": "amp", "agent": "amp",
+             "extra": {"enable_disc": True}},
+    "cfg5_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "units": [512, 512], "env": "amp", "agent": "amp",
+                   "extra": {"enable_disc": True, "amp_minibatch_size": 64, "amp_obs_demo_buffer_size": 4096, "amp_replay_buffer_size": 4096,
+                             "amp_batch_size": 128}},
     # small shapes of the same graphs for tests
     "cfg3_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_z", "env": "vae", "agent": "amp",
                    "extra": {"use_seq_rl": True}},
@@ -79,6 +90,8 @@ def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kin
     env_cfg = dict(ENV_IM_VAE) if env_kind in ("vae", "vae_ppo") else dict(ENV_IM)
     if env_kind == "vae_ppo":
         env_cfg.update({"only_kin_loss": False, "save_kin_info": False, "distill": False})
+    if env_kind == "amp":
+        env_cfg.update({"enable_amp_obs": True, "numAMPObsSteps": 10})
     task = HumanoidIm({"env": env_cfg}, sim, motion, device=device)
     task.progress_buf.copy_(rollout.init_progress)
     return VecTaskPythonWrapper(task, rl_device=device), rollout

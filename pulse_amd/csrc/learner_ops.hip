@@ -31,7 +31,7 @@ __device__ __forceinline__ float wave_sumf(float v) {
 // ------------------------------------------------------------------------------------------------
 // RunningMeanStd: wide matrices (cols >= 64): threads own columns, blocks own row chunks.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRmsMaxColsPerThread = 8;  // 256 threads x 8 = 2048 columns (AMP obs is 1960)
+constexpr int kRmsMaxColsPerThread = 12;  // 256 threads x 12 = 3072 columns (AMP obs is 10 x 232 = 2320)
 
 __global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __
 
 // 16-byte variant of the wide kernel: each thread owns groups of 4 adjacent columns (a wave reads 1 KiB
 // of a row per instruction).  Needs 16-byte aligned rows on both sides and y_cols % 4 == 0.
-constexpr int kRmsVecGroups = 2;   // 256 threads x 4 columns x 2 groups = 2048 columns
+constexpr int kRmsVecGroups = 3;   // 256 threads x 4 columns x 3 groups = 3072 columns
 
 __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,

@@ -114,6 +114,19 @@ class HumanoidIm:
         self._task_obs_size_detail = {k: env[k] for k in ("embedding_size", "embedding_norm", "z_type", "use_vae_prior",
                                                           "use_vae_clamped_prior", "vae_var_clamp_max") if k in env}
         self._task_obs_size_detail.setdefault("proj_norm", True)
+        # ---- AMP observations (humanoid_amp.py:91-118, 296-314): (N, numAMPObsSteps, W) history, slot 0 = current frame
+        self._enable_amp_obs = bool(env.get("enable_amp_obs", False))
+        if self._enable_amp_obs:
+            self._num_amp_obs_steps = int(env.get("numAMPObsSteps", 10))
+            self._amp_root_height_obs = bool(env.get("ampRootHeightObs", env.get("root_height_obs", True)))
+            self._key_body_ids = torch.tensor([syn.SMPL_BODY_NAMES.index(b) for b in env.get("key_bodies", ["R_Ankle", "L_Ankle", "R_Wrist", "L_Wrist"])],
+                                              dtype=torch.int32, device=dev)
+            self._amp_zero_joints = (3, 7, 17, 22)          # dofs 9:12, 21:24, 51:54, 66:69 read as zero (humanoid_amp.py:636-639)
+            self._num_amp_obs_per_step = ops.amp_obs_width(syn.NUM_DOF // 3, self._key_body_ids.numel(), self._amp_root_height_obs)
+            self._amp_obs_buf = torch.zeros(n, self._num_amp_obs_steps, self._num_amp_obs_per_step, device=dev)
+            self._curr_amp_obs_buf = self._amp_obs_buf[:, 0]
+            self._hist_amp_obs_buf = self._amp_obs_buf[:, 1:]
+            self._amp_obs_space = Box(-float("inf"), float("inf"), (self.get_num_amp_obs(),))
         if self.save_kin_info:        # HumanoidImDistill.kin_dict (humanoid_im_distill.py:73-80, 204-205)
             self.kin_dict = {"gt_action": torch.zeros(n, self.num_actions, device=dev),
                              "progress_buf": torch.zeros(n, dtype=torch.int64, device=dev)}
@@ -136,6 +149,34 @@ class HumanoidIm:
 
     def get_running_mean_size(self):
         return (self.get_obs_size(),)
+
+    def get_num_amp_obs(self):
+        return self._num_amp_obs_steps * self._num_amp_obs_per_step
+
+    def _update_hist_amp_obs(self):
+        """humanoid_amp.py:622-631: shift the history by one slot."""
+        self._hist_amp_obs_buf.copy_(self._amp_obs_buf[:, 0:self._num_amp_obs_steps - 1].clone())
+
+    def _compute_amp_observations(self, env_mask=None):
+        """humanoid_amp.py:632-667 -> current frame into slot 0 of the history."""
+        ops.build_amp_observations_smpl(self.sim.rigid_body_state, self.sim.dof_pos, self.sim.dof_vel, self._key_body_ids,
+                                        zero_joints=self._amp_zero_joints, local_root_obs=self._local_root_obs,
+                                        root_height_obs=self._amp_root_height_obs, out=self._curr_amp_obs_buf, env_mask=env_mask)
+
+    def _init_amp_obs(self, mask):
+        """_init_amp_obs + _init_amp_obs_default (humanoid_amp.py:519-530): reset envs restart with a history of
+        copies of their first frame."""
+        self._compute_amp_observations(env_mask=mask)
+        cur = self._curr_amp_obs_buf.unsqueeze(1).expand(-1, self._num_amp_obs_steps - 1, -1)
+        self._hist_amp_obs_buf.copy_(torch.where(mask[:, None, None], cur, self._hist_amp_obs_buf))
+
+    def fetch_amp_obs_demo(self, num_samples):
+        """humanoid_amp.py:215-284: AMP observation windows of reference motion (synthetic poses here)."""
+        s = self._num_amp_obs_steps
+        rb, dp, dv = self._motion_lib.sample_demo_states(num_samples * s)
+        out = ops.build_amp_observations_smpl(rb, dp, dv, self._key_body_ids, zero_joints=self._amp_zero_joints,
+                                              local_root_obs=self._local_root_obs, root_height_obs=self._amp_root_height_obs)
+        return out.view(num_samples, s * self._num_amp_obs_per_step)
 
     def get_task_obs_size_detail(self):
         return self._task_obs_size_detail
@@ -202,6 +243,10 @@ class HumanoidIm:
         self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
         self.extras["terminate"] = self._terminate_buf
         self.extras["reward_raw"] = self.reward_raw
+        if self._enable_amp_obs:                      # HumanoidAMP.post_physics_step (humanoid_amp.py:194-210)
+            self._update_hist_amp_obs()
+            self._compute_amp_observations()
+            self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())
 
     # ------------------------------------------------------------------ reset
     def reset(self, env_ids=None):
@@ -229,6 +274,8 @@ class HumanoidIm:
         self.reset_buf.mul_(keep)
         self._terminate_buf.mul_(keep)
         self._compute_observations(env_mask=mask, ref_next=self._motion_lib.next_after_reset())
+        if self._enable_amp_obs:
+            self._init_amp_obs(mask)
 
 
 class VecTaskPythonWrapper:
@@ -266,4 +313,10 @@ class VecTaskPythonWrapper:
         return 1
 
     def get_env_info(self):
-        return {"action_space": self.act_space, "observation_space": self.obs_space, "task_obs_size": self.task.get_task_obs_size()}
+        info = {"action_space": self.act_space, "observation_space": self.obs_space, "task_obs_size": self.task.get_task_obs_size()}
+        if getattr(self.task, "_enable_amp_obs", False):
+            info["amp_observation_space"] = self.task._amp_obs_space
+        return info
+
+    def fetch_amp_obs_demo(self, num_samples):
+        return self.task.fetch_amp_obs_demo(num_samples)

@@ -21,7 +21,7 @@ class RecordedRollout:
         g = syn.make_generator(seed, rank)
         self.num_envs, self.num_frames = num_envs, num_frames
         n = num_envs
-        keys = ("rb", "reset_rb", "dof_force", "dof_vel", "gt_action")
+        keys = ("rb", "reset_rb", "dof_force", "dof_vel", "gt_action", "dof_pos")
         self.data = {k: [] for k in keys}
         self.ref_now = {k: [] for k in ("pos", "rot", "vel", "ang")}
         self.ref_next = {k: [] for k in ("pos", "rot", "vel", "ang")}
@@ -37,6 +37,7 @@ class RecordedRollout:
             # stand-in for the frozen PHC teacher's action on this frame (humanoid_im_distill.py:143-231; needs released
             # checkpoints, so the distillation target is synthetic)
             self.data["gt_action"].append((0.4 * torch.randn(n, syn.NUM_DOF, generator=g)).clamp(-1, 1))
+            self.data["dof_pos"].append(0.5 * torch.randn(n, syn.NUM_DOF, generator=g))       # exp-map joint angles
             rrb = syn.rigid_body_state(g, n)
             self.data["reset_rb"].append(rrb)
             rr = syn.reference_frame(g, rrb)
@@ -78,6 +79,7 @@ class RecordedSim:
         self.rigid_body_state = rollout.data["rb"][0].clone()               # the persistent "gym tensor"
         self.dof_force = rollout.data["dof_force"][0].clone()
         self.dof_vel = rollout.data["dof_vel"][0].clone()
+        self.dof_pos = rollout.data["dof_pos"][0].clone()
         self.pd_targets = torch.zeros(n, syn.NUM_DOF, device=dev)
 
     @property
@@ -93,6 +95,7 @@ class RecordedSim:
         self.rigid_body_state.copy_(r["rb"][f])
         self.dof_force.copy_(r["dof_force"][f])
         self.dof_vel.copy_(r["dof_vel"][f])
+        self.dof_pos.copy_(r["dof_pos"][f])
 
     def set_dof_position_target_tensor(self, pd_tar):
         # the recorded "physics" ignores the targets; they are kept so the write happens as in
@@ -117,6 +120,21 @@ class RecordedMotion:
     def __init__(self, rollout, sim):
         self.rollout, self.sim = rollout, sim
         self._motion_lengths = rollout.motion_lengths
+        self._demo_gen = torch.Generator(device=rollout.data["rb"].device)
+        self._demo_gen.manual_seed(4321)
+
+    def sample_demo_states(self, count):
+        """Synthetic stand-in for the motion-library states behind fetch_amp_obs_demo (humanoid_amp.py:215-284):
+        ``count`` random reference poses -> (rb records (count, 24, 13), dof_pos, dof_vel), drawn on the device."""
+        dev, g = self.rollout.data["rb"].device, self._demo_gen
+        rb = torch.randn(count, syn.NUM_BODIES, syn.RB_WIDTH, device=dev, generator=g)
+        rb[..., 0:3] *= 0.3
+        rb[:, :, 2] += 0.9
+        q = rb[..., 3:7]
+        rb[..., 3:7] = q / q.norm(dim=-1, keepdim=True)
+        dof_pos = 0.4 * torch.randn(count, syn.NUM_DOF, device=dev, generator=g)
+        dof_vel = 0.8 * torch.randn(count, syn.NUM_DOF, device=dev, generator=g)
+        return rb, dof_pos, dof_vel
 
     def now(self):
         f = self.sim.frame

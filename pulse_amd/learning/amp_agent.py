@@ -9,14 +9,66 @@ Built this round:
     sequences (``use_seq_rl``, :40-42) and ``calc_gradients`` runs ``_optimize_kin`` (:771-849): action RMSE +
     beta KL(q || learned prior) + AR(1) latent smoothness (+ optional regulariser), its own Adam
     (``kin_optimizer``, lr ``kin_lr``), clip 50, KL-weight annealing over epochs 2500-5000.
-NOT built yet (raise if enabled): the adversarial discriminator path (_disc_loss / AMP observations / replay
-buffers, rows a12 / a24).
+  * the adversarial-motion-prior path (rows a12 / a24, ``enable_disc``): AMP observation windows recorded per step
+    (:377), discriminator reward -log(max(1 - sigmoid(D), 1e-4)) * scale combined 0.5 / 0.5 with the task reward
+    (:1011-1041), demo / replay ring buffers with permuted sampling (replay_buffer.py:27-69, amp_agent.py:975-1057),
+    and ``_disc_loss`` (:895-952) -- BCE on agent+replay vs demo logits, logit regulariser, weight decay and the
+    gradient penalty, whose double backward is hand-derived in learning/disc.py -- added to the PPO loss with
+    ``disc_coef``; ONE gradient-norm clip over policy + discriminator parameters, Adam on both flat buffers.
 """
+import numpy as np
 import torch
 
 from .. import kernels as K
 from . import rlg
 from .common_agent import CommonAgent
+from .disc import DiscNetwork
+from .graph import r4
+from .running_mean_std import RunningMeanStd
+
+
+class ReplayBuffer:
+    """phc/learning/replay_buffer.py:27-69 on the device: a ring of rows with a permuted sampling order.
+    ``sample_indices`` returns row indices instead of copies: consumers gather in their own kernels."""
+
+    def __init__(self, buffer_size, width, device, generator=None):
+        self._head, self._total_count, self._buffer_size = 0, 0, int(buffer_size)
+        self._device = torch.device(device)
+        self._gen = generator
+        self.data = torch.zeros(self._buffer_size, width, dtype=torch.float32, device=self._device)
+        self._sample_idx = torch.randperm(self._buffer_size, generator=generator).to(self._device)
+        self._sample_head = 0
+
+    def get_buffer_size(self):
+        return self._buffer_size
+
+    def get_total_count(self):
+        return self._total_count
+
+    def store(self, rows):
+        n, size = rows.shape[0], self._buffer_size
+        assert n <= size
+        store_n = min(n, size - self._head)
+        self.data[self._head:self._head + store_n, :rows.shape[1]] = rows[:store_n]
+        if n - store_n > 0:
+            self.data[0:n - store_n, :rows.shape[1]] = rows[store_n:]
+        self._head = (self._head + n) % size
+        self._total_count += n
+
+    def sample_indices(self, n):
+        size = self._buffer_size
+        idx = torch.arange(self._sample_head, self._sample_head + n, device=self._device) % size
+        rand_idx = self._sample_idx[idx]
+        if self._total_count < size:
+            rand_idx = rand_idx % self._head
+        self._sample_head += n
+        if self._sample_head >= size:
+            self._sample_idx = torch.randperm(size, generator=self._gen).to(self._device)
+            self._sample_head = 0
+        return rand_idx
+
+    def sample(self, n):
+        return self.data[self.sample_indices(n)]
 
 
 def kl_multi(qm, qv, pm, pv):
@@ -36,8 +88,9 @@ class AMPAgent(CommonAgent):
         self.only_kin_loss = bool(env_cfg.get("only_kin_loss", False))
         self.temp_running_mean = bool(getattr(task, "temp_running_mean", True))
         self.kin_lr = float(getattr(task, "kin_lr", 5e-4))
-        if config.get("enable_disc", False):
-            raise NotImplementedError("AMP discriminator training (rows a12 / a24) is not built yet")
+        self.enable_disc = bool(config.get("enable_disc", False))
+        if self.enable_disc:
+            self._load_amp_config(config)
         if self.save_kin_info:
             n = self.model.parameters_count()
             self.kin_exp_avg = torch.zeros(n, device=self.ppo_device)     # kin_optimizer = Adam(a2c_network.parameters(), kin_lr)
@@ -46,6 +99,146 @@ class AMPAgent(CommonAgent):
             self.kin_dict_info = None
         self.running_mean_std_temp = self.running_mean_std.clone_frozen()
         self.z_noise_provider = None                                      # tests inject the re-parameterisation noise
+
+    # ------------------------------------------------------------------ AMP discriminator (amp_agent.py:851-1057)
+    def _load_amp_config(self, config):
+        self._task_reward_w, self._disc_reward_w = float(config["task_reward_w"]), float(config["disc_reward_w"])
+        self._amp_observation_space = self.env_info["amp_observation_space"]
+        self._amp_dim = int(self._amp_observation_space.shape[0])
+        self._amp_pitch = r4(self._amp_dim)
+        self._amp_batch_size, self._amp_minibatch_size = int(config["amp_batch_size"]), int(config["amp_minibatch_size"])
+        assert self._amp_minibatch_size <= self.minibatch_size
+        self._disc_coef, self._disc_logit_reg = float(config["disc_coef"]), float(config["disc_logit_reg"])
+        self._disc_grad_penalty, self._disc_weight_decay = float(config["disc_grad_penalty"]), float(config["disc_weight_decay"])
+        self._disc_reward_scale = float(config["disc_reward_scale"])
+        self._normalize_amp_input = bool(config.get("normalize_amp_input", True))
+        if not self._normalize_amp_input or config.get("norm_disc_reward", False):
+            raise NotImplementedError("normalize_amp_input: True / norm_disc_reward: False (the shipped settings)")
+        self.disc = DiscNetwork(config["network"], self._amp_dim, device=self.ppo_device, split_k=int(config.get("split_k", 8)))
+        self._amp_input_mean_std = RunningMeanStd((self._amp_dim,), device=self.ppo_device)
+        self.disc_exp_avg = torch.zeros(self.disc.n_flat, device=self.ppo_device)
+        self.disc_exp_avg_sq = torch.zeros(self.disc.n_flat, device=self.ppo_device)
+        self._amp_replay_keep_prob = float(config["amp_replay_keep_prob"])
+        self._bce = torch.nn.BCEWithLogitsLoss()
+
+    def _build_amp_buffers(self):
+        gen = torch.Generator()
+        gen.manual_seed(int(self.config.get("seed", 0)) + 77 + self.rank)
+        self.experience_buffer.add("amp_obs", width=self._amp_dim, pitch=self._amp_pitch)
+        self._amp_obs_demo_buffer = ReplayBuffer(int(self.config["amp_obs_demo_buffer_size"]), self._amp_pitch, self.ppo_device, gen)
+        self._amp_replay_buffer = ReplayBuffer(int(self.config["amp_replay_buffer_size"]), self._amp_pitch, self.ppo_device, gen)
+        self.tensor_list += ["amp_obs"]
+        self._disc_r = torch.zeros(self.num_actors, self.horizon_length, 1, device=self.ppo_device)
+        self._amp_norm_scratch = None
+
+    def _fetch_amp_obs_demo(self, num_samples):
+        return self.vec_env.env.fetch_amp_obs_demo(num_samples)
+
+    def _init_amp_demo_buf(self):
+        size = self._amp_obs_demo_buffer.get_buffer_size()
+        for _ in range(int(np.ceil(size / self._amp_batch_size))):
+            self._amp_obs_demo_buffer.store(self._fetch_amp_obs_demo(self._amp_batch_size))
+
+    def _update_amp_demos(self):
+        self._amp_obs_demo_buffer.store(self._fetch_amp_obs_demo(self._amp_batch_size))
+
+    def _init_train(self):
+        super()._init_train()
+        if self.enable_disc and self._amp_obs_demo_buffer.get_total_count() == 0:
+            self._init_amp_demo_buf()
+
+    def _stat_modules(self):
+        return super()._stat_modules() + ([self._amp_input_mean_std] if self.enable_disc else [])
+
+    def set_eval(self):
+        super().set_eval()
+        if self.enable_disc:
+            self._amp_input_mean_std.eval()
+
+    def set_train(self):
+        super().set_train()
+        if self.enable_disc:
+            self._amp_input_mean_std.train()
+
+    def _calc_disc_rewards(self, amp_rows):
+        """:1027-1041 on (B, amp_pitch) rows: disc_r = -log(max(1 - sigmoid(D(norm(x))), 1e-4)) * disc_reward_scale."""
+        b = amp_rows.shape[0]
+        chunk = min(b, 16384)
+        if self._amp_norm_scratch is None or self._amp_norm_scratch.shape[0] != chunk:
+            self._amp_norm_scratch = torch.zeros(chunk, self._amp_pitch, device=self.ppo_device)
+        out = torch.empty(b, 1, device=self.ppo_device)
+        for c0 in range(0, b, chunk):
+            n = min(chunk, b - c0)
+            xs = self._amp_norm_scratch[:n]
+            self._amp_input_mean_std.forward(amp_rows[c0:c0 + n], out=xs, out_cols=self._amp_pitch, update=False)
+            logits = self.disc.eval_disc(self._amp_norm_scratch)[:n]
+            prob = 1 / (1 + torch.exp(-logits))
+            out[c0:c0 + n] = -torch.log(torch.maximum(1 - prob, torch.tensor(0.0001, device=self.ppo_device))) * self._disc_reward_scale
+        return out
+
+    def _rollout_rewards(self, td):
+        if not self.enable_disc:
+            return td["rewards"]
+        eb = self.experience_buffer
+        disc_r = self._calc_disc_rewards(eb.flat("amp_obs"))                     # env-major rows, same order as rewards' storage
+        self._disc_r = disc_r.view(self.num_actors, self.horizon_length, 1)
+        combined = self._task_reward_w * eb.phys["rewards"] + self._disc_reward_w * self._disc_r      # _combine_rewards (:1011-1016)
+        self._mb_rewards = combined
+        return combined.transpose(0, 1)                                          # (T, N, 1) view like td["rewards"]
+
+    def _store_replay_amp_obs(self, amp_obs):
+        """:1043-1057."""
+        buf = self._amp_replay_buffer
+        if buf.get_total_count() > buf.get_buffer_size():
+            keep = torch.bernoulli(torch.full((amp_obs.shape[0],), self._amp_replay_keep_prob, device=self.ppo_device)) == 1.0
+            amp_obs = amp_obs[keep]
+        if amp_obs.shape[0] > buf.get_buffer_size():
+            amp_obs = amp_obs[torch.randperm(amp_obs.shape[0], device=self.ppo_device)[:buf.get_buffer_size()]]
+        buf.store(amp_obs)
+
+    def _param_groups(self):
+        groups = super()._param_groups()
+        if self.enable_disc:
+            groups.append((self.disc.flat, self.disc.grad, self.disc_exp_avg, self.disc_exp_avg_sq, self.disc.n_flat))
+        return groups
+
+    def _extra_gradients(self, input_dict, idx):
+        """The discriminator part of AMPAgent.calc_gradients (:621-629, 700-712): the first amp_minibatch_size rows of
+        the minibatch for agent / replay / demo observations, normalised in that order (each call also updates the
+        running statistics), then _disc_loss and its gradients."""
+        if not self.enable_disc:
+            return {}
+        b = self._amp_minibatch_size
+        d = input_dict["dataset"]
+        sub = idx[:b]
+        ws = self.disc.workspace(b)
+        eb_rows = d["_amp_store"]
+        X = ws["X"]
+        rms = self._amp_input_mean_std
+        rms.forward(eb_rows, row_idx=sub, out=X[0:b], out_cols=self._amp_pitch)                                   # amp_obs
+        rep_src, rep_idx = d["_amp_replay_src"], d["_amp_replay_idx"]
+        rms.forward(rep_src, row_idx=rep_idx[sub] if rep_idx is not None else sub, out=X[b:2 * b], out_cols=self._amp_pitch)   # amp_obs_replay
+        rms.forward(self._amp_obs_demo_buffer.data, row_idx=d["_amp_demo_idx"][sub], out=X[2 * b:3 * b], out_cols=self._amp_pitch)  # amp_obs_demo
+        logits = self.disc.forward(ws)
+        with torch.enable_grad():
+            lg = logits.detach().clone().requires_grad_(True)
+            agent_logit, demo_logit = lg[:2 * b], lg[2 * b:]
+            disc_loss_agent = self._bce(agent_logit, torch.zeros_like(agent_logit))
+            disc_loss_demo = self._bce(demo_logit, torch.ones_like(demo_logit))
+            pred = 0.5 * (disc_loss_agent + disc_loss_demo)
+            (self._disc_coef * pred / self.world_size).backward()
+        ws["dlogits"].copy_(lg.grad)
+        penalty = self.disc.backward(ws, self._disc_grad_penalty, self._disc_logit_reg, self._disc_weight_decay,
+                                     scale=self._disc_coef / self.world_size)
+        w3 = self.disc.get_disc_logit_weights()
+        logit_loss = torch.sum(torch.square(w3))
+        disc_loss = pred.detach() + self._disc_logit_reg * logit_loss + self._disc_grad_penalty * penalty
+        if self._disc_weight_decay != 0:
+            wsum = sum(torch.sum(torch.square(self.disc.book.get(l.w.name))) for l in (self.disc.l1, self.disc.l2, self.disc.l3))
+            disc_loss = disc_loss + self._disc_weight_decay * wsum
+        return {"disc_loss": disc_loss, "disc_grad_penalty": penalty.detach(), "disc_logit_loss": logit_loss.detach(),
+                "disc_agent_acc": torch.mean((agent_logit.detach() < 0).float()), "disc_demo_acc": torch.mean((demo_logit.detach() > 0).float()),
+                "disc_agent_logit": agent_logit.detach().mean(), "disc_demo_logit": demo_logit.detach().mean()}
 
     # ------------------------------------------------------------------ epoch hooks (amp_agent.py:557-583)
     def pre_epoch(self, epoch_num):
@@ -67,10 +260,18 @@ class AMPAgent(CommonAgent):
             self.kin_dict_size = sum(v.reshape(v.shape[0], -1).shape[-1] for v in kd.values())
             self.experience_buffer.add("kin_dict", width=self.kin_dict_size)
             self.tensor_list += ["kin_dict"]
+        if self.enable_disc:
+            self._build_amp_buffers()
+            if self._amp_obs_demo_buffer.get_total_count() == 0:
+                self._init_amp_demo_buf()
 
     def train_epoch(self):
         self.pre_epoch(self.epoch_num)
         info = super().train_epoch()
+        if self.enable_disc:
+            self._store_replay_amp_obs(self.experience_buffer.flat("amp_obs"))       # :534
+            info["disc_rewards"] = self._disc_r
+            info["mb_rewards"] = self._mb_rewards
         self.post_epoch(self.epoch_num)
         return info
 
@@ -79,6 +280,8 @@ class AMPAgent(CommonAgent):
         return res_dict["mus"] if (self.only_kin_loss and self.save_kin_info) else res_dict["actions"]
 
     def _after_env_step(self, n, infos):
+        if self.enable_disc:
+            self.experience_buffer.update_data("amp_obs", n, infos["amp_obs"])          # :377
         if self.save_kin_info:
             flat = torch.cat([v.reshape(v.shape[0], -1).float() for v in infos["kin_dict"].values()], dim=-1)
             self.experience_buffer.update_data("kin_dict", n, flat)
@@ -87,6 +290,18 @@ class AMPAgent(CommonAgent):
         d = super().prepare_dataset(batch_dict)
         if self.save_kin_info:
             d["kin_dict"] = batch_dict["kin_dict"]
+        if self.enable_disc:
+            # amp_agent.py:474-484: a fresh demo batch enters the demo ring, then T*N demo / replay rows are drawn.  Only the
+            # first amp_minibatch_size rows of every minibatch are ever used (:621-628), so the draws are kept as ROW INDICES
+            # into the rings and gathered inside the normaliser kernel instead of materialising two (T*N, 2320) copies.
+            self._update_amp_demos()
+            n = self.batch_size
+            d["_amp_store"] = self.experience_buffer.flat("amp_obs")
+            d["_amp_demo_idx"] = self._amp_obs_demo_buffer.sample_indices(n)
+            if self._amp_replay_buffer.get_total_count() == 0:
+                d["_amp_replay_src"], d["_amp_replay_idx"] = d["_amp_store"], None      # batch_dict['amp_obs_replay'] = batch_dict['amp_obs']
+            else:
+                d["_amp_replay_src"], d["_amp_replay_idx"] = self._amp_replay_buffer.data, self._amp_replay_buffer.sample_indices(n)
         self.dataset.update_values_dict(d, rnn_format=True, horizon_length=self.horizon_length, num_envs=self.num_actors)
         return d
 
@@ -163,9 +378,9 @@ class AMPAgent(CommonAgent):
         if self.multi_gpu:
             self.dist.sync_gradients(model.grad)
         self.kin_step += 1
-        K.sqnorm_partial(model.grad, model.n_flat, self._sq_partials)
+        K.sqnorm_partial(model.grad, model.n_flat, self._sq_partials[:256])
         K.adam_step(model.flat, model.grad, self.kin_exp_avg, self.kin_exp_avg_sq, model.n_flat, lr=self.kin_lr, step=self.kin_step,
-                    max_norm=self.grad_norm, sqnorm_partials=self._sq_partials, grad_norm_out=self._grad_norm)
+                    max_norm=self.grad_norm, sqnorm_partials=self._sq_partials[:256], grad_norm_out=self._grad_norm)
         info["kin_loss"] = kin_loss.detach()
         info["grad_norm"] = self._grad_norm.clone()
         return info

@@ -299,7 +299,8 @@ class CommonAgent:
         self._pending_done_mask = done_mask
 
         td = eb.tensor_dict
-        mb_advs, mb_returns = ops.discount_values(td["dones"], td["values"], td["rewards"], td["next_values"], self.gamma, self.tau,
+        mb_rewards = self._rollout_rewards(td)
+        mb_advs, mb_returns = ops.discount_values(td["dones"], td["values"], mb_rewards, td["next_values"], self.gamma, self.tau,
                                                   return_returns=True)
         batch_dict = eb.get_transformed_list(rlg.swap_and_flatten01, self.tensor_list)
         batch_dict["returns"] = rlg.swap_and_flatten01(mb_returns)
@@ -309,6 +310,9 @@ class CommonAgent:
 
     def _action_for_env(self, res_dict):
         return res_dict["actions"]
+
+    def _rollout_rewards(self, td):
+        return td["rewards"]
 
     def _after_env_step(self, n, infos):
         return
@@ -389,13 +393,8 @@ class CommonAgent:
                    dmu=ws["dmu"], dmu_stride=ws["dmu"].stride(0), dvalue=ws["dval"], dvalue_stride=ws["dval"].stride(0),
                    partials=self._loss_partials)
         net.backward(ws, mb, grad_scale=1.0 / self.world_size)
-        if self.multi_gpu:
-            self.dist.sync_gradients(net.grad)                          # optimizer.synchronize()
-        self.optimizer_step += 1
-        K.sqnorm_partial(net.grad, net.n_flat, self._sq_partials)
-        K.adam_step(net.flat, net.grad, self.exp_avg, self.exp_avg_sq, net.n_flat, lr=self.last_lr, step=self.optimizer_step,
-                    weight_decay=self.weight_decay, max_norm=self.grad_norm if self.truncate_grads else 0.0,
-                    sqnorm_partials=self._sq_partials, grad_norm_out=self._grad_norm)
+        extra_info = self._extra_gradients(input_dict, idx)               # AMPAgent: discriminator loss / gradients
+        self._apply_gradients()
         info = self._loss_partials.sum(0) / mb                          # [a_loss, c_loss, b_loss, clip_frac, kl]
         if self._entropy is None:
             ent = float((0.5 + 0.5 * math.log(2 * math.pi)) * self.actions_num) + float(net.sigma.sum().item())
@@ -403,6 +402,32 @@ class CommonAgent:
         self.train_result = {"entropy": self._entropy, "kl": info[4], "last_lr": self.last_lr, "lr_mul": 1.0, "b_loss": info[2],
                              "actor_loss": info[0], "actor_clip_frac": info[3], "critic_loss": info[1],
                              "grad_norm": self._grad_norm.clone()}
+        self.train_result.update(extra_info)
+
+    def _extra_gradients(self, input_dict, idx):
+        return {}
+
+    def _param_groups(self):
+        """(params, grads, exp_avg, exp_avg_sq, count) of every flat buffer the optimiser owns."""
+        net = self.model
+        return [(net.flat, net.grad, self.exp_avg, self.exp_avg_sq, net.n_flat)]
+
+    def _apply_gradients(self):
+        """[all-reduce] -> clip_grad_norm_ over ALL parameters -> Adam, one fused launch per flat buffer."""
+        groups = self._param_groups()
+        if self.multi_gpu:
+            for g in groups:
+                self.dist.sync_gradients(g[1])                               # optimizer.synchronize()
+        self.optimizer_step += 1
+        nb = 256
+        if self._sq_partials.numel() != nb * len(groups):
+            self._sq_partials = torch.zeros(nb * len(groups), device=self.ppo_device)
+        for i, g in enumerate(groups):
+            K.sqnorm_partial(g[1], g[4], self._sq_partials[i * nb:(i + 1) * nb])
+        for g in groups:
+            K.adam_step(g[0], g[1], g[2], g[3], g[4], lr=self.last_lr, step=self.optimizer_step, weight_decay=self.weight_decay,
+                        max_norm=self.grad_norm if self.truncate_grads else 0.0, sqnorm_partials=self._sq_partials,
+                        grad_norm_out=self._grad_norm)
 
     # ------------------------------------------------------------------ epoch (common_agent.py:191-260)
     def train_epoch(self):
@@ -458,6 +483,8 @@ class CommonAgent:
         self.obs = self.env_reset()
         if self.multi_gpu:
             self.dist.setup_algo(self.model.flat, (self.model.sigma, self.exp_avg, self.exp_avg_sq))
+            for g in self._param_groups()[1:]:
+                self.dist.setup_algo(g[0], (g[2], g[3]))
         self._init_train()
         total_time = 0.0
         max_epochs = self.max_epochs if max_epochs is None else max_epochs
@@ -465,7 +492,7 @@ class CommonAgent:
             epoch_num = self.update_epoch()
             train_info = self.train_epoch()
             if self.multi_gpu:
-                self.curr_frames = self.dist.sync_stats([self.running_mean_std, self.value_mean_std], self.curr_frames)
+                self.curr_frames = self.dist.sync_stats(self._stat_modules(), self.curr_frames)
             total_time += train_info["total_time"]
             self.frame += self.curr_frames
             if self.rank == 0:
@@ -479,6 +506,9 @@ class CommonAgent:
 
     def _init_train(self):
         return
+
+    def _stat_modules(self):
+        return [self.running_mean_std, self.value_mean_std]
 
     # ------------------------------------------------------------------ checkpoint surface
     def get_full_state_weights(self):

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--reference", default="motion_lib", choices=["motion_lib", "recorded"],
+                    help="reference-motion source: HBM-resident motion library queried every step, or pre-recorded frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-minibatches", type=int, default=4, help="PPO minibatch steps timed on the CPU oracle")
     ap.add_argument("--cpu-steps", type=int, default=8, help="rollout steps timed on the CPU oracle")
@@ -50,7 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches):
+def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches, reference="motion_lib"):
     """Runs in a SUBPROCESS (hard wall-clock bound): the oracle agent on the host cores for a bounded
     sample -- ``sample_steps`` of the T rollout steps and ``n_minibatches`` PPO minibatch steps at the
     full N and the full minibatch size -- extrapolated linearly to the whole epoch."""
@@ -65,9 +67,13 @@ def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches):
     scfg = dict(cfg)
     scfg["horizon_length"] = sample_steps
     assert sample_steps * num_envs % cfg["minibatch_size"] == 0
-    rollout = RecordedRollout(num_envs, sample_steps + 1, seed=seed)
     torch.manual_seed(seed)
-    env = AO.OracleEnv(rollout, syn.RESET_BODY_IDS, list(range(24)))
+    if reference == "motion_lib":
+        from oracle import motion_oracle as MO
+        env = MO.make_agent_env(num_envs, sample_steps, seed)
+    else:
+        rollout = RecordedRollout(num_envs, sample_steps + 1, seed=seed)
+        env = AO.OracleEnv(rollout, syn.RESET_BODY_IDS, list(range(24)))
     agent = AO.OracleCommonAgent(scfg, env, cfg["network"]["mlp"]["units"], seed=seed)
     agent.obs = env.reset()
     t0 = time.time()
@@ -77,17 +83,17 @@ def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches):
     per_mb = r["update_time"] / max(1, r["minibatches"])
     epoch_s = per_step * T + per_mb * total_mb
     return {"value": T * num_envs / epoch_s, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cfg_name} at full width ({num_envs} envs, minibatch {cfg['minibatch_size']}): {sample_steps} of {T} rollout steps "
+            "sample": f"{cfg_name} ({reference} reference) at full width ({num_envs} envs, minibatch {cfg['minibatch_size']}): {sample_steps} of {T} rollout steps "
                       f"({r['play_time']:.1f} s) + {r['minibatches']} of {total_mb} PPO minibatch steps ({r['update_time']:.1f} s), each extrapolated "
                       f"linearly to the epoch; {wall:.1f} s of CPU work; oracle/agent_oracle.py, torch {torch.__version__} eager fp32, "
                       f"{cores} intra-op threads of {os.cpu_count()} logical CPUs",
             "rollout_s_per_step": per_step, "update_s_per_minibatch": per_mb, "epoch_s_extrapolated": epoch_s}
 
 
-def cpu_baseline(cfg_name, seed, sample_steps, n_minibatches, budget_s):
+def cpu_baseline(cfg_name, seed, sample_steps, n_minibatches, budget_s, reference="motion_lib"):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", cfg_name, "--cpu-steps", str(sample_steps),
-           "--cpu-minibatches", str(n_minibatches)]
+           "--cpu-minibatches", str(n_minibatches), "--reference", reference]
     env = dict(os.environ)
     env["HIP_VISIBLE_DEVICES"] = ""                           # the worker never touches the GPU
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -105,7 +111,7 @@ def cpu_baseline(cfg_name, seed, sample_steps, n_minibatches, budget_s):
 def main():
     a = parse()
     if a.cpu_baseline_worker:
-        print(json.dumps(cpu_baseline_worker(a.config, 1234, a.cpu_steps, a.cpu_minibatches)), flush=True)
+        print(json.dumps(cpu_baseline_worker(a.config, 1234, a.cpu_steps, a.cpu_minibatches, a.reference)), flush=True)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,9 +131,11 @@ def main():
     seed = 1234
     cfg, num_envs = configs.agent_config(a.config)
     T = cfg["horizon_length"]
-    rollout_cpu = RecordedRollout(num_envs, T + 1, seed=seed, rank=rank)     # synthetic rollout inputs, seed 1234 + rank
-    log(f"rank {rank}: synthetic rollout generated")
-    agent, _ = configs.make_agent(a.config, device=device, seed=seed, rank=rank, rollout=rollout_cpu, multi_gpu=world > 1, dist=dist)
+    # synthetic inputs, seed 1234 + rank: a motion library resident in HBM (+ tracking physics stand-in) or recorded frames
+    rollout_cpu = RecordedRollout(num_envs, T + 1, seed=seed, rank=rank) if a.reference == "recorded" else None
+    agent, _ = configs.make_agent(a.config, device=device, seed=seed, rank=rank, rollout=rollout_cpu, reference=a.reference,
+                                  multi_gpu=world > 1, dist=dist)
+    log(f"rank {rank}: synthetic inputs generated ({a.reference})")
     agent.init_tensors()
     agent.obs = agent.env_reset()
     agent._tensors_ready = True
@@ -163,7 +171,9 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{a.config}: {num_envs} SMPL-humanoid envs/GPU x horizon {T}, imitation obs/reward/reset + PPO "
                                f"(actor+critic MLP {cfg['network']['mlp']['units']}, minibatch {cfg['minibatch_size']} x {cfg['mini_epochs']} mini-epochs)",
-                   "num_envs_per_gpu": num_envs, "horizon": T, "global_batch": T * num_envs * world, "parallelism": f"dp{world}"},
+                   "num_envs_per_gpu": num_envs, "horizon": T, "global_batch": T * num_envs * world, "parallelism": f"dp{world}",
+                   "reference_motion": "HBM-resident motion library (1024 clips), queried every step" if a.reference == "motion_lib"
+                   else "pre-recorded reference frames"},
         "play_ms_per_step": 1e3 * play / a.steps, "update_ms_per_step": 1e3 * upd / a.steps,
     }
     if not a.no_roofline:
@@ -178,7 +188,7 @@ def main():
                            "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in s.items()}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle (subprocess, bounded)")
-        out["cpu_baseline"] = cpu_baseline(a.config, seed, a.cpu_steps, a.cpu_minibatches, a.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(a.config, seed, a.cpu_steps, a.cpu_minibatches, a.cpu_budget, a.reference)
         if out["cpu_baseline"]["value"]:
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 4
+#define PULSE_ABI_VERSION 5
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -170,6 +170,59 @@ typedef struct pulse_amp_obs_args {
 int pulse_sizeof_amp_obs_args(void);
 int pulse_amp_obs_width(int num_joints, int num_key_bodies, int root_height_obs);
 int pulse_amp_obs(const pulse_amp_obs_args* args, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
+ * 2b. Reference-motion query: MotionLibBase.get_motion_state / get_root_pos_smpl /
+ *     _calc_frame_blend (phc/utils/motion_lib_base.py:434-565).
+ *
+ *     Device data format.  The reference keeps six flat per-frame tables (gts, grs, lrs,
+ *     gvs, gavs, dvs; :297-304) and gathers two rows from each.  Here ONE packed table
+ *     holds a fixed-size record per frame with the six fields at the float offsets off_*
+ *     (pulse_amd packs [grs J*4 | lrs J*4 | gts J*3 | gvs J*3 | gavs J*3 | dvs (J-1)*3 | pad]),
+ *     so a query touches two contiguous records (SMPL: 477 floats, pitch 480 = 1920 B)
+ *     instead of twelve scattered rows.  Frame f of motion m is record length_starts[m]+f.
+ * ------------------------------------------------------------------------- */
+typedef struct pulse_motion_tables {
+    const float* frames;              /* (total_frames, frame_stride) packed records */
+    int64_t frame_stride;             /* floats per record, multiple of 4 */
+    int64_t total_frames;
+    int32_t num_bodies;               /* J <= 32 */
+    int32_t off_gts, off_grs, off_lrs, off_gvs, off_gavs, off_dvs;   /* float offsets of the fields inside a record */
+    const float* motion_lengths;      /* (num_motions) seconds  (_motion_lengths) */
+    const float* motion_dt;           /* (num_motions)          (_motion_dt) */
+    const int64_t* motion_num_frames; /* (num_motions)          (_motion_num_frames) */
+    const int64_t* length_starts;     /* (num_motions) first record of each motion (:311-314) */
+    int32_t num_motions;
+} pulse_motion_tables;
+
+typedef struct pulse_motion_state_args {
+    pulse_motion_tables tab;
+    int64_t n;                        /* queries */
+    const int64_t* motion_ids;        /* (n) */
+    /* query time: motion_times (n) if non-NULL; otherwise the episode clock is evaluated in-kernel
+       (humanoid_im.py:723-731, 859): query i belongs to env e = i / time_steps, sample k = i % time_steps,
+           t = (progress[e] + step_shift) * dt + k * traj_dt + start_times[e] + start_offsets[e],
+       and motion_ids / offset are then indexed by e as well (n = num_envs * time_steps). */
+    const float* motion_times;
+    const int64_t* progress; int32_t step_shift; float dt;
+    const float* start_times; const float* start_offsets;
+    int32_t time_steps; float traj_dt;   /* _num_traj_samples (>= 1) and _traj_sample_timestep; clock mode only */
+    const float* offset;              /* optional (n,3) added to every body position (_global_offset) */
+    int32_t root_only;                /* get_root_pos_smpl: only root_pos is produced */
+    /* outputs, contiguous; any pointer may be NULL to skip that field */
+    float* rg_pos;                    /* (n, J, 3) */
+    float* rb_rot;                    /* (n, J, 4) */
+    float* body_vel;                  /* (n, J, 3) */
+    float* body_ang_vel;              /* (n, J, 3) */
+    float* dof_pos;                   /* (n, (J-1)*3) exp-map of the slerped local rotations (:562-565) */
+    float* dof_vel;                   /* (n, (J-1)*3) */
+    float* root_pos;                  /* (n, 3)  (root_only mode) */
+    float* rb_records;                /* optional (n, J, 13) [pos | rot | vel | ang vel] records, the simulator's rigid-body */
+    int64_t rb_query_stride;          /*   layout (humanoid.py:219-222): reference-state init writes them as-is; floats per query */
+    int64_t* frame_idx0; int64_t* frame_idx1; float* blend;   /* optional (n): _calc_frame_blend results, idx RELATIVE to the motion */
+} pulse_motion_state_args;
+int pulse_sizeof_motion_state_args(void);
+int pulse_motion_state(const pulse_motion_state_args* args, pulse_stream_t s);
 
 /* ------------------------------------------------------------------------- *
  * 3. GAE: CommonAgent.discount_values + returns, phc/learning/common_agent.py:493-505,

@@ -247,6 +247,41 @@ def gen_rms():
     np.savez_compressed(os.path.join(GOLDEN_DIR, "rms.npz"), **_np(out))
 
 
+def gen_motion_lib(num_motions=9, n=203):
+    """MotionLibBase.get_motion_state / get_root_pos_smpl / _calc_frame_blend / get_motion_num_steps run from the reference's own
+    source on a synthetic library (tables stored alongside so the test needs nothing else)."""
+    cls = refload.motion_lib_class()
+    g = syn.make_generator(777)
+    tabs = syn.synthetic_motion_library(g, num_motions, min_frames=8, max_frames=40)
+    ref = cls()
+    for k in ("gts", "grs", "lrs", "gvs", "gavs", "dvs", "length_starts"):
+        setattr(ref, k, tabs[k])
+    ref._motion_lengths, ref._motion_fps, ref._motion_dt = tabs["motion_lengths"], tabs["motion_fps"], tabs["motion_dt"]
+    ref._motion_num_frames, ref.num_bodies, ref._device = tabs["motion_num_frames"], syn.NUM_BODIES, "cpu"
+    ref._motion_aa = torch.zeros(tabs["gts"].shape[0], 72)
+    ref._motion_bodies = torch.zeros(num_motions, 17)
+    ref._motion_limb_weights = torch.zeros(num_motions, 10)
+    ids = torch.randint(0, num_motions, (n,), generator=g)
+    length = tabs["motion_lengths"][ids]
+    times = torch.rand(n, generator=g) * length * 1.15 - 0.05 * length          # some before 0 and past the end
+    dt = tabs["motion_dt"][ids]
+    k = torch.randint(0, 8, (n,), generator=g).float()
+    exact = torch.rand(n, generator=g) < 0.3                                     # exact frame times (blend 0 / float edge)
+    times = torch.where(exact, torch.minimum(k * dt, length), times)
+    times[0], times[1], times[2] = 0.0, length[1], -0.3
+    offset = torch.randn(n, 3, generator=g) * torch.tensor([2.0, 2.0, 0.0])
+    res = ref.get_motion_state(ids, times, offset)
+    res_no = ref.get_motion_state(ids, times)
+    f0, f1, blend = ref._calc_frame_blend(times, length, tabs["motion_num_frames"][ids], dt)
+    out = {"tab_" + k: v for k, v in tabs.items()}
+    out.update({"motion_ids": ids, "motion_times": times, "offset": offset, "frame_idx0": f0, "frame_idx1": f1, "blend": blend,
+                "root_pos_smpl": ref.get_root_pos_smpl(ids, times)["root_pos"], "num_steps": ref.get_motion_num_steps(),
+                "rg_pos_no_offset": res_no["rg_pos"]})
+    for key in ("root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos", "rb_rot", "body_vel", "body_ang_vel"):
+        out[key] = res[key]
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "motion_lib.npz"), **_np(out))
+
+
 def main():
     assert refload.available(), "reference tree not found; goldens can only be generated in the build container"
     os.makedirs(GOLDEN_DIR, exist_ok=True)
@@ -257,6 +292,7 @@ def main():
     gen_env_amp()
     gen_agent_math()
     gen_rms()
+    gen_motion_lib()
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)), "bytes")
 

@@ -124,6 +124,27 @@ def agent_methods():
     return _cache["agent"]
 
 
+MOTION_LIB_METHODS = ["get_motion_state", "get_root_pos_smpl", "_calc_frame_blend", "_get_num_bodies", "_local_rotation_to_dof_smpl",
+                      "get_motion_num_steps", "get_motion_length", "sample_time", "sample_time_interval"]
+
+
+def motion_lib_class():
+    """A class carrying MotionLibBase's query methods (phc/utils/motion_lib_base.py:396-564), extracted by name and
+    exec'd against the namespace the module would have had (``flags.real_traj`` False, as in every training config).
+    The module itself cannot be imported (smpl_sim, joblib-loaded AMASS pickles, multiprocessing loaders)."""
+    if "motion_lib" in _cache:
+        return _cache["motion_lib"]
+    ns = _namespace()
+    ns["flags"] = types.SimpleNamespace(real_traj=False)
+    path = os.path.join(REFERENCE_ROOT, "phc", "utils", "motion_lib_base.py")
+    srcs = _extract(path, MOTION_LIB_METHODS, methods_of="MotionLibBase")
+    for name, text in srcs.items():
+        exec(compile(text, f"<reference:MotionLibBase.{name}>", "exec"), ns)
+    cls = type("ReferenceMotionLibQueries", (), {k: ns[k] for k in srcs})
+    _cache["motion_lib"] = cls
+    return cls
+
+
 def importable_modules():
     """Reference modules that import cleanly here (no shim needed)."""
     _ensure_paths()

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -53,6 +53,24 @@ class AmpObsArgs(Structure):
                 ("joint_ids", c_void_p), ("num_joints", c_int32), ("zero_joint_mask", c_uint32),
                 ("key_body_ids", c_void_p), ("num_key_bodies", c_int32), ("local_root_obs", c_int32), ("root_height_obs", c_int32),
                 ("out", c_void_p), ("out_stride", c_int64)]
+
+
+class MotionTables(Structure):
+    _fields_ = [("frames", c_void_p), ("frame_stride", c_int64), ("total_frames", c_int64), ("num_bodies", c_int32),
+                ("off_gts", c_int32), ("off_grs", c_int32), ("off_lrs", c_int32), ("off_gvs", c_int32), ("off_gavs", c_int32),
+                ("off_dvs", c_int32),
+                ("motion_lengths", c_void_p), ("motion_dt", c_void_p), ("motion_num_frames", c_void_p), ("length_starts", c_void_p),
+                ("num_motions", c_int32)]
+
+
+class MotionStateArgs(Structure):
+    _fields_ = [("tab", MotionTables), ("n", c_int64), ("motion_ids", c_void_p), ("motion_times", c_void_p),
+                ("progress", c_void_p), ("step_shift", c_int32), ("dt", c_float), ("start_times", c_void_p), ("start_offsets", c_void_p),
+                ("time_steps", c_int32), ("traj_dt", c_float), ("offset", c_void_p), ("root_only", c_int32),
+                ("rg_pos", c_void_p), ("rb_rot", c_void_p), ("body_vel", c_void_p), ("body_ang_vel", c_void_p),
+                ("dof_pos", c_void_p), ("dof_vel", c_void_p), ("root_pos", c_void_p),
+                ("rb_records", c_void_p), ("rb_query_stride", c_int64),
+                ("frame_idx0", c_void_p), ("frame_idx1", c_void_p), ("blend", c_void_p)]
 
 
 class GemmDesc(Structure):
@@ -107,6 +125,8 @@ SIGNATURES = {
     "pulse_sizeof_amp_obs_args": (c_int, []),
     "pulse_amp_obs_width": (c_int, [c_int, c_int, c_int]),
     "pulse_amp_obs": (c_int, [POINTER(AmpObsArgs), P]),
+    "pulse_sizeof_motion_state_args": (c_int, []),
+    "pulse_motion_state": (c_int, [POINTER(MotionStateArgs), P]),
     "pulse_gae": (c_int, [P, P, P, P, c_int32, c_int32, c_int64, c_int64, c_float, c_float, P, P, P]),
     "pulse_sizeof_gemm_desc": (c_int, []),
     "pulse_gemm_f32": (c_int, [POINTER(GemmDesc), P]),

@@ -79,29 +79,42 @@ def agent_config(name, **overrides):
     return cfg, c["num_envs"]
 
 
-def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kind="im"):
+def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kind="im", reference="recorded", env_overrides=None):
+    """``reference``: 'recorded' = pre-recorded rigid-body / reference frames (RecordedRollout, what the CPU oracle agent replays);
+    'motion_lib' = reference motion queried from the HBM-resident MotionLib every step, physics stand-in tracking it."""
     from .env.humanoid_im import HumanoidIm, VecTaskPythonWrapper
+    env_cfg = dict(ENV_IM_VAE) if env_kind in ("vae", "vae_ppo") else dict(ENV_IM)
+    if env_kind == "vae_ppo":
+        env_cfg.update({"only_kin_loss": False, "save_kin_info": False, "distill": False})
+    if env_kind == "amp":
+        env_cfg.update({"enable_amp_obs": True, "numAMPObsSteps": 10})
+    env_cfg.update(env_overrides or {})
+    if reference == "motion_lib":
+        from . import synthetic as syn
+        from .env.motion_lib import MotionLib
+        from .env.sim import KinematicSim
+        tables = syn.synthetic_motion_library(syn.make_generator(seed + 5, rank), min(num_envs, 1024))
+        motion = MotionLib.from_tables(tables, device)
+        sim = KinematicSim(num_envs, horizon + 1, device, seed=seed, rank=rank)
+        task = HumanoidIm({"env": env_cfg}, sim, motion, device=device)
+        return VecTaskPythonWrapper(task, rl_device=device), None
     from .env.sim import RecordedMotion, RecordedRollout, RecordedSim
     if rollout is None:
         rollout = RecordedRollout(num_envs, horizon + 1, seed=seed, rank=rank)
     rollout.to(device)
     sim = RecordedSim(rollout)
     motion = RecordedMotion(rollout, sim)
-    env_cfg = dict(ENV_IM_VAE) if env_kind in ("vae", "vae_ppo") else dict(ENV_IM)
-    if env_kind == "vae_ppo":
-        env_cfg.update({"only_kin_loss": False, "save_kin_info": False, "distill": False})
-    if env_kind == "amp":
-        env_cfg.update({"enable_amp_obs": True, "numAMPObsSteps": 10})
     task = HumanoidIm({"env": env_cfg}, sim, motion, device=device)
     task.progress_buf.copy_(rollout.init_progress)
     return VecTaskPythonWrapper(task, rl_device=device), rollout
 
 
-def make_agent(name="cfg2", device="cuda:0", seed=1234, rank=0, rollout=None, **overrides):
+def make_agent(name="cfg2", device="cuda:0", seed=1234, rank=0, rollout=None, reference="recorded", env_overrides=None, **overrides):
     from .learning.amp_agent import AMPAgent
     from .learning.common_agent import CommonAgent
     cfg, num_envs = agent_config(name, **overrides)
-    vec_env, rollout = make_env(num_envs, cfg["horizon_length"], device, seed=seed, rank=rank, rollout=rollout, env_kind=cfg["_env_kind"])
+    vec_env, rollout = make_env(num_envs, cfg["horizon_length"], device, seed=seed, rank=rank, rollout=rollout, env_kind=cfg["_env_kind"],
+                                reference=reference, env_overrides=env_overrides)
     cfg.update({"vec_env": vec_env, "device": device, "seed": seed})
     cls = AMPAgent if cfg["_agent_kind"] == "amp" else CommonAgent
     return cls("pulse_amd", cfg), rollout

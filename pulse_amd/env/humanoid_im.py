@@ -53,8 +53,10 @@ class HumanoidIm:
             raise NotImplementedError("self_obs_v 1 with obs_v 6 | 7 are built (SURVEY.md 8a); others are listed as next")
         self._fut_tracks = bool(env.get("fut_tracks", False))
         self._num_traj_samples = int(env.get("numTrajSamples", 3)) if self._fut_tracks else 1
-        if self._fut_tracks:
-            raise NotImplementedError("fut_tracks needs a motion library with future sampling (next row f-1)")
+        self._traj_sample_timestep = 1.0 / float(env.get("trajSampleTimestepInv", 30))   # humanoid_im.py:80-82
+        self._use_motion_lib = hasattr(motion_lib, "query")           # HBM-resident MotionLib vs recorded reference frames
+        if self._fut_tracks and not self._use_motion_lib:
+            raise NotImplementedError("fut_tracks samples future reference frames: needs the MotionLib reference source")
         self._local_root_obs = bool(env.get("local_root_obs", True))
         self._root_height_obs = bool(env.get("root_height_obs", True))
         self._full_body_reward = bool(env.get("full_body_reward", True))        # humanoid_im.py:37
@@ -94,6 +96,9 @@ class HumanoidIm:
         self._motion_start_times = torch.zeros(n, device=dev)
         self._motion_start_times_offset = torch.zeros(n, device=dev)
         self._pass_time = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._motion_len_env = motion_lib._motion_lengths
+        if self._use_motion_lib:
+            self._init_motion_clock(env)
         self.extras = {}
         self.actions = None
         # attributes the agent reaches for (amp_agent.py:59-63; common_agent.py:54); defaults of humanoid.py:105,296-345
@@ -134,6 +139,46 @@ class HumanoidIm:
         self.has_task = True
         self.viewer = None
 
+    # ------------------------------------------------------------------ reference motion from the HBM-resident library
+    def _init_motion_clock(self, env):
+        """humanoid_im.py:130-140, 424-455: every env follows motion ``_sampled_motion_ids[e]`` from ``_motion_start_times[e]``,
+        translated by ``_global_offset[e]`` (its env origin)."""
+        n, dev, lib = self.num_envs, self.device, self._motion_lib
+        self._sampled_motion_ids = torch.arange(n, dtype=torch.int64, device=dev) % lib.num_motions()
+        self._motion_len_env = lib.get_motion_length(self._sampled_motion_ids).contiguous()
+        e = torch.arange(n, device=dev)
+        side = int(n ** 0.5) + 1
+        spacing = float(env.get("envSpacing", 5.0))
+        self._global_offset = torch.stack([(e % side) * spacing, (e // side) * spacing, torch.zeros(n, device=dev)], dim=-1).float().contiguous()
+        self._clock_gen = torch.Generator(device=dev)
+        self._clock_gen.manual_seed(int(env.get("motion_clock_seed", 2024)))
+        self._state_init_random = env.get("stateInit", "Random") != "Start"              # HumanoidAMP.StateInit
+        self._ref_bufs = {"now": {}, "next": {}, "reset": {}, "track": {}, "demo": {}}
+
+    def _ref_query(self, which, shift, with_records=False, time_steps=1):
+        res = self._motion_lib.query(self._sampled_motion_ids, offset=self._global_offset, progress=self.progress_buf, step_shift=shift,
+                                     dt=self.dt, start_times=self._motion_start_times, start_offsets=self._motion_start_times_offset,
+                                     time_steps=time_steps, traj_dt=self._traj_sample_timestep, out=self._ref_bufs[which],
+                                     with_records=with_records)
+        res["pos"], res["rot"], res["vel"], res["ang"] = res["rg_pos"], res["rb_rot"], res["body_vel"], res["body_ang_vel"]
+        return res
+
+    def _ref_now(self):
+        """Reference at the current motion time (reward / reset; humanoid_im.py:859-861)."""
+        return self._ref_query("now", 0) if self._use_motion_lib else self._motion_lib.now()
+
+    def _ref_next(self):
+        """Reference at the next control step(s) (task observation, humanoid_im.py:723-735); its single-step form is also what
+        the kinematic physics stand-in tracks."""
+        if not self._use_motion_lib:
+            return self._motion_lib.next()
+        if self._num_traj_samples > 1:
+            self.sim.track(self._ref_query("track", 1, with_records=True))    # the t+1 state the simulator tracks
+            return self._ref_query("next", 1, time_steps=self._num_traj_samples)
+        res = self._ref_query("next", 1, with_records=True)
+        self.sim.track(res)
+        return res
+
     # ------------------------------------------------------------------ sizes / spaces
     def get_obs_size(self):
         return self.num_obs
@@ -173,9 +218,21 @@ class HumanoidIm:
     def fetch_amp_obs_demo(self, num_samples):
         """humanoid_amp.py:215-284: AMP observation windows of reference motion (synthetic poses here)."""
         s = self._num_amp_obs_steps
-        rb, dp, dv = self._motion_lib.sample_demo_states(num_samples * s)
-        out = ops.build_amp_observations_smpl(rb, dp, dv, self._key_body_ids, zero_joints=self._amp_zero_joints,
-                                              local_root_obs=self._local_root_obs, root_height_obs=self._amp_root_height_obs)
+        if self._use_motion_lib:
+            lib = self._motion_lib
+            ids = lib.sample_motions(num_samples, generator=self._clock_gen)
+            t0 = lib.sample_time(ids, generator=self._clock_gen)                       # _sample_time, humanoid_amp.py:223-224
+            steps = -self.dt * torch.arange(0, s, device=self.device)                  # build_amp_obs_demo, :256-262
+            times = (t0.unsqueeze(-1) + steps).view(-1)
+            bufs = self._ref_bufs["demo"] if self._ref_bufs["demo"].get("dof_pos", torch.empty(0)).shape[0] == num_samples * s else {}
+            res = lib.query(ids.repeat_interleave(s), times, out=bufs, with_records=True)
+            self._ref_bufs["demo"] = res
+            rb, dp, dv = res["rb_records"], res["dof_pos"], res["dof_vel"]
+        else:
+            rb, dp, dv = self._motion_lib.sample_demo_states(num_samples * s)
+        # the toe / hand zeroing of :636-639 touches the SIMULATED dofs only; demo windows use the library dofs as they are
+        out = ops.build_amp_observations_smpl(rb, dp, dv, self._key_body_ids, zero_joints=(), local_root_obs=self._local_root_obs,
+                                              root_height_obs=self._amp_root_height_obs)
         return out.view(num_samples, s * self._num_amp_obs_per_step)
 
     def get_task_obs_size_detail(self):
@@ -209,14 +266,14 @@ class HumanoidIm:
             torch.ge(self.progress_buf, self.max_episode_length - 1, out=self._pass_time)
         else:
             t = self.progress_buf * self.dt + self._motion_start_times + self._motion_start_times_offset
-            torch.ge(t, self._motion_lib._motion_lengths, out=self._pass_time)
+            torch.ge(t, self._motion_len_env, out=self._pass_time)
 
     def _im_step(self, what, env_ids=None, env_mask=None, ref_next=None):
         need_now = what & (PULSE_IM_REWARD | PULSE_IM_RESET)
         return ops.im_step(
             self.sim.rigid_body_state, what=what,
-            ref_now=self._motion_lib.now() if need_now else None,
-            ref_next=(ref_next if ref_next is not None else self._motion_lib.next()) if what & PULSE_IM_TASK_OBS else None,
+            ref_now=self._ref_now() if need_now else None,
+            ref_next=(ref_next if ref_next is not None else self._ref_next()) if what & PULSE_IM_TASK_OBS else None,
             time_steps=self._num_traj_samples, dof_force=self.sim.dof_force, dof_vel=self.sim.dof_vel,
             progress=self.progress_buf, pass_time=self._pass_time, cycle_counter=self._cycle_counter,
             track_ids=self._track_bodies_id, reset_ids=self._reset_bodies_id, term_dist=self._termination_distances,
@@ -268,12 +325,24 @@ class HumanoidIm:
     def reset_masked(self, mask):
         """Sync-free form of reset(env_ids): mask is a (N,) bool device tensor.
         _reset_envs (humanoid.py:541-560): state init, buffer clears, observation recompute."""
-        self.sim.set_env_states_masked(mask)
         keep = ~mask
-        self.progress_buf.mul_(keep)
+        if self._use_motion_lib:
+            # _reset_envs -> _sample_ref_state (humanoid_im.py:966-986): new start time, state := reference state at that time
+            if self._state_init_random:
+                new_t = self._motion_lib.sample_time(self._sampled_motion_ids, generator=self._clock_gen)
+            else:
+                new_t = torch.zeros_like(self._motion_start_times)
+            torch.where(mask, new_t, self._motion_start_times, out=self._motion_start_times)
+            self.progress_buf.mul_(keep)
+            self.sim.set_env_states_masked(mask, self._ref_query("reset", 0, with_records=True))
+            ref_next = self._ref_next()
+        else:
+            self.sim.set_env_states_masked(mask)
+            self.progress_buf.mul_(keep)
+            ref_next = self._motion_lib.next_after_reset()
         self.reset_buf.mul_(keep)
         self._terminate_buf.mul_(keep)
-        self._compute_observations(env_mask=mask, ref_next=self._motion_lib.next_after_reset())
+        self._compute_observations(env_mask=mask, ref_next=ref_next)
         if self._enable_amp_obs:
             self._init_amp_obs(mask)
 

@@ -1,0 +1,206 @@
+"""Reference-motion library resident in HBM (mirrors the query surface of phc/utils/motion_lib_base.py).
+
+What the reference does per env step (humanoid_im.py:708-735, 853-861, 950-964): twice, gather two frames from six flat
+tables (gts, grs, lrs, gvs, gavs, dvs; motion_lib_base.py:297-304) for every env, lerp / slerp them, turn the local
+rotations into exp-map dof positions and add the per-env offset -- ~60 small launches and twelve scattered gathers.
+
+Here the tables are packed ONCE at load time into one record per frame (include/pulse_hip.h section 2b:
+[gts | grs | lrs | gvs | gavs | dvs | pad], 480 floats = 1920 B for SMPL) and ``get_motion_state`` is one launch of
+``pulse_motion_state`` that reads two contiguous records per query.  Clip loading from AMASS pickles / SkeletonMotion
+construction (motion_lib_base.py:172-285, motion_lib_smpl.py) is CPU-side data preparation and stays out of scope;
+``MotionLib`` takes the finished tables (``from_tables``) -- synthetic clips here (pulse_amd/synthetic.py).
+
+Same names and return keys as MotionLibBase: ``get_motion_state``, ``get_root_pos_smpl``, ``get_motion_length``,
+``get_motion_num_steps``, ``sample_motions``, ``sample_time``, ``sample_time_interval``, ``num_motions``,
+``get_total_length``; attributes ``_motion_lengths``, ``_motion_fps``, ``_motion_dt``, ``_motion_num_frames``,
+``length_starts``, ``_sampling_prob``.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .._lib import MotionStateArgs
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _round4(n):
+    return (n + 3) // 4 * 4
+
+
+class MotionLib:
+    FIELDS = ("gts", "grs", "lrs", "gvs", "gavs", "dvs")
+
+    def __init__(self, tables, device="cuda:0"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError("MotionLib lives in HBM (pulse_amd has no CPU path)")
+        self._device = dev
+        gts = tables["gts"]
+        total, j = gts.shape[0], gts.shape[1]
+        self.num_bodies = j
+        self.num_dof = (j - 1) * 3
+        widths = {"gts": j * 3, "grs": j * 4, "lrs": j * 4, "gvs": j * 3, "gavs": j * 3, "dvs": (j - 1) * 3}
+        # quaternion fields on 16-B boundaries: order [grs | lrs | gts | gvs | gavs | dvs] keeps them aligned for any J
+        order = ("grs", "lrs", "gts", "gvs", "gavs", "dvs")
+        self.offsets, off = {}, 0
+        for k in order:
+            self.offsets[k] = off
+            off += widths[k]
+        self.frame_stride = _round4(off)
+        frames = torch.zeros(total, self.frame_stride, dtype=torch.float32, device=dev)
+        for k in order:
+            t = tables[k]
+            if t.shape[0] != total or t.dtype != torch.float32:
+                raise ValueError(f"table {k}: expected ({total}, ...) float32")
+            frames[:, self.offsets[k]:self.offsets[k] + widths[k]] = t.reshape(total, -1).to(dev)
+        self.frames = frames
+        self._motion_lengths = tables["motion_lengths"].to(dev, torch.float32).contiguous()
+        self._motion_fps = tables["motion_fps"].to(dev, torch.float32).contiguous()
+        self._motion_dt = tables["motion_dt"].to(dev, torch.float32).contiguous()
+        self._motion_num_frames = tables["motion_num_frames"].to(dev, torch.int64).contiguous()
+        lengths_shifted = self._motion_num_frames.roll(1)                      # motion_lib_base.py:311-314
+        lengths_shifted[0] = 0
+        self.length_starts = lengths_shifted.cumsum(0).contiguous()
+        self._num_motions = self._motion_lengths.shape[0]
+        self.motion_ids = torch.arange(self._num_motions, dtype=torch.long, device=dev)
+        self._sampling_prob = torch.ones(self._num_motions, device=dev) / self._num_motions      # :205, uniform until re-weighted
+        self._sampling_batch_prob = self._sampling_prob
+        self._lengths_host = None
+
+    @classmethod
+    def from_tables(cls, tables, device="cuda:0"):
+        return cls(tables, device)
+
+    # ---- table views (reference attribute names), strided views into the packed records
+    def _field(self, k, inner):
+        j = self.num_bodies if k != "dvs" else self.num_bodies - 1
+        return self.frames[:, self.offsets[k]:self.offsets[k] + j * inner].view(self.frames.shape[0], j, inner)
+
+    gts = property(lambda self: self._field("gts", 3))
+    grs = property(lambda self: self._field("grs", 4))
+    lrs = property(lambda self: self._field("lrs", 4))
+    gvs = property(lambda self: self._field("gvs", 3))
+    gavs = property(lambda self: self._field("gavs", 3))
+    dvs = property(lambda self: self._field("dvs", 3))
+
+    # ---- bookkeeping queries (motion_lib_base.py:325-432)
+    def num_motions(self):
+        return self._num_motions
+
+    def get_total_length(self):
+        if self._lengths_host is None:
+            self._lengths_host = float(self._motion_lengths.sum().item())
+        return self._lengths_host
+
+    def get_motion_length(self, motion_ids=None):
+        return self._motion_lengths if motion_ids is None else self._motion_lengths[motion_ids]
+
+    def get_motion_num_steps(self, motion_ids=None):
+        if motion_ids is None:
+            return (self._motion_num_frames * 30 / self._motion_fps).int()
+        return (self._motion_num_frames[motion_ids] * 30 / self._motion_fps).int()
+
+    def sample_motions(self, n, generator=None):
+        return torch.multinomial(self._sampling_batch_prob, num_samples=n, replacement=True, generator=generator).to(self._device)
+
+    def sample_time(self, motion_ids, truncate_time=None, generator=None):
+        phase = torch.rand(motion_ids.shape, device=self._device, generator=generator)
+        motion_len = self._motion_lengths[motion_ids]
+        if truncate_time is not None:
+            assert truncate_time >= 0.0
+            motion_len = motion_len - truncate_time
+        return phase * motion_len
+
+    def sample_time_interval(self, motion_ids, truncate_time=None, generator=None):
+        phase = torch.rand(motion_ids.shape, device=self._device, generator=generator)
+        motion_len = self._motion_lengths[motion_ids]
+        if truncate_time is not None:
+            assert truncate_time >= 0.0
+            motion_len = motion_len - truncate_time
+        curr_fps = 1 / 30
+        return ((phase * motion_len) / curr_fps).long() * curr_fps
+
+    # ---- the hot query
+    def _tables(self, a):
+        t = a.tab
+        t.frames, t.frame_stride, t.total_frames, t.num_bodies = self.frames.data_ptr(), self.frame_stride, self.frames.shape[0], self.num_bodies
+        o = self.offsets
+        t.off_gts, t.off_grs, t.off_lrs, t.off_gvs, t.off_gavs, t.off_dvs = o["gts"], o["grs"], o["lrs"], o["gvs"], o["gavs"], o["dvs"]
+        t.motion_lengths, t.motion_dt = self._motion_lengths.data_ptr(), self._motion_dt.data_ptr()
+        t.motion_num_frames, t.length_starts, t.num_motions = self._motion_num_frames.data_ptr(), self.length_starts.data_ptr(), self._num_motions
+
+    def query(self, motion_ids, motion_times=None, offset=None, *, progress=None, step_shift=0, dt=0.0, start_times=None,
+              start_offsets=None, time_steps=1, traj_dt=0.0, out=None, root_only=False, with_frames=False, with_records=False):
+        """One launch.  Times either given (``motion_times``) or built in-kernel from the episode clock
+        ((progress + step_shift) * dt + start_times + start_offsets).  ``out``: dict of preallocated outputs to reuse."""
+        lib = _lib.load()
+        dev = self._device
+        ids = motion_ids
+        if ids.dtype != torch.int64 or not ids.is_cuda:
+            raise TypeError("motion_ids: int64 device tensor expected")
+        ids = ids.contiguous()
+        ne = ids.numel()                                   # per-env arrays
+        n = ne if motion_times is not None else ne * int(time_steps)
+        j, nd = self.num_bodies, self.num_dof
+        keep = [ids]
+
+        def f32(t, name, shape):
+            if t is None:
+                return None
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise TypeError(f"{name}: float32 device tensor expected")
+            t = t.contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+            keep.append(t)
+            return t
+
+        a = MotionStateArgs()
+        self._tables(a)
+        a.n, a.motion_ids = n, ids.data_ptr()
+        if motion_times is not None:
+            a.motion_times = f32(motion_times, "motion_times", (n,)).data_ptr()
+        else:
+            if progress is None or progress.dtype != torch.int64:
+                raise TypeError("query needs motion_times or an int64 progress tensor")
+            progress = progress.contiguous()
+            keep.append(progress)
+            a.progress, a.step_shift, a.dt = progress.data_ptr(), int(step_shift), float(dt)
+            a.time_steps, a.traj_dt = int(time_steps), float(traj_dt)
+            st, so = f32(start_times, "start_times", (ne,)), f32(start_offsets, "start_offsets", (ne,))
+            a.start_times = st.data_ptr() if st is not None else None
+            a.start_offsets = so.data_ptr() if so is not None else None
+        off = f32(offset, "offset", (ne, 3))
+        a.offset = off.data_ptr() if off is not None else None
+        res = {} if out is None else out
+        e = lambda key, *shape, dtype=torch.float32: res[key] if key in res else res.setdefault(key, torch.empty(*shape, dtype=dtype, device=dev))
+        if root_only:
+            a.root_only = 1
+            a.root_pos = e("root_pos", n, 3).data_ptr()
+        else:
+            a.rg_pos, a.rb_rot = e("rg_pos", n, j, 3).data_ptr(), e("rb_rot", n, j, 4).data_ptr()
+            a.body_vel, a.body_ang_vel = e("body_vel", n, j, 3).data_ptr(), e("body_ang_vel", n, j, 3).data_ptr()
+            a.dof_pos, a.dof_vel = e("dof_pos", n, nd).data_ptr(), e("dof_vel", n, nd).data_ptr()
+        if with_records and not root_only:
+            rec = e("rb_records", n, j, 13)
+            a.rb_records, a.rb_query_stride = rec.data_ptr(), rec.stride(0)
+        if with_frames:
+            a.frame_idx0, a.frame_idx1 = e("frame_idx0", n, dtype=torch.int64).data_ptr(), e("frame_idx1", n, dtype=torch.int64).data_ptr()
+            a.blend = e("blend", n).data_ptr()
+        _lib.check(lib.pulse_motion_state(ctypes.byref(a), _stream()), "pulse_motion_state")
+        return res
+
+    def get_motion_state(self, motion_ids, motion_times, offset=None, out=None):
+        """MotionLibBase.get_motion_state (motion_lib_base.py:434-517).  Root entries are views of body 0 (the reference
+        clones them); motion_aa / motion_bodies / motion_limb_weights (SMPL shape metadata) are not carried."""
+        res = self.query(motion_ids, motion_times, offset, out=out)
+        res["root_pos"], res["root_rot"] = res["rg_pos"][:, 0], res["rb_rot"][:, 0]
+        res["root_vel"], res["root_ang_vel"] = res["body_vel"][:, 0], res["body_ang_vel"][:, 0]
+        return res
+
+    def get_root_pos_smpl(self, motion_ids, motion_times):
+        return self.query(motion_ids, motion_times, root_only=True)

@@ -147,3 +147,62 @@ class RecordedMotion:
     def next_after_reset(self):
         f = self.sim.frame
         return {k: v[f] for k, v in self.rollout.ref_next_reset.items()}
+
+
+class KinematicSim:
+    """Physics stand-in for the motion-library path: the simulated humanoid TRACKS the reference motion with recorded
+    perturbations.  ``simulate_and_refresh`` sets the rigid-body state to the reference state the env asked it to
+    track (the t+1 reference of the previous step) plus this frame's noise record; reference-state init
+    (humanoid_amp.py:447-488, humanoid_im.py:966-986) writes the motion state unperturbed.  Same tensor surface as
+    RecordedSim.  The noise bank is generated on the CPU (pulse_amd/synthetic.py generator) so a CPU twin can replay it."""
+
+    def __init__(self, num_envs, bank_frames, device, seed=1234, rank=0, drift_rate=0.01):
+        g = syn.make_generator(seed + 17, rank)
+        n, j, f = num_envs, syn.NUM_BODIES, bank_frames
+        self.num_envs, self.bank_frames = n, f
+        noise = torch.randn(f, n, j, syn.RB_WIDTH, generator=g)
+        noise[..., 0:3] *= 0.03
+        noise[..., 3:7] *= 0.04
+        noise[..., 7:10] *= 0.15
+        noise[..., 10:13] *= 0.3
+        far = torch.rand(f, n, generator=g) < drift_rate          # some envs lose their reference -> early termination
+        noise[:, :, 13, 0:3] += far[..., None].float() * 1.0
+        self.bank = {"rb": noise, "dof_force": 50.0 * torch.randn(f, n, syn.NUM_DOF, generator=g),
+                     "dof_pos": 0.02 * torch.randn(f, n, syn.NUM_DOF, generator=g), "dof_vel": 0.1 * torch.randn(f, n, syn.NUM_DOF, generator=g),
+                     "gt_action": (0.4 * torch.randn(f, n, syn.NUM_DOF, generator=g)).clamp(-1, 1)}
+        self.bank = {k: v.to(device) for k, v in self.bank.items()}
+        self.frame = 0
+        self.rigid_body_state = torch.zeros(n, j, syn.RB_WIDTH, device=device)
+        self.rigid_body_state[..., 6] = 1.0
+        self.dof_force = self.bank["dof_force"][0].clone()
+        self.dof_vel = torch.zeros(n, syn.NUM_DOF, device=device)
+        self.dof_pos = torch.zeros(n, syn.NUM_DOF, device=device)
+        self.pd_targets = torch.zeros(n, syn.NUM_DOF, device=device)
+        self._target = None
+
+    @property
+    def gt_action(self):
+        return self.bank["gt_action"][self.frame]
+
+    def set_dof_position_target_tensor(self, pd_tar):
+        self.pd_targets = pd_tar
+
+    def track(self, state):
+        """state: a MotionLib query result with rb_records / dof_pos / dof_vel (the reference at the NEXT control step)."""
+        self._target = state
+
+    def simulate_and_refresh(self):
+        self.frame = (self.frame + 1) % self.bank_frames
+        f, t = self.frame, self._target
+        rb = self.rigid_body_state
+        torch.add(t["rb_records"], self.bank["rb"][f], out=rb)
+        q = rb[..., 3:7]
+        q.div_(q.norm(dim=-1, keepdim=True))
+        torch.add(t["dof_pos"], self.bank["dof_pos"][f], out=self.dof_pos)
+        torch.add(t["dof_vel"], self.bank["dof_vel"][f], out=self.dof_vel)
+        self.dof_force.copy_(self.bank["dof_force"][f])
+
+    def set_env_states_masked(self, mask, state):
+        torch.where(mask[:, None, None], state["rb_records"], self.rigid_body_state, out=self.rigid_body_state)
+        torch.where(mask[:, None], state["dof_pos"], self.dof_pos, out=self.dof_pos)
+        torch.where(mask[:, None], state["dof_vel"], self.dof_vel, out=self.dof_vel)

@@ -127,3 +127,89 @@ def rollout_scalars(g, t, n, done_p=0.02):
     term = dones & (_rand(g, t, n) < 0.5)
     next_values = next_values * (1.0 - term.float()[..., None])
     return rewards, values, next_values, dones.to(torch.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Synthetic motion library: the flat per-frame tables MotionLibBase builds from AMASS clips
+# (phc/utils/motion_lib_base.py:287-316): gts/grs/lrs/gvs/gavs (F, 24, 3|4), dvs (F, 23, 3) plus per-motion
+# length / fps / dt / frame count.  Clips are smooth random articulated motions of an SMPL-shaped kinematic tree
+# (forward kinematics over SMPL_PARENTS), velocities by finite differences like SkeletonMotion does.
+# ---------------------------------------------------------------------------------------------------------------------
+SMPL_PARENTS = [-1, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 12, 11, 14, 15, 16, 17, 11, 19, 20, 21, 22]
+
+
+def _exp_map_to_quat_xyzw(e):
+    ang = e.norm(dim=-1, keepdim=True)
+    half = 0.5 * ang
+    k = torch.where(ang > 1e-8, torch.sin(half) / ang.clamp_min(1e-8), torch.full_like(ang, 0.5))
+    return torch.cat([e * k, torch.cos(half)], dim=-1)
+
+
+def _quat_rotate_xyzw(q, v):
+    qv, w = q[..., :3], q[..., 3:4]
+    t = 2.0 * torch.cross(qv, v, dim=-1)
+    return v + w * t + torch.cross(qv, t, dim=-1)
+
+
+def synthetic_motion_library(g, num_motions, min_frames=45, max_frames=180, fps=30.0):
+    """dict of CPU tensors in the reference's table layout; frame f of motion m sits at length_starts[m] + f."""
+    m, j = num_motions, NUM_BODIES
+    num_frames = torch.randint(min_frames, max_frames + 1, (m,), generator=g, dtype=torch.int64)
+    starts = torch.cumsum(num_frames, 0) - num_frames
+    total = int(num_frames.sum())
+    mid = torch.repeat_interleave(torch.arange(m), num_frames)                     # motion of every frame
+    fidx = torch.arange(total) - starts[mid]
+    dt = 1.0 / fps
+    t = (fidx.float() * dt)[:, None, None]                                         # (F,1,1)
+    # joint exp-map trajectories: two sinusoids per dof
+    amp = 0.35 * _rand(g, m, j, 3, 2)
+    amp[:, 0] *= 0.3                                                               # pelvis tilt stays small
+    frq = 0.3 + 1.7 * _rand(g, m, j, 3, 2)
+    pha = 6.2831853 * _rand(g, m, j, 3, 2)
+    e = (amp[mid] * torch.sin(6.2831853 * frq[mid] * t[..., None] + pha[mid])).sum(-1)      # (F,24,3)
+    yaw_rate = 0.8 * _randn(g, m)
+    e[:, 0, 2] += 6.2831853 * _rand(g, m)[mid] + yaw_rate[mid] * t[:, 0, 0]
+    lrs = _exp_map_to_quat_xyzw(e)
+    lrs = lrs / lrs.norm(dim=-1, keepdim=True)
+    offsets = 0.08 + 0.3 * _rand(g, j, 3) * torch.tensor([0.4, 0.4, 1.0])
+    offsets[0] = 0.0
+    # root path: constant drift + sway
+    drift = 0.6 * _randn(g, m, 3) * torch.tensor([1.0, 1.0, 0.0])
+    sway = 0.05 * _randn(g, m, 3)
+    root = drift[mid] * t[:, 0] + sway[mid] * torch.sin(3.0 * t[:, 0]) + torch.tensor([0.0, 0.0, 0.9])
+    grs = torch.empty(total, j, 4)
+    gts = torch.empty(total, j, 3)
+    for b in range(j):
+        p = SMPL_PARENTS[b]
+        if p < 0:
+            grs[:, b], gts[:, b] = lrs[:, b], root
+        else:
+            grs[:, b] = _quat_mul_xyzw(grs[:, p], lrs[:, b])
+            gts[:, b] = gts[:, p] + _quat_rotate_xyzw(grs[:, p], offsets[b].expand(total, 3))
+    grs = grs / grs.norm(dim=-1, keepdim=True)
+
+    def fdiff(x):                                                                  # forward difference inside each clip, last frame repeats
+        nxt = torch.roll(x, -1, 0)
+        d = (nxt - x) / dt
+        last = fidx == (num_frames[mid] - 1)
+        d[last] = d[torch.where(last)[0] - 1]
+        return d
+
+    def ang_vel(q):                                                                # 2 (q_{f+1} conj(q_f)).xyz / dt
+        nxt = torch.roll(q, -1, 0)
+        conj = q * torch.tensor([-1.0, -1.0, -1.0, 1.0])
+        dq = _quat_mul_xyzw(nxt, conj)
+        dq = torch.where(dq[..., 3:4] < 0, -dq, dq)
+        w = 2.0 * dq[..., :3] / dt
+        last = fidx == (num_frames[mid] - 1)
+        w[last] = w[torch.where(last)[0] - 1]
+        return w
+
+    gvs, gavs = fdiff(gts), ang_vel(grs)
+    dvs = ang_vel(lrs)[:, 1:]
+    return {
+        "gts": gts.contiguous(), "grs": grs.contiguous(), "lrs": lrs.contiguous(), "gvs": gvs.contiguous(),
+        "gavs": gavs.contiguous(), "dvs": dvs.contiguous(),
+        "motion_num_frames": num_frames, "motion_fps": torch.full((m,), fps), "motion_dt": torch.full((m,), dt),
+        "motion_lengths": ((1.0 / fps) * (num_frames - 1).double()).float(), "length_starts": starts,   # curr_len, motion_lib_base.py:263
+    }

@@ -23,6 +23,8 @@
 // what lets a single ds_read_b128 feed four consecutive MFMAs.
 // 256 CUs / 8 XCDs: the 1-D grid is remapped so each XCD owns a contiguous band of m-tiles (A panels
 // stay in that XCD's L2; the small weight matrix is shared by all).
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace pulse {
@@ -104,6 +106,45 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (
     }
 }
 
+// ---- per-unit forms (one 16-byte access each) for the interleaved main loop -------------------------------
+template <bool KC>
+__device__ __forceinline__ void load_unit(float4& r, const float* __restrict__ P, int ld, int out0, int ext, int k0, int kbeg, int kend,
+                                          int tid, int i) {
+    if constexpr (KC) {
+        int k = k0 + (tid & 7) * 4;
+        k = k < kend ? k : kbeg;
+        int row = out0 + (tid >> 3) + 32 * i;
+        row = row < ext ? row : ext - 1;
+        r = *reinterpret_cast<const float4*>(P + (long long)row * ld + k);
+    } else {
+        int m = out0 + (tid & 31) * 4;
+        m = m < ext ? m : 0;
+        int k = k0 + (tid >> 5) + 8 * i;
+        k = k < kend ? k : kend - 1;
+        r = *reinterpret_cast<const float4*>(P + (long long)k * ld + m);
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_unit(float* __restrict__ s, const float4& r, int k0, int kend, int tid, int i) {
+    if constexpr (KC) {
+        const int k = k0 + (tid & 7) * 4;
+        float4 v = r;
+        if (k + 3 >= kend) {
+            if (k >= kend) v.x = 0.f;
+            if (k + 1 >= kend) v.y = 0.f;
+            if (k + 2 >= kend) v.z = 0.f;
+            v.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * PITCH_KC + (tid & 7) * 4) = v;
+    } else {
+        const int k = k0 + (tid >> 5) + 8 * i;
+        float4 v = r;
+        if (k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * PITCH_MC + (tid & 31) * 4) = v;
+    }
+}
+
 // fragment for one 32-wide tile: the 4 k-values this lane feeds to 4 consecutive MFMAs
 template <bool KC>
 __device__ __forceinline__ float4 load_frag(const float* __restrict__ s, int out_in_tile, int kk, int half) {
@@ -153,7 +194,67 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[4], rb[4];
+    float4 fa[2][2], fb[2][2];                                   // two fragment sets: one feeding MFMAs, one in flight from LDS
     const int nkt = (kend - kbeg + BK - 1) / BK;
+    const int arow = wm * 64 + l31, brow = wn * 64 + l31;
+
+    // fragment unit u of set SET: order fa0, fb0, fb1, fa1 = the order the MFMA pairs consume them
+    auto frag_unit = [&](int set, int u, const float* a_s, const float* b_s, int kk) {
+        if (u == 0) fa[set][0] = load_frag<AKC>(a_s, arow, kk, half);
+        else if (u == 1) fb[set][0] = load_frag<BKC>(b_s, brow, kk, half);
+        else if (u == 2) fb[set][1] = load_frag<BKC>(b_s, brow + 32, kk, half);
+        else fa[set][1] = load_frag<AKC>(a_s, arow + 32, kk, half);
+    };
+    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+
+    // One k-tile = 64 MFMAs issued as 32 PAIRS (two accumulator chains alternate, so no MFMA waits on its predecessor).
+    // With ONE wave per SIMD doing all the work, everything else has to ride in the issue shadow of those MFMAs
+    // (each occupies the matrix pipe for 64 cycles): after every pair exactly one small unit of side work is issued --
+    //   pairs  0-3   fragment reads for pairs  8-15   (set 1, k +8)
+    //   pairs  8-11  fragment reads for pairs 16-23   (set 0, k +16)
+    //   pairs 16-19  fragment reads for pairs 24-31   (set 1, k +24)
+    //   pairs 19-26  the 8 register->LDS spills of tile t+1 (its global loads were issued a tile ago)
+    //   after pair 27  the ONE barrier of the tile
+    //   pairs 24-31  the 8 global loads of tile t+2 (load k re-uses the registers spill k just drained)
+    //   pairs 28-31  fragment reads for pairs 0-7 of tile t+1 (set 0, other LDS stage)
+    // sched_barrier(0) after every pair pins that order.
+    auto tile = [&](auto last_tag, int t) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int cur = t & 1;
+        const float* a_s = smem + cur * 2 * TILE_FLOATS;
+        const float* b_s = a_s + TILE_FLOATS;
+        float* a_o = smem + (cur ^ 1) * 2 * TILE_FLOATS;
+        float* b_o = a_o + TILE_FLOATS;
+        const int k_next = kbeg + (t + 1) * BK, k_next2 = kbeg + (t + 2) * BK;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const int grp = p >> 3, set = grp & 1, q = p & 7, i = q >> 2, c = q & 3;
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[set][i], c), comp(fb[set][0], c), acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[set][i], c), comp(fb[set][1], c), acc[i][1], 0, 0, 0);
+            if (p < 4) frag_unit(1, p, a_s, b_s, 8);
+            else if (p >= 8 && p < 12) frag_unit(0, p - 8, a_s, b_s, 16);
+            else if (p >= 16 && p < 20) frag_unit(1, p - 16, a_s, b_s, 24);
+            if constexpr (!LAST) {
+                if (p >= 19 && p < 27) {
+                    const int u = p - 19;
+                    if (u < 4) store_unit<AKC>(a_o, ra[u], k_next, kend, tid, u);
+                    else store_unit<BKC>(b_o, rb[u - 4], k_next, kend, tid, u - 4);
+                }
+                if (p == 27) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                }
+                if (p >= 24) {              // unconditional: past the last tile the clamped addresses re-read valid memory, never stored
+                    const int u = p - 24;
+                    if (u < 4) load_unit<AKC>(ra[u], A, g.lda, m0, g.M, k_next2, kbeg, kend, tid, u);
+                    else load_unit<BKC>(rb[u - 4], B, g.ldb, n0, g.N, k_next2, kbeg, kend, tid, u - 4);
+                }
+                if (p >= 28) frag_unit(0, p - 28, a_o, b_o, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     if (nkt > 0) {
         load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg, kbeg, kend, tid);
         load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg, kbeg, kend, tid);
@@ -161,39 +262,19 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
         store_tile<BKC>(smem + TILE_FLOATS, rb, kbeg, kend, tid);
     }
     __syncthreads();
-
-    for (int t = 0; t < nkt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nkt) {
-            load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg + (t + 1) * BK, kbeg, kend, tid);
-            load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg + (t + 1) * BK, kbeg, kend, tid);
-        }
-        const float* a_s = smem + cur * 2 * TILE_FLOATS;
-        const float* b_s = a_s + TILE_FLOATS;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
-            float4 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = load_frag<AKC>(a_s, wm * 64 + i * 32 + l31, kk, half);
-                fb[i] = load_frag<BKC>(b_s, wn * 64 + i * 32 + l31, kk, half);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (t + 1 < nkt) {
-            store_tile<AKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS, ra, kbeg + (t + 1) * BK, kend, tid);
-            store_tile<BKC>(smem + (cur ^ 1) * 2 * TILE_FLOATS + TILE_FLOATS, rb, kbeg + (t + 1) * BK, kend, tid);
-        }
-        __syncthreads();
+    if (nkt > 1) {
+        load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg + BK, kbeg, kend, tid);
+        load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg + BK, kbeg, kend, tid);
     }
+    if (nkt > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) frag_unit(0, u, smem, smem + TILE_FLOATS, 0);
+    }
+    for (int t = 0; t + 1 < nkt; ++t) tile(std::false_type{}, t);
+    if (nkt > 0) tile(std::true_type{}, nkt - 1);
+    __syncthreads();                                              // the epilogue reuses the staging buffers
+#undef PULSE_LOAD_FRAGS
+#undef PULSE_MFMA_GROUP
 
     // ---- epilogue -----------------------------------------------------------------------------------
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
@@ -414,7 +495,8 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     auto al16 = [](const void* p, long long ld, long long st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0 && (st % 4) == 0; };
     g.vec_epi = al16(d->C, d->ldc, d->stride_c) && (d->split_stride % 4) == 0 && (!d->aux || al16(d->aux, d->ldaux, d->stride_aux)) &&
                 (!d->C2 || al16(d->C2, d->ldc2, d->stride_c2)) && (!d->bias || al16(d->bias, 4, d->stride_bias));
-    const size_t lds = sizeof(float) * 4 * TILE_FLOATS;   // 73,728 B -> two workgroups per CU
+    static const size_t lds_extra = getenv("PULSE_GEMM_LDS_EXTRA") ? (size_t)atoi(getenv("PULSE_GEMM_LDS_EXTRA")) : 0;   // tuning knob
+    const size_t lds = sizeof(float) * 4 * TILE_FLOATS + lds_extra;   // 73,728 B -> two workgroups per CU
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
     // The 72 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling
     // hipFuncSetAttribute on every launch serialises the host against the stream).

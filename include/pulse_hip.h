@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 5
+#define PULSE_ABI_VERSION 6
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -74,6 +74,20 @@ int pulse_calc_heading_quat(const float* q, float* out, int64_t m, int inverse, 
  * 2. Fused HumanoidIm post-physics step: reward -> reset -> next observation
  *    (phc/env/tasks/humanoid.py:1315-1331 order).
  * ------------------------------------------------------------------------- */
+/* Packed reference-motion library (layout and semantics: section 2b). */
+typedef struct pulse_motion_tables {
+    const float* frames;              /* (total_frames, frame_stride) packed records */
+    int64_t frame_stride;             /* floats per record, multiple of 4 */
+    int64_t total_frames;
+    int32_t num_bodies;               /* J <= 32 */
+    int32_t off_gts, off_grs, off_lrs, off_gvs, off_gavs, off_dvs;   /* float offsets of the fields inside a record */
+    const float* motion_lengths;      /* (num_motions) seconds  (_motion_lengths) */
+    const float* motion_dt;           /* (num_motions)          (_motion_dt) */
+    const int64_t* motion_num_frames; /* (num_motions)          (_motion_num_frames) */
+    const int64_t* length_starts;     /* (num_motions) first record of each motion (:311-314) */
+    int32_t num_motions;
+} pulse_motion_tables;
+
 typedef struct pulse_reward_specs {
     /* phc/env/tasks/humanoid_im.py:55 (reward_specs) and :92 (power_coefficient) */
     float k_pos, k_rot, k_vel, k_ang_vel;
@@ -145,6 +159,31 @@ typedef struct pulse_im_step_args {
     float* rew_raw;           /* (num_envs, 5 if power_reward else 4) */
     int64_t* reset;           /* (num_envs) */
     int64_t* terminate;       /* (num_envs) */
+
+    /* ---- optional: episode clock advanced in-kernel (post_physics_step: progress_buf += 1, humanoid.py:1316;
+       _compute_reset: pass_time, humanoid_im.py:1120-1123,1148).  progress_rw != NULL: every processed env uses
+       p = progress_rw[e] + progress_inc as its progress (``progress`` is ignored) and p is written back.
+       clock_motion_len != NULL: pass_time = cycle_motion ? p >= max_episode_length - 1
+                                                          : p * clock_dt + start_times[e] + start_offsets[e] >= clock_motion_len[e]
+       (``pass_time`` is ignored; the flag is also stored to pass_time_out when given). */
+    int64_t* progress_rw; int32_t progress_inc;
+    float clock_dt;           /* control step, also the time base of the in-kernel reference below */
+    const float* clock_start_times; const float* clock_start_offsets; const float* clock_motion_len;
+    int32_t cycle_motion; int32_t max_episode_length;
+    uint8_t* pass_time_out;
+
+    /* ---- optional: reference motion evaluated in-kernel from the packed library (use_motion != 0) instead of
+       ref_now_* / ref_next_*: two frame records per (env, time) are blended in the staging phase
+       (get_motion_state, motion_lib_base.py:434-517) at t = p * clock_dt + start + offset (reward / reset) and
+       (p + 1) * clock_dt + k * traj_dt + start + offset, k < time_steps (task obs; humanoid_im.py:723-735).
+       track_*: optional outputs of the k = 0 next-step reference as simulator-layout records / dofs. */
+    int32_t use_motion;
+    pulse_motion_tables motion;
+    const int64_t* motion_ids;    /* (num_envs) _sampled_motion_ids */
+    const float* motion_offset;   /* (num_envs, 3) _global_offset or NULL */
+    float traj_dt;
+    float* track_rb; int64_t track_rb_stride;   /* (num_envs, J, 13) */
+    float* track_dof_pos; float* track_dof_vel; /* (num_envs, (J-1)*3) */
 } pulse_im_step_args;
 
 /* width of the self / task observation for the given options */
@@ -182,18 +221,7 @@ int pulse_amp_obs(const pulse_amp_obs_args* args, pulse_stream_t s);
  *     so a query touches two contiguous records (SMPL: 477 floats, pitch 480 = 1920 B)
  *     instead of twelve scattered rows.  Frame f of motion m is record length_starts[m]+f.
  * ------------------------------------------------------------------------- */
-typedef struct pulse_motion_tables {
-    const float* frames;              /* (total_frames, frame_stride) packed records */
-    int64_t frame_stride;             /* floats per record, multiple of 4 */
-    int64_t total_frames;
-    int32_t num_bodies;               /* J <= 32 */
-    int32_t off_gts, off_grs, off_lrs, off_gvs, off_gavs, off_dvs;   /* float offsets of the fields inside a record */
-    const float* motion_lengths;      /* (num_motions) seconds  (_motion_lengths) */
-    const float* motion_dt;           /* (num_motions)          (_motion_dt) */
-    const int64_t* motion_num_frames; /* (num_motions)          (_motion_num_frames) */
-    const int64_t* length_starts;     /* (num_motions) first record of each motion (:311-314) */
-    int32_t num_motions;
-} pulse_motion_tables;
+/* pulse_motion_tables: declared in section 2 (the fused env step can evaluate the reference in-kernel too). */
 
 typedef struct pulse_motion_state_args {
     pulse_motion_tables tab;
@@ -220,9 +248,55 @@ typedef struct pulse_motion_state_args {
     float* rb_records;                /* optional (n, J, 13) [pos | rot | vel | ang vel] records, the simulator's rigid-body */
     int64_t rb_query_stride;          /*   layout (humanoid.py:219-222): reference-state init writes them as-is; floats per query */
     int64_t* frame_idx0; int64_t* frame_idx1; float* blend;   /* optional (n): _calc_frame_blend results, idx RELATIVE to the motion */
+    /* reset mode (reset_mask != NULL; per env, n = num_envs): reference-state init of the masked envs in one launch
+       (_reset_envs -> _sample_ref_state, humanoid_im.py:966-986).  For env e with reset_mask[e] != 0:
+           start = reset_phase ? reset_phase[e] * motion_length : 0      (MotionLibBase.sample_time with phase ~ U[0,1))
+           reset_start_times[e] = start; reset_progress[e] = 0; reset_clear0/1[e] = 0   (reset_buf, _terminate_buf)
+           outputs at row e := state at time step_shift * dt + start + start_offsets[e]
+       rows of unmasked envs are left untouched (so the outputs can BE the simulator's state tensors). */
+    const uint8_t* reset_mask; const float* reset_phase;
+    float* reset_start_times; int64_t* reset_progress; int64_t* reset_clear0; int64_t* reset_clear1;
 } pulse_motion_state_args;
 int pulse_sizeof_motion_state_args(void);
 int pulse_motion_state(const pulse_motion_state_args* args, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
+ * 2c. Per-step rollout bookkeeping of play_steps (phc/learning/amp_agent.py:372-412,
+ *     common_agent.py:318-347) in ONE launch instead of ~45 elementwise / reduction launches:
+ *       rewards[n]     = (reward + shift) * scale                 (DefaultRewardsShaper)
+ *       dones[n]       = dones
+ *       next_values[n] = unnorm(critic(next_obs)) * (1 - terminate)          (:394-398)
+ *       current_rewards += reward; current_lengths += 1
+ *       game_rewards.update(current_rewards[done]); game_lengths.update(current_lengths[done])
+ *                       (rl_games AverageMeter: windowed running mean, Appendix B)
+ *       current_* *= (1 - done);  done_mask = dones != 0
+ *     Buffer element of env e lives at base[e * env_stride] (the experience buffer is env-major).
+ * ------------------------------------------------------------------------- */
+typedef struct pulse_rollout_record_args {
+    int32_t num_envs;
+    const float* rewards;             /* (N) env reward buffer */
+    float reward_scale, reward_shift;
+    const int64_t* dones;             /* (N) reset_buf */
+    const int64_t* terminate;         /* (N) extras['terminate'] */
+    const float* value_raw; int64_t value_stride;       /* critic output for the NEXT obs, (N, stride) */
+    const double* value_mean; const double* value_var;  /* value normaliser statistics (NULL: no un-normalisation) */
+    float value_eps;
+    float* buf_rewards; float* buf_next_values; uint8_t* buf_dones; int64_t env_stride;   /* slot n of the experience buffer */
+    float* current_rewards; float* current_lengths;      /* (N) episode accumulators */
+    float* meter_rewards; float* meter_lengths;          /* each: [mean, current_size] (AverageMeter state) */
+    float meter_max_size;                                /* games_to_track */
+    uint8_t* done_mask;               /* (N) out: dones != 0 (drives the next masked reset) */
+} pulse_rollout_record_args;
+int pulse_sizeof_rollout_record_args(void);
+int pulse_rollout_record(const pulse_rollout_record_args* args, pulse_stream_t s);
+
+/* Physics STAND-IN (Isaac Gym is out of scope): the simulated humanoid tracks a reference state with a recorded
+ * perturbation -- rb = target + noise (quaternions re-normalised), dof_pos/vel = target + noise, dof_force = recorded.
+ * Bench / test infrastructure for the motion-library path, kept in the library so the stand-in costs one launch. */
+int pulse_kinematic_sim_step(const float* target_rb, const float* noise_rb, float* rb, int64_t num_envs, int32_t num_bodies,
+                             const float* target_dof_pos, const float* noise_dof_pos, float* dof_pos,
+                             const float* target_dof_vel, const float* noise_dof_vel, float* dof_vel,
+                             const float* force_src, float* dof_force, int32_t num_dof, pulse_stream_t s);
 
 /* ------------------------------------------------------------------------- *
  * 3. GAE: CommonAgent.discount_values + returns, phc/learning/common_agent.py:493-505,

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -29,6 +29,14 @@ class RewardSpecs(Structure):
                 ("power_coef", c_float), ("power_reward", c_int32)]
 
 
+class MotionTables(Structure):
+    _fields_ = [("frames", c_void_p), ("frame_stride", c_int64), ("total_frames", c_int64), ("num_bodies", c_int32),
+                ("off_gts", c_int32), ("off_grs", c_int32), ("off_lrs", c_int32), ("off_gvs", c_int32), ("off_gavs", c_int32),
+                ("off_dvs", c_int32),
+                ("motion_lengths", c_void_p), ("motion_dt", c_void_p), ("motion_num_frames", c_void_p), ("length_starts", c_void_p),
+                ("num_motions", c_int32)]
+
+
 class ImStepArgs(Structure):
     _fields_ = [
         ("rb", c_void_p), ("rb_env_stride", c_int64), ("num_envs", c_int32), ("num_bodies", c_int32),
@@ -44,6 +52,11 @@ class ImStepArgs(Structure):
         ("specs", RewardSpecs),
         ("obs", c_void_p), ("obs_stride", c_int64), ("obs_cols", c_int32),
         ("rew", c_void_p), ("rew_raw", c_void_p), ("reset", c_void_p), ("terminate", c_void_p),
+        ("progress_rw", c_void_p), ("progress_inc", c_int32), ("clock_dt", c_float),
+        ("clock_start_times", c_void_p), ("clock_start_offsets", c_void_p), ("clock_motion_len", c_void_p),
+        ("cycle_motion", c_int32), ("max_episode_length", c_int32), ("pass_time_out", c_void_p),
+        ("use_motion", c_int32), ("motion", MotionTables), ("motion_ids", c_void_p), ("motion_offset", c_void_p), ("traj_dt", c_float),
+        ("track_rb", c_void_p), ("track_rb_stride", c_int64), ("track_dof_pos", c_void_p), ("track_dof_vel", c_void_p),
     ]
 
 
@@ -55,14 +68,6 @@ class AmpObsArgs(Structure):
                 ("out", c_void_p), ("out_stride", c_int64)]
 
 
-class MotionTables(Structure):
-    _fields_ = [("frames", c_void_p), ("frame_stride", c_int64), ("total_frames", c_int64), ("num_bodies", c_int32),
-                ("off_gts", c_int32), ("off_grs", c_int32), ("off_lrs", c_int32), ("off_gvs", c_int32), ("off_gavs", c_int32),
-                ("off_dvs", c_int32),
-                ("motion_lengths", c_void_p), ("motion_dt", c_void_p), ("motion_num_frames", c_void_p), ("length_starts", c_void_p),
-                ("num_motions", c_int32)]
-
-
 class MotionStateArgs(Structure):
     _fields_ = [("tab", MotionTables), ("n", c_int64), ("motion_ids", c_void_p), ("motion_times", c_void_p),
                 ("progress", c_void_p), ("step_shift", c_int32), ("dt", c_float), ("start_times", c_void_p), ("start_offsets", c_void_p),
@@ -70,7 +75,18 @@ class MotionStateArgs(Structure):
                 ("rg_pos", c_void_p), ("rb_rot", c_void_p), ("body_vel", c_void_p), ("body_ang_vel", c_void_p),
                 ("dof_pos", c_void_p), ("dof_vel", c_void_p), ("root_pos", c_void_p),
                 ("rb_records", c_void_p), ("rb_query_stride", c_int64),
-                ("frame_idx0", c_void_p), ("frame_idx1", c_void_p), ("blend", c_void_p)]
+                ("frame_idx0", c_void_p), ("frame_idx1", c_void_p), ("blend", c_void_p),
+                ("reset_mask", c_void_p), ("reset_phase", c_void_p), ("reset_start_times", c_void_p), ("reset_progress", c_void_p),
+                ("reset_clear0", c_void_p), ("reset_clear1", c_void_p)]
+
+
+class RolloutRecordArgs(Structure):
+    _fields_ = [("num_envs", c_int32), ("rewards", c_void_p), ("reward_scale", c_float), ("reward_shift", c_float),
+                ("dones", c_void_p), ("terminate", c_void_p), ("value_raw", c_void_p), ("value_stride", c_int64),
+                ("value_mean", c_void_p), ("value_var", c_void_p), ("value_eps", c_float),
+                ("buf_rewards", c_void_p), ("buf_next_values", c_void_p), ("buf_dones", c_void_p), ("env_stride", c_int64),
+                ("current_rewards", c_void_p), ("current_lengths", c_void_p), ("meter_rewards", c_void_p), ("meter_lengths", c_void_p),
+                ("meter_max_size", c_float), ("done_mask", c_void_p)]
 
 
 class GemmDesc(Structure):
@@ -125,6 +141,9 @@ SIGNATURES = {
     "pulse_sizeof_amp_obs_args": (c_int, []),
     "pulse_amp_obs_width": (c_int, [c_int, c_int, c_int]),
     "pulse_amp_obs": (c_int, [POINTER(AmpObsArgs), P]),
+    "pulse_sizeof_rollout_record_args": (c_int, []),
+    "pulse_rollout_record": (c_int, [POINTER(RolloutRecordArgs), P]),
+    "pulse_kinematic_sim_step": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, P, P, P, P, c_int32, P]),
     "pulse_sizeof_motion_state_args": (c_int, []),
     "pulse_motion_state": (c_int, [POINTER(MotionStateArgs), P]),
     "pulse_gae": (c_int, [P, P, P, P, c_int32, c_int32, c_int64, c_int64, c_float, c_float, P, P, P]),

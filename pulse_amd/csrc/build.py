@@ -28,6 +28,7 @@ SOURCES = [
     ("env_step.hip", NO_CONTRACT),
     ("amp_obs.hip", NO_CONTRACT),
     ("motion_state.hip", NO_CONTRACT),
+    ("rollout_ops.hip", NO_CONTRACT),
     ("gae.hip", NO_CONTRACT),
     ("gemm_f32.hip", []),
     ("learner_ops.hip", NO_CONTRACT),

@@ -19,6 +19,7 @@
 // Compiled with -ffp-contract=off so products/sums round exactly like the eager reference.
 #include "common.h"
 #include "rot_math.h"
+#include "motion_math.h"
 
 namespace pulse {
 
@@ -100,6 +101,26 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
         if (a.env_mask && a.env_mask[e] == 0) valid = false;
     }
 
+    // episode clock: the progress value this launch works with (optionally advanced here) and the time-out flag
+    long long prog = 0;
+    bool pass_time = false;
+    if (valid) {
+        if (a.progress_rw) prog = a.progress_rw[e] + a.progress_inc;
+        else if (a.progress) prog = a.progress[e];
+        if (a.clock_motion_len || a.cycle_motion) {
+            if (a.cycle_motion) {
+                pass_time = prog >= (long long)a.max_episode_length - 1;
+            } else {
+                float t = (float)prog * a.clock_dt;
+                if (a.clock_start_times) t = t + a.clock_start_times[e];
+                if (a.clock_start_offsets) t = t + a.clock_start_offsets[e];
+                pass_time = t >= a.clock_motion_len[e];
+            }
+        } else if (a.pass_time) {
+            pass_time = a.pass_time[e] != 0;
+        }
+    }
+
     const bool do_self = a.what & PULSE_IM_SELF_OBS;
     const bool do_task = a.what & PULSE_IM_TASK_OBS;
     const bool do_rew = a.what & PULSE_IM_REWARD;
@@ -118,30 +139,81 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     if (valid) {
         const float* g_rb = a.rb + e * a.rb_env_stride;
         stage(rb_e, g_rb, J13, lane, aligned16(g_rb));
-        if (need_now) {
-            // ref_now_* rows are J*3 / J*4 floats per env; 16-byte aligned whenever J % 4 == 0
-            const float* p = a.ref_now_pos + e * (J * 3);
-            const float* q = a.ref_now_rot + e * (J * 4);
-            const float* v = a.ref_now_vel + e * (J * 3);
-            const float* w = a.ref_now_ang + e * (J * 3);
-            stage(rn_e, p, J * 3, lane, aligned16(p));
-            stage(rn_e + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
-            stage(rn_e + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
-            stage(rn_e + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
-        }
-        if (do_task) {
-            for (int t = 0; t < T; ++t) {
-                const int64_t r = e * T + t;
-                float* d = rx_e + t * J13p;
-                const float* p = a.ref_next_pos + r * (J * 3);
-                const float* v = a.ref_next_vel + r * (J * 3);
-                stage(d, p, J * 3, lane, aligned16(p));
-                stage(d + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
-                if (a.obs_version != 7) {
-                    const float* q = a.ref_next_rot + r * (J * 4);
-                    const float* w = a.ref_next_ang + r * (J * 3);
-                    stage(d + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
-                    stage(d + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
+        if (a.use_motion) {
+            // reference motion straight from the packed library: lane j blends body j of the two frame records
+            // (get_motion_state, motion_lib_base.py:434-517) into the same LDS images the array path stages
+            const pulse_motion_tables& M = a.motion;
+            const long long m = a.motion_ids[e];
+            const float* off = a.motion_offset ? a.motion_offset + 3 * e : nullptr;
+            if (need_now) {
+                float t = (float)prog * a.clock_dt;                       // humanoid_im.py:859
+                if (a.clock_start_times) t = t + a.clock_start_times[e];
+                if (a.clock_start_offsets) t = t + a.clock_start_offsets[e];
+                const FramePair fp = frame_pair(M, m, t);
+                if (lane < J) {
+                    const BodyState b = blend_body(M, fp.r0, fp.r1, fp.blend, lane, off);
+                    float* o = rn_e + 3 * lane;           o[0] = b.p.x; o[1] = b.p.y; o[2] = b.p.z;
+                    o = rn_e + J * 3 + 4 * lane;          o[0] = b.q.x; o[1] = b.q.y; o[2] = b.q.z; o[3] = b.q.w;
+                    o = rn_e + J * 7 + 3 * lane;          o[0] = b.v.x; o[1] = b.v.y; o[2] = b.v.z;
+                    o = rn_e + J * 10 + 3 * lane;         o[0] = b.w.x; o[1] = b.w.y; o[2] = b.w.z;
+                }
+            }
+            if (do_task) {
+                for (int k = 0; k < T; ++k) {
+                    float t = (float)(prog + 1) * a.clock_dt;             // humanoid_im.py:723-731 (next frame, so +1)
+                    if (T > 1) t = t + (float)k * a.traj_dt;
+                    if (a.clock_start_times) t = t + a.clock_start_times[e];
+                    if (a.clock_start_offsets) t = t + a.clock_start_offsets[e];
+                    const FramePair fp = frame_pair(M, m, t);
+                    float* d = rx_e + k * J13p;
+                    if (lane < J) {
+                        const BodyState b = blend_body(M, fp.r0, fp.r1, fp.blend, lane, off);
+                        float* o = d + 3 * lane;              o[0] = b.p.x; o[1] = b.p.y; o[2] = b.p.z;
+                        o = d + J * 3 + 4 * lane;             o[0] = b.q.x; o[1] = b.q.y; o[2] = b.q.z; o[3] = b.q.w;
+                        o = d + J * 7 + 3 * lane;             o[0] = b.v.x; o[1] = b.v.y; o[2] = b.v.z;
+                        o = d + J * 10 + 3 * lane;            o[0] = b.w.x; o[1] = b.w.y; o[2] = b.w.z;
+                        if (k == 0 && a.track_rb) {
+                            float* rec = a.track_rb + e * a.track_rb_stride + 13 * lane;
+                            rec[0] = b.p.x; rec[1] = b.p.y; rec[2] = b.p.z;
+                            rec[3] = b.q.x; rec[4] = b.q.y; rec[5] = b.q.z; rec[6] = b.q.w;
+                            rec[7] = b.v.x; rec[8] = b.v.y; rec[9] = b.v.z;
+                            rec[10] = b.w.x; rec[11] = b.w.y; rec[12] = b.w.z;
+                        }
+                    }
+                    if (k == 0 && a.track_dof_pos && lane < J - 1) {
+                        V3 dp, dv;
+                        blend_dof(M, fp.r0, fp.r1, fp.blend, lane, &dp, &dv);
+                        float* o = a.track_dof_pos + e * (3 * (J - 1)) + 3 * lane;  o[0] = dp.x; o[1] = dp.y; o[2] = dp.z;
+                        o = a.track_dof_vel + e * (3 * (J - 1)) + 3 * lane;         o[0] = dv.x; o[1] = dv.y; o[2] = dv.z;
+                    }
+                }
+            }
+        } else {
+            if (need_now) {
+                // ref_now_* rows are J*3 / J*4 floats per env; 16-byte aligned whenever J % 4 == 0
+                const float* p = a.ref_now_pos + e * (J * 3);
+                const float* q = a.ref_now_rot + e * (J * 4);
+                const float* v = a.ref_now_vel + e * (J * 3);
+                const float* w = a.ref_now_ang + e * (J * 3);
+                stage(rn_e, p, J * 3, lane, aligned16(p));
+                stage(rn_e + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
+                stage(rn_e + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
+                stage(rn_e + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
+            }
+            if (do_task) {
+                for (int t = 0; t < T; ++t) {
+                    const int64_t r = e * T + t;
+                    float* d = rx_e + t * J13p;
+                    const float* p = a.ref_next_pos + r * (J * 3);
+                    const float* v = a.ref_next_vel + r * (J * 3);
+                    stage(d, p, J * 3, lane, aligned16(p));
+                    stage(d + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
+                    if (a.obs_version != 7) {
+                        const float* q = a.ref_next_rot + r * (J * 4);
+                        const float* w = a.ref_next_ang + r * (J * 3);
+                        stage(d + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
+                        stage(d + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
+                    }
                 }
             }
         }
@@ -161,6 +233,10 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
 
     // ---------------- per-(env, body) math ----------------
     if (valid) {
+        if (lane == 0) {                                   // every lane of this env read the old value before the barrier
+            if (a.progress_rw) a.progress_rw[e] = prog;
+            if (a.pass_time_out) a.pass_time_out[e] = pass_time ? 1 : 0;
+        }
         const V3 root_p{rb_e[0], rb_e[1], rb_e[2]};
         const Q4 root_q{rb_e[3], rb_e[4], rb_e[5], rb_e[6]};
         const Q4 hinv = heading_quat(root_q, true);   // calc_heading_quat_inv
@@ -274,7 +350,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                 raw[0] = r_pos; raw[1] = r_rot; raw[2] = r_vel; raw[3] = r_ang;
                 if (a.specs.power_reward) {
                     float p = -a.specs.power_coef * pw;
-                    if (a.progress[e] <= 3) p = 0.0f;     // first frames are not charged (humanoid_im.py:914)
+                    if (prog <= 3) p = 0.0f;     // first frames are not charged (humanoid_im.py:914)
                     rew += p;
                     raw[4] = p;
                 }
@@ -300,8 +376,8 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                 fallen = group_or(fell);
             }
             if (lane == 0) {
-                const bool pt = a.pass_time[e] != 0;
-                int64_t term = (fallen && a.progress[e] > 1) ? 1 : 0;
+                const bool pt = pass_time;
+                int64_t term = (fallen && prog > 1) ? 1 : 0;
                 int64_t rst = pt ? 1 : term;
                 if (a.cycle_counter && !pt && a.cycle_counter[e] > 0) { rst = 0; term = 0; }
                 a.reset[e] = rst;
@@ -362,12 +438,14 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
     if (a.what & PULSE_IM_TASK_OBS) {
         PULSE_REQUIRE(a.obs_version == 6 || a.obs_version == 7, "pulse_im_step: obs_version %d unsupported (6|7)", a.obs_version);
         PULSE_REQUIRE(a.track_ids != nullptr && a.num_track >= 1 && a.num_track <= a.num_bodies, "pulse_im_step: bad track ids");
-        PULSE_REQUIRE(a.ref_next_pos && a.ref_next_vel, "pulse_im_step: null ref_next");
-        PULSE_REQUIRE(a.obs_version == 7 || (a.ref_next_rot && a.ref_next_ang), "pulse_im_step: null ref_next rot/ang");
+        if (!a.use_motion) {
+            PULSE_REQUIRE(a.ref_next_pos && a.ref_next_vel, "pulse_im_step: null ref_next");
+            PULSE_REQUIRE(a.obs_version == 7 || (a.ref_next_rot && a.ref_next_ang), "pulse_im_step: null ref_next rot/ang");
+        }
     }
     if (a.what & (PULSE_IM_REWARD | PULSE_IM_RESET)) {
-        PULSE_REQUIRE(a.ref_now_pos && a.ref_now_rot && a.ref_now_vel && a.ref_now_ang, "pulse_im_step: null ref_now");
-        PULSE_REQUIRE(a.progress != nullptr, "pulse_im_step: null progress");
+        PULSE_REQUIRE(a.use_motion || (a.ref_now_pos && a.ref_now_rot && a.ref_now_vel && a.ref_now_ang), "pulse_im_step: null ref_now");
+        PULSE_REQUIRE(a.progress != nullptr || a.progress_rw != nullptr, "pulse_im_step: null progress");
     }
     if (a.what & PULSE_IM_REWARD) {
         PULSE_REQUIRE(a.rew && a.rew_raw, "pulse_im_step: null reward outputs");
@@ -376,8 +454,20 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
             PULSE_REQUIRE(a.dof_force && a.dof_vel && a.num_dof >= 1, "pulse_im_step: power reward needs dof force/vel");
     }
     if (a.what & PULSE_IM_RESET) {
-        PULSE_REQUIRE(a.reset && a.terminate && a.pass_time && a.term_dist, "pulse_im_step: null reset inputs/outputs");
+        PULSE_REQUIRE(a.reset && a.terminate && a.term_dist, "pulse_im_step: null reset inputs/outputs");
+        PULSE_REQUIRE(a.pass_time || a.clock_motion_len || a.cycle_motion, "pulse_im_step: reset needs pass_time or the in-kernel clock");
         PULSE_REQUIRE(a.reset_ids && a.num_reset >= 1 && a.num_reset <= kLanesPerEnv, "pulse_im_step: bad reset ids");
+    }
+    if (a.use_motion) {
+        const pulse_motion_tables& M = a.motion;
+        PULSE_REQUIRE(M.frames && M.motion_lengths && M.motion_dt && M.motion_num_frames && M.length_starts && a.motion_ids,
+                      "pulse_im_step: in-kernel reference needs the motion tables and motion_ids");
+        PULSE_REQUIRE(M.num_bodies == a.num_bodies, "pulse_im_step: motion library has %d bodies, env %d", M.num_bodies, a.num_bodies);
+        PULSE_REQUIRE(M.frame_stride % 4 == 0 && M.off_grs % 4 == 0 && M.off_lrs % 4 == 0, "pulse_im_step: motion record fields must be 16-B aligned");
+        PULSE_REQUIRE(a.progress != nullptr || a.progress_rw != nullptr, "pulse_im_step: in-kernel reference needs the episode clock (progress)");
+        PULSE_REQUIRE(a.clock_dt > 0.f, "pulse_im_step: in-kernel reference needs clock_dt");
+        PULSE_REQUIRE((a.track_dof_pos == nullptr) == (a.track_dof_vel == nullptr), "pulse_im_step: track_dof_pos / track_dof_vel go together");
+        PULSE_REQUIRE(a.track_rb == nullptr || a.track_rb_stride >= 13 * a.num_bodies, "pulse_im_step: track_rb_stride too small");
     }
     constexpr int E = 4;
     const int J13p = (a.num_bodies * 13 + 3) & ~3;

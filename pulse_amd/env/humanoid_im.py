@@ -153,7 +153,11 @@ class HumanoidIm:
         self._clock_gen = torch.Generator(device=dev)
         self._clock_gen.manual_seed(int(env.get("motion_clock_seed", 2024)))
         self._state_init_random = env.get("stateInit", "Random") != "Start"              # HumanoidAMP.StateInit
-        self._ref_bufs = {"now": {}, "next": {}, "reset": {}, "track": {}, "demo": {}}
+        self._ref_bufs = {"demo": {}}
+        z = lambda *sh: torch.zeros(*sh, device=dev)
+        self._track = {"rb_records": z(n, self.num_bodies, 13), "dof_pos": z(n, self._dof_size), "dof_vel": z(n, self._dof_size)}
+        self.sim.track(self._track)
+        self._reset_phase = torch.zeros(n, device=dev)
 
     def _ref_query(self, which, shift, with_records=False, time_steps=1):
         res = self._motion_lib.query(self._sampled_motion_ids, offset=self._global_offset, progress=self.progress_buf, step_shift=shift,
@@ -164,20 +168,21 @@ class HumanoidIm:
         return res
 
     def _ref_now(self):
-        """Reference at the current motion time (reward / reset; humanoid_im.py:859-861)."""
-        return self._ref_query("now", 0) if self._use_motion_lib else self._motion_lib.now()
+        return self._motion_lib.now()
 
     def _ref_next(self):
-        """Reference at the next control step(s) (task observation, humanoid_im.py:723-735); its single-step form is also what
-        the kinematic physics stand-in tracks."""
-        if not self._use_motion_lib:
-            return self._motion_lib.next()
-        if self._num_traj_samples > 1:
-            self.sim.track(self._ref_query("track", 1, with_records=True))    # the t+1 state the simulator tracks
-            return self._ref_query("next", 1, time_steps=self._num_traj_samples)
-        res = self._ref_query("next", 1, with_records=True)
-        self.sim.track(res)
-        return res
+        return self._motion_lib.next()
+
+    def _motion_kwargs(self, inc=0):
+        """Fused-kernel arguments of the motion-library mode: the episode clock (optionally advanced by ``inc``) and the
+        library the kernel blends its reference from; the t+1 reference also lands in the buffers the physics stand-in tracks."""
+        clock = {"progress_rw": self.progress_buf, "inc": inc, "dt": self.dt, "start_times": self._motion_start_times,
+                 "start_offsets": self._motion_start_times_offset, "motion_len": self._motion_len_env, "cycle_motion": self.cycle_motion,
+                 "max_episode_length": self.max_episode_length, "pass_time_out": self._pass_time}
+        tr = self._track
+        motion = {"lib": self._motion_lib, "ids": self._sampled_motion_ids, "offset": self._global_offset, "traj_dt": self._traj_sample_timestep,
+                  "track_rb": tr["rb_records"], "track_dof_pos": tr["dof_pos"], "track_dof_vel": tr["dof_vel"]}
+        return clock, motion
 
     # ------------------------------------------------------------------ sizes / spaces
     def get_obs_size(self):
@@ -251,7 +256,7 @@ class HumanoidIm:
         self.post_physics_step()
 
     def _action_to_pd_targets(self, action):
-        return self._pd_action_offset + self._pd_action_scale * action           # humanoid.py:1392-1394
+        return torch.addcmul(self._pd_action_offset, self._pd_action_scale, action)   # offset + scale * action, humanoid.py:1392-1394
 
     def pre_physics_step(self, actions):
         self.actions = actions
@@ -268,12 +273,17 @@ class HumanoidIm:
             t = self.progress_buf * self.dt + self._motion_start_times + self._motion_start_times_offset
             torch.ge(t, self._motion_len_env, out=self._pass_time)
 
-    def _im_step(self, what, env_ids=None, env_mask=None, ref_next=None):
+    def _im_step(self, what, env_ids=None, env_mask=None, ref_next=None, inc=0):
         need_now = what & (PULSE_IM_REWARD | PULSE_IM_RESET)
+        if self._use_motion_lib:
+            clock, motion = self._motion_kwargs(inc)
+            ref_now = ref_next = None
+        else:
+            clock = motion = None
+            ref_now = self._ref_now() if need_now else None
+            ref_next = (ref_next if ref_next is not None else self._ref_next()) if what & PULSE_IM_TASK_OBS else None
         return ops.im_step(
-            self.sim.rigid_body_state, what=what,
-            ref_now=self._ref_now() if need_now else None,
-            ref_next=(ref_next if ref_next is not None else self._ref_next()) if what & PULSE_IM_TASK_OBS else None,
+            self.sim.rigid_body_state, what=what, ref_now=ref_now, ref_next=ref_next,
             time_steps=self._num_traj_samples, dof_force=self.sim.dof_force, dof_vel=self.sim.dof_vel,
             progress=self.progress_buf, pass_time=self._pass_time, cycle_counter=self._cycle_counter,
             track_ids=self._track_bodies_id, reset_ids=self._reset_bodies_id, term_dist=self._termination_distances,
@@ -281,7 +291,7 @@ class HumanoidIm:
             local_root_obs=self._local_root_obs, root_height_obs=self._root_height_obs, specs=self.reward_specs,
             power_coef=self.power_coefficient, power_reward=self.power_reward, env_ids=env_ids, env_mask=env_mask,
             obs=self._obs_store, obs_cols=self.obs_pitch, rew=self.rew_buf, rew_raw=self.reward_raw,
-            reset=self.reset_buf, terminate=self._terminate_buf)
+            reset=self.reset_buf, terminate=self._terminate_buf, clock=clock, motion=motion)
 
     def _compute_reward(self, actions=None):
         self._im_step(PULSE_IM_REWARD)
@@ -294,10 +304,14 @@ class HumanoidIm:
         self._im_step(PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, env_ids=env_ids, env_mask=env_mask, ref_next=ref_next)
 
     def post_physics_step(self):
-        self.progress_buf += 1
-        self._update_pass_time()
-        # reward -> reset -> observations (humanoid.py:1325-1328), fused into one launch
-        self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
+        # progress += 1, pass_time, reward -> reset -> observations (humanoid.py:1316-1328): one launch.  With the motion library
+        # the increment, the time-out test and the reference blend (t and t+1) all happen inside it.
+        if self._use_motion_lib:
+            self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, inc=1)
+        else:
+            self.progress_buf += 1
+            self._update_pass_time()
+            self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
         self.extras["terminate"] = self._terminate_buf
         self.extras["reward_raw"] = self.reward_raw
         if self._enable_amp_obs:                      # HumanoidAMP.post_physics_step (humanoid_amp.py:194-210)
@@ -325,21 +339,26 @@ class HumanoidIm:
     def reset_masked(self, mask):
         """Sync-free form of reset(env_ids): mask is a (N,) bool device tensor.
         _reset_envs (humanoid.py:541-560): state init, buffer clears, observation recompute."""
-        keep = ~mask
         if self._use_motion_lib:
-            # _reset_envs -> _sample_ref_state (humanoid_im.py:966-986): new start time, state := reference state at that time
+            # _reset_envs -> _sample_ref_state (humanoid_im.py:966-986) for the masked envs in ONE launch: new start time
+            # (phase * motion length), clock and reset / terminate flags cleared, simulator state := reference state there
             if self._state_init_random:
-                new_t = self._motion_lib.sample_time(self._sampled_motion_ids, generator=self._clock_gen)
-            else:
-                new_t = torch.zeros_like(self._motion_start_times)
-            torch.where(mask, new_t, self._motion_start_times, out=self._motion_start_times)
-            self.progress_buf.mul_(keep)
-            self.sim.set_env_states_masked(mask, self._ref_query("reset", 0, with_records=True))
-            ref_next = self._ref_next()
-        else:
-            self.sim.set_env_states_masked(mask)
-            self.progress_buf.mul_(keep)
-            ref_next = self._motion_lib.next_after_reset()
+                self._reset_phase.uniform_(0.0, 1.0, generator=self._clock_gen)           # MotionLibBase.sample_time's torch.rand
+            sim = self.sim
+            self._motion_lib.query(self._sampled_motion_ids, offset=self._global_offset, dt=self.dt, start_offsets=self._motion_start_times_offset,
+                                   out={"rb_records": sim.rigid_body_state, "dof_pos": sim.dof_pos, "dof_vel": sim.dof_vel},
+                                   fields=("rb_records", "dof_pos", "dof_vel"),
+                                   reset={"mask": mask, "phase": self._reset_phase if self._state_init_random else None,
+                                          "start_times": self._motion_start_times, "progress": self.progress_buf,
+                                          "clear0": self.reset_buf, "clear1": self._terminate_buf})
+            self._compute_observations(env_mask=mask)
+            if self._enable_amp_obs:
+                self._init_amp_obs(mask)
+            return
+        keep = ~mask
+        self.sim.set_env_states_masked(mask)
+        self.progress_buf.mul_(keep)
+        ref_next = self._motion_lib.next_after_reset()
         self.reset_buf.mul_(keep)
         self._terminate_buf.mul_(keep)
         self._compute_observations(env_mask=mask, ref_next=ref_next)

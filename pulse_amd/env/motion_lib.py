@@ -125,8 +125,8 @@ class MotionLib:
         return ((phase * motion_len) / curr_fps).long() * curr_fps
 
     # ---- the hot query
-    def _tables(self, a):
-        t = a.tab
+    def fill_tables(self, t):
+        """Fill a pulse_motion_tables struct (by reference) with this library's device pointers."""
         t.frames, t.frame_stride, t.total_frames, t.num_bodies = self.frames.data_ptr(), self.frame_stride, self.frames.shape[0], self.num_bodies
         o = self.offsets
         t.off_gts, t.off_grs, t.off_lrs, t.off_gvs, t.off_gavs, t.off_dvs = o["gts"], o["grs"], o["lrs"], o["gvs"], o["gavs"], o["dvs"]
@@ -134,7 +134,8 @@ class MotionLib:
         t.motion_num_frames, t.length_starts, t.num_motions = self._motion_num_frames.data_ptr(), self.length_starts.data_ptr(), self._num_motions
 
     def query(self, motion_ids, motion_times=None, offset=None, *, progress=None, step_shift=0, dt=0.0, start_times=None,
-              start_offsets=None, time_steps=1, traj_dt=0.0, out=None, root_only=False, with_frames=False, with_records=False):
+              start_offsets=None, time_steps=1, traj_dt=0.0, out=None, root_only=False, with_frames=False, with_records=False,
+              reset=None, fields=None):
         """One launch.  Times either given (``motion_times``) or built in-kernel from the episode clock
         ((progress + step_shift) * dt + start_times + start_offsets).  ``out``: dict of preallocated outputs to reuse."""
         lib = _lib.load()
@@ -160,9 +161,26 @@ class MotionLib:
             return t
 
         a = MotionStateArgs()
-        self._tables(a)
+        self.fill_tables(a.tab)
         a.n, a.motion_ids = n, ids.data_ptr()
-        if motion_times is not None:
+        if reset is not None:
+            # reset mode (include/pulse_hip.h 2b): masked envs get a new start time and their reference state in one launch
+            m = reset["mask"]
+            m = (m.view(torch.uint8) if m.dtype == torch.bool else m).contiguous()
+            keep.append(m)
+            a.reset_mask, a.step_shift, a.dt = m.data_ptr(), int(step_shift), float(dt)
+            ph = f32(reset.get("phase"), "reset.phase", (ne,))
+            a.reset_phase = ph.data_ptr() if ph is not None else None
+            for field, key, dt_ in (("reset_start_times", "start_times", torch.float32), ("reset_progress", "progress", torch.int64),
+                                    ("reset_clear0", "clear0", torch.int64), ("reset_clear1", "clear1", torch.int64)):
+                t_ = reset.get(key)
+                if t_ is not None:
+                    if t_.dtype != dt_ or not t_.is_contiguous() or t_.numel() != ne:
+                        raise TypeError(f"reset.{key}: contiguous {dt_} tensor of {ne} elements expected")
+                    setattr(a, field, t_.data_ptr())
+            so = f32(start_offsets, "start_offsets", (ne,))
+            a.start_offsets = so.data_ptr() if so is not None else None
+        elif motion_times is not None:
             a.motion_times = f32(motion_times, "motion_times", (n,)).data_ptr()
         else:
             if progress is None or progress.dtype != torch.int64:
@@ -182,12 +200,16 @@ class MotionLib:
             a.root_only = 1
             a.root_pos = e("root_pos", n, 3).data_ptr()
         else:
-            a.rg_pos, a.rb_rot = e("rg_pos", n, j, 3).data_ptr(), e("rb_rot", n, j, 4).data_ptr()
-            a.body_vel, a.body_ang_vel = e("body_vel", n, j, 3).data_ptr(), e("body_ang_vel", n, j, 3).data_ptr()
-            a.dof_pos, a.dof_vel = e("dof_pos", n, nd).data_ptr(), e("dof_vel", n, nd).data_ptr()
-        if with_records and not root_only:
-            rec = e("rb_records", n, j, 13)
-            a.rb_records, a.rb_query_stride = rec.data_ptr(), rec.stride(0)
+            shapes = {"rg_pos": (n, j, 3), "rb_rot": (n, j, 4), "body_vel": (n, j, 3), "body_ang_vel": (n, j, 3), "dof_pos": (n, nd),
+                      "dof_vel": (n, nd), "rb_records": (n, j, 13)}
+            want = fields if fields is not None else ("rg_pos", "rb_rot", "body_vel", "body_ang_vel", "dof_pos", "dof_vel") + (("rb_records",) if with_records else ())
+            for k in want:
+                t_ = e(k, *shapes[k])
+                if tuple(t_.shape) != shapes[k] or t_.dtype != torch.float32 or not t_.is_contiguous():
+                    raise ValueError(f"out[{k}]: contiguous float32 {shapes[k]} expected")
+                setattr(a, k, t_.data_ptr())
+                if k == "rb_records":
+                    a.rb_query_stride = t_.stride(0)
         if with_frames:
             a.frame_idx0, a.frame_idx1 = e("frame_idx0", n, dtype=torch.int64).data_ptr(), e("frame_idx1", n, dtype=torch.int64).data_ptr()
             a.blend = e("blend", n).data_ptr()

@@ -11,6 +11,7 @@ that "physics" overwrites every step, dof force / velocity tensors, a PD-target 
 """
 import torch
 
+from .. import kernels as K
 from .. import synthetic as syn
 
 
@@ -193,14 +194,9 @@ class KinematicSim:
 
     def simulate_and_refresh(self):
         self.frame = (self.frame + 1) % self.bank_frames
-        f, t = self.frame, self._target
-        rb = self.rigid_body_state
-        torch.add(t["rb_records"], self.bank["rb"][f], out=rb)
-        q = rb[..., 3:7]
-        q.div_(q.norm(dim=-1, keepdim=True))
-        torch.add(t["dof_pos"], self.bank["dof_pos"][f], out=self.dof_pos)
-        torch.add(t["dof_vel"], self.bank["dof_vel"][f], out=self.dof_vel)
-        self.dof_force.copy_(self.bank["dof_force"][f])
+        f, t, b = self.frame, self._target, self.bank
+        K.kinematic_sim_step(t["rb_records"], b["rb"][f], self.rigid_body_state, t["dof_pos"], b["dof_pos"][f], self.dof_pos,
+                             t["dof_vel"], b["dof_vel"][f], self.dof_vel, b["dof_force"][f], self.dof_force)      # one launch
 
     def set_env_states_masked(self, mask, state):
         torch.where(mask[:, None, None], state["rb_records"], self.rigid_body_state, out=self.rigid_body_state)

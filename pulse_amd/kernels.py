@@ -201,3 +201,28 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9,
                                            eps, weight_decay, int(step), float(max_norm), _p(sqnorm_partials),
                                            sqnorm_partials.numel() if sqnorm_partials is not None else 0, _p(grad_norm_out),
                                            _stream()), "pulse_adam_step")
+
+
+def rollout_record(*, rewards, dones, terminate, value_raw, value_stride, value_mean, value_var, value_eps, buf_rewards, buf_next_values,
+                   buf_dones, env_stride, current_rewards, current_lengths, meter_rewards, meter_lengths, meter_max_size, done_mask,
+                   reward_scale=1.0, reward_shift=0.0):
+    """play_steps bookkeeping of one rollout step in one launch (include/pulse_hip.h section 2c)."""
+    a = _lib.RolloutRecordArgs()
+    a.num_envs = rewards.numel()
+    a.rewards, a.reward_scale, a.reward_shift = _p(rewards), float(reward_scale), float(reward_shift)
+    a.dones, a.terminate = _p(dones), _p(terminate)
+    a.value_raw, a.value_stride = _p(value_raw), int(value_stride)
+    a.value_mean, a.value_var, a.value_eps = _p(value_mean), _p(value_var), float(value_eps)
+    a.buf_rewards, a.buf_next_values, a.buf_dones, a.env_stride = _p(buf_rewards), _p(buf_next_values), _p(buf_dones), int(env_stride)
+    a.current_rewards, a.current_lengths = _p(current_rewards), _p(current_lengths)
+    a.meter_rewards, a.meter_lengths, a.meter_max_size = _p(meter_rewards), _p(meter_lengths), float(meter_max_size)
+    a.done_mask = _p(done_mask)
+    _lib.check(_lib.load().pulse_rollout_record(ctypes.byref(a), _stream()), "pulse_rollout_record")
+
+
+def kinematic_sim_step(target_rb, noise_rb, rb, target_dof_pos, noise_dof_pos, dof_pos, target_dof_vel, noise_dof_vel, dof_vel, force_src,
+                       dof_force):
+    n, j = rb.shape[0], rb.shape[1]
+    _lib.check(_lib.load().pulse_kinematic_sim_step(_p(target_rb), _p(noise_rb), _p(rb), n, j, _p(target_dof_pos), _p(noise_dof_pos),
+                                                    _p(dof_pos), _p(target_dof_vel), _p(noise_dof_vel), _p(dof_vel), _p(force_src),
+                                                    _p(dof_force), dof_pos.shape[1], _stream()), "pulse_kinematic_sim_step")

@@ -170,6 +170,10 @@ class CommonAgent:
         self.current_rewards = torch.zeros(self.num_actors, self.value_size, device=self.ppo_device)
         self.current_lengths = torch.zeros(self.num_actors, device=self.ppo_device)
         self.dones = torch.ones(self.num_actors, dtype=torch.uint8, device=self.ppo_device)
+        self._done_mask = torch.zeros(self.num_actors, dtype=torch.bool, device=self.ppo_device)
+        sh = self.rewards_shaper
+        if self.value_size != 1 or sh.min_val != -float("inf") or sh.max_val != float("inf"):
+            raise NotImplementedError("rollout bookkeeping kernel: value_size 1, reward shaper without clamping (every shipped config)")
         self.update_list = ["actions", "neglogpacs", "values", "mus", "sigmas"]
         self.tensor_list = self.update_list + ["obses", "states", "dones"] + ["next_obses"]
         self._tensors_ready = True
@@ -252,13 +256,19 @@ class CommonAgent:
         return {"actions": td["actions"][s], "neglogpacs": td["neglogpacs"][s], "values": td["values"][s], "mus": td["mus"][s],
                 "sigmas": td["sigmas"][s], "rnn_states": None}
 
-    def _eval_critic(self, obs_dict, out=None):
+    def _eval_critic_raw(self, obs_dict):
+        """Normalise + critic MLP; the (still normalised) value sits in ws['val']."""
         n = self.num_actors
         net = self.model
         ws = net.workspace(n, train=False)
         net.eval()
         self._preproc_obs(obs_dict["obs"], ws, n)
         net.eval_critic(ws, n)
+        return ws
+
+    def _eval_critic(self, obs_dict, out=None):
+        n = self.num_actors
+        ws = self._eval_critic_raw(obs_dict)
         value = torch.empty(n, 1, device=self.ppo_device) if out is None else out
         if self.normalize_value:
             self.value_mean_std.forward(ws["val"], unnorm=True, out=value, out_cols=1)
@@ -278,24 +288,21 @@ class CommonAgent:
             for k in self.update_list:
                 eb.update_data(k, n, res_dict[k])
             self.obs, rewards, self.dones, infos = self.env_step(self._action_for_env(res_dict))
-            shaped_rewards = self.rewards_shaper(rewards)
-            eb.update_data("rewards", n, shaped_rewards)
             eb.update_data("next_obses", n, self.obs["obs"])
-            eb.update_data("dones", n, self.dones)
             self._after_env_step(n, infos)
-            terminated = infos["terminate"].float().unsqueeze(-1)
-            next_vals = self._eval_critic(self.obs)
-            next_vals *= (1.0 - terminated)
-            eb.update_data("next_values", n, next_vals)
-
-            self.current_rewards += rewards
-            self.current_lengths += 1
-            done_mask = self.dones != 0
-            self.game_rewards.update_masked(self.current_rewards, done_mask)
-            self.game_lengths.update_masked(self.current_lengths.unsqueeze(1), done_mask)
-            not_dones = 1.0 - self.dones.float()
-            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
-            self.current_lengths = self.current_lengths * not_dones
+            # critic on the next observation, then ONE launch for the rest of the step's bookkeeping (:318-347):
+            # shaped reward / dones / bootstrap value (zeroed at terminations) into slot n, episode accumulators, the two
+            # AverageMeters, and the done mask that drives the next masked reset
+            ws = self._eval_critic_raw(self.obs)
+            vm = self.value_mean_std
+            K.rollout_record(rewards=rewards, dones=self.dones, terminate=infos["terminate"], value_raw=ws["val"],
+                             value_stride=ws["val"].stride(0), value_mean=vm.running_mean if vm is not None else None,
+                             value_var=vm.running_var if vm is not None else None, value_eps=vm.epsilon if vm is not None else 0.0,
+                             buf_rewards=eb.phys["rewards"][:, n], buf_next_values=eb.phys["next_values"][:, n], buf_dones=eb.phys["dones"][:, n],
+                             env_stride=self.horizon_length, current_rewards=self.current_rewards, current_lengths=self.current_lengths,
+                             meter_rewards=self.game_rewards.state, meter_lengths=self.game_lengths.state, meter_max_size=self.games_to_track,
+                             done_mask=self._done_mask, reward_scale=self.rewards_shaper.scale_value, reward_shift=self.rewards_shaper.shift_value)
+            done_mask = self._done_mask
         self._pending_done_mask = done_mask
 
         td = eb.tensor_dict

@@ -169,12 +169,16 @@ class AMPDataset:
 
 
 class AverageMeter:
-    """torch_ext.AverageMeter with a masked, sync-free update."""
+    """torch_ext.AverageMeter (rl_games) with device-resident state ``[mean, current_size]`` so the
+    rollout's per-step update runs inside pulse_rollout_record; ``update_masked`` is the same update for other callers."""
 
     def __init__(self, in_shape, max_size, device):
+        if tuple(in_shape) != (1,):
+            raise NotImplementedError("scalar meters (value_size 1) are what the hot path tracks")
         self.max_size = max_size
-        self.mean = torch.zeros(in_shape, dtype=torch.float32, device=device)
-        self.current_size = torch.zeros((), dtype=torch.float32, device=device)
+        self.state = torch.zeros(2, dtype=torch.float32, device=device)
+        self.mean = self.state[0:1]
+        self.current_size = self.state[1]
 
     def update_masked(self, values, mask):
         """values (N, ...) / mask (N,) bool: same as update(values[mask]) without materialising it."""
@@ -187,8 +191,8 @@ class AverageMeter:
         size_sum = old_size + size_c
         upd = (self.mean * old_size + new_mean * size_c) / torch.clamp(size_sum, min=1.0)
         has = size > 0
-        self.mean = torch.where(has, upd, self.mean)
-        self.current_size = torch.where(has, size_sum, self.current_size)
+        self.mean.copy_(torch.where(has, upd, self.mean))
+        self.current_size.copy_(torch.where(has, size_sum, self.current_size))
 
     def clear(self):
         self.current_size.zero_()

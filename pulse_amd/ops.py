@@ -189,8 +189,11 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
             reset_use_mean=False, full_body_reward=True, obs_version=6, local_root_obs=True,
             root_height_obs=True, specs=None, power_coef=0.0005, power_reward=True,
             env_ids=None, env_mask=None, obs=None, obs_cols=None, rew=None, rew_raw=None, reset=None,
-            terminate=None):
-    """Low-level entry: one launch of pulse_im_step.  ``rb`` is (N, J, 13) with unit inner strides
+            terminate=None, clock=None, motion=None):
+    """``clock``: dict(progress_rw, inc, dt, start_times, start_offsets, motion_len, cycle_motion, max_episode_length,
+    pass_time_out) -- the episode clock advanced / evaluated in-kernel.  ``motion``: dict(lib, ids, offset, traj_dt, track_rb,
+    track_dof_pos, track_dof_vel) -- the reference evaluated in-kernel from a MotionLib instead of ref_now / ref_next.
+    Low-level entry: one launch of pulse_im_step.  ``rb`` is (N, J, 13) with unit inner strides
     (the env stride may be larger).  ref_* are dicts with keys pos/rot/vel/ang.  Outputs that are
     not supplied are allocated.  Returns dict(obs, rew, rew_raw, reset, terminate)."""
     lib = _lib.load()
@@ -273,6 +276,24 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         terminate = torch.empty(n, dtype=torch.int64, device=dev) if terminate is None else _dev(terminate, "terminate", torch.int64)
         a.reset, a.terminate = reset.data_ptr(), terminate.data_ptr()
         out["reset"], out["terminate"] = reset, terminate
+    if clock is not None:
+        a.progress_rw, a.progress_inc = P(clock.get("progress_rw"), "clock.progress_rw", torch.int64), int(clock.get("inc", 0))
+        a.clock_dt = float(clock.get("dt", 0.0))
+        a.clock_start_times, a.clock_start_offsets = P(clock.get("start_times"), "clock.start_times"), P(clock.get("start_offsets"), "clock.start_offsets")
+        a.clock_motion_len = P(clock.get("motion_len"), "clock.motion_len")
+        a.cycle_motion, a.max_episode_length = int(bool(clock.get("cycle_motion", False))), int(clock.get("max_episode_length", 0))
+        pto = clock.get("pass_time_out")
+        if pto is not None:
+            a.pass_time_out = P(pto.view(torch.uint8) if pto.dtype == torch.bool else pto, "clock.pass_time_out", torch.uint8)
+    if motion is not None:
+        a.use_motion = 1
+        motion["lib"].fill_tables(a.motion)
+        a.motion_ids, a.motion_offset = P(motion["ids"], "motion.ids", torch.int64), P(motion.get("offset"), "motion.offset")
+        a.traj_dt = float(motion.get("traj_dt", 0.0))
+        trb = motion.get("track_rb")
+        if trb is not None:
+            a.track_rb, a.track_rb_stride = P(trb, "motion.track_rb"), trb.stride(0)
+        a.track_dof_pos, a.track_dof_vel = P(motion.get("track_dof_pos"), "motion.track_dof_pos"), P(motion.get("track_dof_vel"), "motion.track_dof_vel")
     _lib.check(lib.pulse_im_step(ctypes.byref(a), _stream()), "pulse_im_step")
     return out
 

@@ -53,3 +53,4 @@ def test_struct_layout_matches_c():
     assert ctypes.sizeof(_lib.AmpObsArgs) == _lib.load().pulse_sizeof_amp_obs_args()
     assert ctypes.sizeof(_lib.PpoLossArgs) == _lib.load().pulse_sizeof_ppo_loss_args()
     assert ctypes.sizeof(_lib.MotionStateArgs) == _lib.load().pulse_sizeof_motion_state_args()
+    assert ctypes.sizeof(_lib.RolloutRecordArgs) == _lib.load().pulse_sizeof_rollout_record_args()

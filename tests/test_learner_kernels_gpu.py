@@ -339,3 +339,53 @@ def test_clip_and_adam_vs_torch(dev, max_norm):
         if max_norm > 0:
             np.testing.assert_allclose(norm_out.item(), ref_norm.item(), rtol=1e-5)          # grad-norm within 1e-4 (north_star)
         np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), atol=2e-7, rtol=1e-6)
+
+
+def test_rollout_record_matches_reference_sequence(dev):
+    """pulse_rollout_record vs the op-by-op sequence of play_steps (amp_agent.py:372-412) with rl_games' AverageMeter."""
+    from pulse_amd import kernels as K
+    torch.manual_seed(5)
+    n, t, slot, max_size = 1000, 7, 3, 100
+    cur_r, cur_l = torch.randn(n).abs() * 5, torch.randint(1, 200, (n,)).float()
+    meter_r, meter_l = torch.tensor([1.5, 40.0]), torch.tensor([120.0, 40.0])
+    vmean, vvar = torch.tensor([0.3], dtype=torch.float64), torch.tensor([2.5], dtype=torch.float64)
+    d = {k: v.to(dev) for k, v in dict(cur_r=cur_r.clone(), cur_l=cur_l.clone(), meter_r=meter_r.clone(), meter_l=meter_l.clone()).items()}
+    buf_r, buf_nv = torch.zeros(n, t, 1, device=dev), torch.zeros(n, t, 1, device=dev)
+    buf_d = torch.zeros(n, t, dtype=torch.uint8, device=dev)
+    mask = torch.zeros(n, dtype=torch.bool, device=dev)
+    ref_r, ref_l = [1.5, 40.0], [120.0, 40.0]
+    for step in range(4):
+        rew = torch.rand(n)
+        dones = (torch.rand(n) < (0.0 if step == 2 else 0.3)).long()            # step 2: nobody finishes
+        if step == 3:
+            dones[:] = 1                                                          # more finished episodes than the window holds
+        term = dones * (torch.rand(n) < 0.5).long()
+        val = torch.randn(n, 4) * 3
+        K.rollout_record(rewards=rew.to(dev), dones=dones.to(dev), terminate=term.to(dev), value_raw=val.to(dev), value_stride=4,
+                         value_mean=vmean.to(dev), value_var=vvar.to(dev), value_eps=1e-5, buf_rewards=buf_r[:, slot], buf_next_values=buf_nv[:, slot],
+                         buf_dones=buf_d[:, slot], env_stride=t, current_rewards=d["cur_r"], current_lengths=d["cur_l"], meter_rewards=d["meter_r"],
+                         meter_lengths=d["meter_l"], meter_max_size=max_size, done_mask=mask)
+        # reference sequence on the CPU
+        nv = (torch.sqrt(vvar.float() + 1e-5) * torch.clamp(val[:, 0], -5, 5) + vmean.float()) * (1.0 - term.float())
+        cur_r = cur_r + rew
+        cur_l = cur_l + 1
+        idx = dones.nonzero().flatten()
+        for st, vals in ((ref_r, cur_r[idx]), (ref_l, cur_l[idx])):
+            size = vals.shape[0]
+            if size == 0:
+                continue
+            new_mean = vals.float().mean().item()
+            size = float(np.clip(size, 0, max_size))
+            old = min(max_size - size, st[1])
+            st[0], st[1] = (st[0] * old + new_mean * size) / (old + size), old + size
+        nd = 1.0 - dones.float()
+        cur_r, cur_l = cur_r * nd, cur_l * nd
+        np.testing.assert_array_equal(buf_r[:, slot, 0].cpu().numpy(), rew.numpy())
+        np.testing.assert_array_equal(buf_d[:, slot].cpu().numpy(), dones.numpy().astype(np.uint8))
+        np.testing.assert_allclose(buf_nv[:, slot, 0].cpu().numpy(), nv.numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(d["cur_r"].cpu().numpy(), cur_r.numpy())
+        np.testing.assert_array_equal(d["cur_l"].cpu().numpy(), cur_l.numpy())
+        np.testing.assert_array_equal(mask.cpu().numpy(), dones.numpy() != 0)
+        np.testing.assert_allclose(d["meter_r"].cpu().numpy(), ref_r, rtol=2e-5)
+        np.testing.assert_allclose(d["meter_l"].cpu().numpy(), ref_l, rtol=2e-5)
+    assert buf_r[:, :slot].abs().sum() == 0 and buf_r[:, slot + 1:].abs().sum() == 0      # only slot `slot` was written

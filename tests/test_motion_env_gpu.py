@@ -92,3 +92,70 @@ def test_agent_epoch_on_motion_lib_env(dev):
     raw = ag.vec_env.env.task.reward_raw
     assert (raw[:, :4] > 0.02).all()                          # the tracked humanoid earns imitation reward on every term
     assert ag.experience_buffer.phys["dones"].sum() > 0
+
+
+def test_in_kernel_reference_equals_array_reference(dev):
+    """pulse_im_step blending the reference from the packed library == the same launch fed by pulse_motion_state's arrays
+    (bit for bit: same device functions), and the in-kernel clock == progress += 1 / pass_time done outside."""
+    from pulse_amd import ops
+    from pulse_amd._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS
+    n = 131
+    env, _ = configs.make_env(n, 8, dev, seed=9, reference="motion_lib", env_overrides={"fut_tracks": True, "numTrajSamples": 2})
+    task = env.task
+    env.reset()
+    for _ in range(3):
+        env.step(torch.zeros(n, 69, device=dev))
+        env.reset(torch.nonzero(task.reset_buf).flatten())
+    task.sim.simulate_and_refresh()
+    lib = task._motion_lib
+    what = PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS
+    prog0 = task.progress_buf.clone()
+    # (a) arrays path: advance the clock by hand, query the library, feed the arrays
+    prog = prog0 + 1
+    t = prog * task.dt + task._motion_start_times + task._motion_start_times_offset
+    pass_time = t >= task._motion_len_env
+    kw = dict(offset=task._global_offset, progress=prog, dt=task.dt, start_times=task._motion_start_times, start_offsets=task._motion_start_times_offset)
+    now = lib.query(task._sampled_motion_ids, step_shift=0, **kw)
+    nxt = lib.query(task._sampled_motion_ids, step_shift=1, time_steps=2, traj_dt=task._traj_sample_timestep, **kw)
+    ref = lambda r: {"pos": r["rg_pos"], "rot": r["rb_rot"], "vel": r["body_vel"], "ang": r["body_ang_vel"]}
+    common = dict(time_steps=2, dof_force=task.sim.dof_force, dof_vel=task.sim.dof_vel, cycle_counter=task._cycle_counter,
+                  track_ids=task._track_bodies_id, reset_ids=task._reset_bodies_id, term_dist=task._termination_distances,
+                  specs=task.reward_specs, power_coef=task.power_coefficient, power_reward=task.power_reward)
+    a = ops.im_step(task.sim.rigid_body_state, what=what, ref_now=ref(now), ref_next=ref(nxt), progress=prog, pass_time=pass_time, **common)
+    # (b) fused path
+    task.progress_buf.copy_(prog0)
+    clock, motion = task._motion_kwargs(inc=1)
+    b = ops.im_step(task.sim.rigid_body_state, what=what, progress=task.progress_buf, clock=clock, motion=motion, **common)
+    for k in ("obs", "rew", "rew_raw", "reset", "terminate"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(task.progress_buf, prog) and torch.equal(task._pass_time, pass_time)
+    one = lib.query(task._sampled_motion_ids, step_shift=1, with_records=True, **kw)
+    assert torch.equal(task._track["rb_records"], one["rb_records"]) and torch.equal(task._track["dof_pos"], one["dof_pos"])
+    assert torch.equal(task._track["dof_vel"], one["dof_vel"])
+
+
+def test_reset_mode_matches_separate_ops(dev):
+    n = 77
+    env, _ = configs.make_env(n, 8, dev, seed=10, reference="motion_lib")
+    task = env.task
+    env.reset()
+    lib, sim = task._motion_lib, task.sim
+    for _ in range(2):
+        env.step(torch.zeros(n, 69, device=dev))
+    mask = torch.rand(n, device=dev) < 0.4
+    before = {k: v.clone() for k, v in dict(rb=sim.rigid_body_state, dp=sim.dof_pos, dv=sim.dof_vel, st=task._motion_start_times,
+                                            pg=task.progress_buf).items()}
+    task.reset_buf.fill_(1)
+    task._terminate_buf.fill_(1)
+    state = task._clock_gen.get_state()
+    task.reset_masked(mask)
+    task._clock_gen.set_state(state)
+    phase = torch.zeros(n, device=dev).uniform_(0.0, 1.0, generator=task._clock_gen)
+    st = torch.where(mask, phase * task._motion_len_env, before["st"])
+    assert torch.equal(task._motion_start_times, st)
+    assert torch.equal(task.progress_buf, before["pg"] * (~mask))
+    assert torch.equal(task.reset_buf, (~mask).long()) and torch.equal(task._terminate_buf, (~mask).long())
+    want = lib.query(task._sampled_motion_ids, st, task._global_offset, with_records=True)
+    assert torch.equal(sim.rigid_body_state, torch.where(mask[:, None, None], want["rb_records"], before["rb"]))
+    assert torch.equal(sim.dof_pos, torch.where(mask[:, None], want["dof_pos"], before["dp"]))
+    assert torch.equal(sim.dof_vel, torch.where(mask[:, None], want["dof_vel"], before["dv"]))

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 6
+#define PULSE_ABI_VERSION 7
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -337,6 +337,10 @@ typedef struct pulse_gemm_desc {
     int64_t split_stride;
     int32_t activation;   /* PULSE_ACT_* */
     int32_t epilogue;     /* PULSE_EPI_* */
+    /* optional, (OUT, OUT) layouts only (the dW pass, A = dY stored [batch row][out feature]):
+       rowsum[z * stride_rowsum + s * split_stride + m] = sum over slab s of A(k, m) -- the BIAS gradient, taken from the
+       A fragments the kernel already holds, so no separate column-sum pass over dY is needed. */
+    float* rowsum; int64_t stride_rowsum;
 } pulse_gemm_desc;
 
 int pulse_sizeof_gemm_desc(void);

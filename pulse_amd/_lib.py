@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -98,6 +98,7 @@ class GemmDesc(Structure):
         ("stride_a", c_int64), ("stride_b", c_int64), ("stride_c", c_int64), ("stride_c2", c_int64),
         ("stride_bias", c_int64), ("stride_aux", c_int64),
         ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
+        ("rowsum", c_void_p), ("stride_rowsum", c_int64),
     ]
 
 

@@ -47,6 +47,7 @@ struct GemmArgs {
     int epi;                                   // 0 bias+act, 1 relu-grad mask, 2 silu-grad
     int tiles_m, tiles_n;
     int vec_epi;                               // all epilogue pointers / pitches are 16-byte aligned
+    float* rowsum; long long sRowsum;          // <MC,MC> only: per-slab sums over k of A(k, m)  (bias gradient)
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -195,6 +196,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
 
     float4 ra[4], rb[4];
     float4 fa[2][2], fb[2][2];                                   // two fragment sets: one feeding MFMAs, one in flight from LDS
+    float rsum[2] = {0.f, 0.f};
     const int nkt = (kend - kbeg + BK - 1) / BK;
     const int arow = wm * 64 + l31, brow = wn * 64 + l31;
 
@@ -229,6 +231,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
             const int grp = p >> 3, set = grp & 1, q = p & 7, i = q >> 2, c = q & 3;
+            if constexpr (!AKC) {                  // dW pass: the A fragments are dY -- their k-sums are the bias gradient
+                if (q == 0) {
+                    rsum[0] += (fa[set][0].x + fa[set][0].y) + (fa[set][0].z + fa[set][0].w);
+                    rsum[1] += (fa[set][1].x + fa[set][1].y) + (fa[set][1].z + fa[set][1].w);
+                }
+            }
             acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[set][i], c), comp(fb[set][0], c), acc[i][0], 0, 0, 0);
             acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[set][i], c), comp(fb[set][1], c), acc[i][1], 0, 0, 0);
             if (p < 4) frag_unit(1, p, a_s, b_s, 8);
@@ -272,6 +280,19 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     }
     for (int t = 0; t + 1 < nkt; ++t) tile(std::false_type{}, t);
     if (nkt > 0) tile(std::true_type{}, nkt - 1);
+    if constexpr (!AKC) {
+        if (g.rowsum && tn == 0 && wn == 0) {
+            // this lane summed the k-offsets of its half; the other half's lane holds the rest of the same row
+            const float r0 = rsum[0] + __shfl_xor(rsum[0], 32, 64);
+            const float r1 = rsum[1] + __shfl_xor(rsum[1], 32, 64);
+            if (half == 0) {
+                float* rs = g.rowsum + bz * g.sRowsum + sp * g.sSplit;
+                const int row = m0 + wm * 64 + l31;
+                if (row < g.M) rs[row] = r0;
+                if (row + 32 < g.M) rs[row + 32] = r1;
+            }
+        }
+    }
     __syncthreads();                                              // the epilogue reuses the staging buffers
 #undef PULSE_LOAD_FRAGS
 #undef PULSE_MFMA_GROUP
@@ -477,6 +498,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     PULSE_REQUIRE(d->ldc >= d->N, "pulse_gemm_f32: ldc too small");
     PULSE_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2 && d->activation >= 0 && d->activation <= 2, "pulse_gemm_f32: bad epilogue / activation");
     PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr, "pulse_gemm_f32: gradient epilogue needs aux");
+    PULSE_REQUIRE(d->rowsum == nullptr || (!akc && !bkc), "pulse_gemm_f32: rowsum needs the (OUT, OUT) layouts (dW pass)");
     PULSE_REQUIRE(d->split_k == 1 || (d->epilogue == 0 && d->activation == 0 && d->bias == nullptr),
                   "pulse_gemm_f32: split-K slabs carry no epilogue");
 
@@ -491,6 +513,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.kchunk = kchunk > 0 ? kchunk : BK;
     g.sSplit = d->split_stride;
     g.act = d->activation; g.epi = d->epilogue;
+    g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     auto al16 = [](const void* p, long long ld, long long st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0 && (st % 4) == 0; };
     g.vec_epi = al16(d->C, d->ldc, d->stride_c) && (d->split_stride % 4) == 0 && (!d->aux || al16(d->aux, d->ldaux, d->stride_aux)) &&

@@ -54,7 +54,8 @@ PROFILER = GemmProfiler()
 def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, bias=None,
                    activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
                    stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
-                   a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None):
+                   a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None, rowsum=None, rowsum_off=0,
+                   stride_rowsum=0):
     """Build (descriptor, algorithmic FLOPs, variant tag) once; launch many times with launch_gemm."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -69,6 +70,8 @@ def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG,
     d.stride_a, d.stride_b, d.stride_c, d.stride_c2 = stride_a, stride_b, stride_c, stride_c2
     d.stride_bias, d.stride_aux = stride_bias, stride_aux
     d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
+    d.rowsum = (rowsum.data_ptr() + 4 * rowsum_off) if rowsum is not None else None
+    d.stride_rowsum = stride_rowsum
     tag = ("fwd" if b_layout == GEMM_RED_CONTIG else "dx") if a_layout == GEMM_RED_CONTIG else "dw"
     flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
     return d, flops, tag

@@ -213,7 +213,7 @@ class MlpGraph:
             width = max(r4(op["lin"].n) for op in self.ops)
             self._bias_scratch = torch.zeros(64, width + 8, dtype=torch.float32, device=self.dev)
             small = [op["lin"] for op in self.ops if op["lin"].n * op["lin"].w.pitch <= 128 * 1024]
-            self._w_scratch = torch.zeros(32, max([l.n * l.w.pitch for l in small] + [4]), dtype=torch.float32, device=self.dev)
+            self._w_scratch = torch.zeros(32, r4(max([l.n * l.w.pitch + l.n for l in small] + [4])), dtype=torch.float32, device=self.dev)
         sc = self._bias_scratch
         for op in reversed(self.ops):
             if tags is not None and op["tag"] not in tags:
@@ -222,21 +222,20 @@ class MlpGraph:
             x = self.act_bufs[op["src"]]
             gz = self.grad(op["dst"])
             gzo, ldg = op["dst_col"], gz.stride(0)
-            # bias gradient
-            chunks = 64 if m >= 1024 else 1
-            p.call("pulse_colsum_partial", gz.data_ptr() + 4 * gzo, m, lin.n, ldg, chunks, sc.data_ptr(), sc.stride(0))
-            p.call("pulse_reduce_slabs", sc.data_ptr(), chunks, sc.stride(0), lin.n, book.slabs.data_ptr() + 4 * lin.b.off, 1.0)
-            # weight gradient: dW[n][k] = sum_m gz[m][n] x[m][k]
+            # weight gradient dW[n][k] = sum_m gz[m][n] x[m][k]; the bias gradient (column sums of gz) comes out of the same
+            # launch as per-slab row sums of the A operand (pulse_gemm_desc.rowsum)
             tiles = ((lin.n + 127) // 128) * ((lin.k_phys + 127) // 128)
-            if tiles * S < 128 and lin.n * lin.w.pitch <= self._w_scratch.shape[1] and m >= 32 * 32:
+            wcount = lin.n * lin.w.pitch
+            if tiles * S < 128 and wcount + lin.n <= self._w_scratch.shape[1] and m >= 32 * 32 and lin.b.off == lin.w.off + wcount:
                 ws_ = self._w_scratch
                 p.gemm(gz, x, ws_, M=lin.n, N=lin.k_phys, K=m, lda=ldg, ldb=x.stride(0), ldc=lin.w.pitch, a_layout=GEMM_OUT_CONTIG,
-                       b_layout=GEMM_OUT_CONTIG, a_off=gzo, b_off=op["src_col"], split_k=32, split_stride=ws_.stride(0), algo_n=lin.k_logical)
-                p.call("pulse_reduce_slabs", ws_.data_ptr(), 32, ws_.stride(0), lin.n * lin.w.pitch, book.slabs.data_ptr() + 4 * lin.w.off, 1.0)
+                       b_layout=GEMM_OUT_CONTIG, a_off=gzo, b_off=op["src_col"], split_k=32, split_stride=ws_.stride(0), algo_n=lin.k_logical,
+                       rowsum=ws_, rowsum_off=wcount)
+                p.call("pulse_reduce_slabs", ws_.data_ptr(), 32, ws_.stride(0), wcount + lin.n, book.slabs.data_ptr() + 4 * lin.w.off, 1.0)
             else:
                 p.gemm(gz, x, book.slabs, M=lin.n, N=lin.k_phys, K=m, lda=ldg, ldb=x.stride(0), ldc=lin.w.pitch, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, a_off=gzo, b_off=op["src_col"], c_off=lin.w.off, split_k=S, split_stride=P,
-                       algo_n=lin.k_logical)
+                       algo_n=lin.k_logical, rowsum=book.slabs, rowsum_off=lin.b.off)
             # input gradients for the requested column ranges, producer's activation derivative fused
             for (c0, c1, act, aux_name, aux_col) in op["grad_ranges"]:
                 gx = self.grad(op["src"])

@@ -221,7 +221,7 @@ class A2CNetwork:
                 self._bias_chunks = 64
                 self._bias_scratch = torch.zeros(self._bias_chunks, 2 * max(max(u), self.a_pitch) + 8, dtype=torch.float32, device=dev)
                 self._head_split = 32
-                self._head_scratch = torch.zeros(self._head_split, 2 * self.head_rows * u[-1], dtype=torch.float32, device=dev)
+                self._head_scratch = torch.zeros(self._head_split, self.bh_off - self.wh_off + 2 * self.a_pitch, dtype=torch.float32, device=dev)
             ws["plan_bwd"] = self._plan_backward(ws, m)
         self._ws[key] = ws
         return ws
@@ -267,14 +267,6 @@ class A2CNetwork:
         aux = ws["h"] if self.act == ACT_RELU else ws["z"]
         p = K.Plan()
 
-        def bias_grad(dz, n, ld, off):
-            # db = column sums: 64 row chunks (enough workgroups to stream at HBM rate) into a scratch, then one
-            # ordered reduce straight into slab 0 (the other slabs stay zero at bias positions)
-            c = self._bias_chunks if m >= 64 * 16 else 1
-            sc = self._bias_scratch
-            p.call("pulse_colsum_partial", dz.data_ptr(), m, n, ld, c, sc.data_ptr(), sc.stride(0))
-            p.call("pulse_reduce_slabs", sc.data_ptr(), c, sc.stride(0), n, slabs.data_ptr() + 4 * off, 1.0)
-
         dhd = ws["dheads"]
         # heads -> dH_L for both nets in one launch (activation derivative fused)
         p.gemm(dhd, f, ws["dh"][-1], M=m, N=uL, K=hr, lda=2 * ap, ldb=uL, ldc=2 * uL, b_layout=GEMM_OUT_CONTIG, batch=2,
@@ -282,23 +274,24 @@ class A2CNetwork:
                ldaux=2 * uL, algo_k=(self.actions_num + 1) / 2.0)
         # head weight gradients: tiny outputs (2 x [A][uL]) over a long reduction -> split wide into a scratch
         hs, HS = self._head_scratch, self._head_split if m >= 32 * self._head_split else 1
+        hb = self.bh_off - self.wh_off                       # the scratch rows mirror the flat layout [head weights | head biases]
         p.gemm(dhd, ws["h"][-1], hs, M=hr, N=uL, K=m, lda=2 * ap, ldb=2 * uL, ldc=uL, a_layout=GEMM_OUT_CONTIG,
                b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=ap, stride_b=uL, stride_c=hr * uL, split_k=HS, split_stride=hs.stride(0),
-               algo_k=m * (self.actions_num + 1) / (2.0 * hr))
-        p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), 2 * hr * uL, slabs.data_ptr() + 4 * self.wh_off, 1.0)
-        bias_grad(dhd, 2 * ap, 2 * ap, self.bh_off)
+               algo_k=m * (self.actions_num + 1) / (2.0 * hr), rowsum=hs, rowsum_off=hb, stride_rowsum=ap)
+        p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), hb + 2 * ap, slabs.data_ptr() + 4 * self.wh_off, 1.0)
         for l in range(L - 1, -1, -1):
             uu, k = u[l], self.in_w[l]
             dz = ws["dh"][l]
-            bias_grad(dz, 2 * uu, 2 * uu, self.b_off[l])
+            # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
             if l == 0:
                 p.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
-                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P, algo_n=self.in_dim)
+                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P, algo_n=self.in_dim,
+                       rowsum=slabs, rowsum_off=self.b_off[0])
             else:
                 up = u[l - 1]
                 p.gemm(dz, ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],
-                       split_k=S, split_stride=P)
+                       split_k=S, split_stride=P, rowsum=slabs, rowsum_off=self.b_off[l], stride_rowsum=uu)
                 p.gemm(dz, f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
                        batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
                        aux=aux[l - 1], ldaux=2 * up, stride_aux=up)

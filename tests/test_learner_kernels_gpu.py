@@ -389,3 +389,27 @@ def test_rollout_record_matches_reference_sequence(dev):
         np.testing.assert_allclose(d["meter_r"].cpu().numpy(), ref_r, rtol=2e-5)
         np.testing.assert_allclose(d["meter_l"].cpu().numpy(), ref_l, rtol=2e-5)
     assert buf_r[:, :slot].abs().sum() == 0 and buf_r[:, slot + 1:].abs().sum() == 0      # only slot `slot` was written
+
+
+@pytest.mark.parametrize("m_out,n_out,k_red,split,batch", [(200, 130, 1000, 1, 1), (70, 512, 4096, 8, 2), (1024, 70, 5000, 4, 1)])
+def test_gemm_rowsum_is_the_bias_gradient(dev, m_out, n_out, k_red, split, batch):
+    """dW pass with pulse_gemm_desc.rowsum: slab sums of the A operand's columns == dY.sum(0) (bias gradient)."""
+    torch.manual_seed(m_out + k_red)
+    lda, ldb = batch * ((m_out + 3) // 4 * 4), batch * ((n_out + 3) // 4 * 4)
+    dy = torch.randn(k_red, lda, device=dev)
+    x = torch.randn(k_red, ldb, device=dev)
+    cnt = m_out * n_out
+    slab = (batch * (cnt + m_out) + 3) // 4 * 4
+    out = torch.full((split, slab), 7.0, device=dev)
+    K.gemm(dy, x, out, M=m_out, N=n_out, K=k_red, lda=lda, ldb=ldb, ldc=n_out, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
+           batch=batch, stride_a=lda // batch, stride_b=ldb // batch, stride_c=cnt, split_k=split, split_stride=slab,
+           rowsum=out, rowsum_off=batch * cnt, stride_rowsum=m_out)
+    tot = out.sum(0).cpu().double()
+    for z in range(batch):
+        a = dy[:, z * (lda // batch): z * (lda // batch) + m_out].cpu().double()
+        b = x[:, z * (ldb // batch): z * (ldb // batch) + n_out].cpu().double()
+        w = tot[z * cnt:(z + 1) * cnt].view(m_out, n_out)
+        rs = tot[batch * cnt + z * m_out: batch * cnt + (z + 1) * m_out]
+        ref_w, ref_b = a.t() @ b, a.sum(0)
+        assert (w - ref_w).abs().max() <= 2e-5 * ref_w.abs().max()
+        assert (rs - ref_b).abs().max() <= 2e-5 * max(1.0, ref_b.abs().max())

@@ -90,6 +90,19 @@ def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches, reference="
             "rollout_s_per_step": per_step, "update_s_per_minibatch": per_mb, "epoch_s_extrapolated": epoch_s}
 
 
+def gemm_traffic(cfg_name):
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, separate passes, mean over the GEMM launches of one epoch of this config); None if not collected.  The
+    counters serialise kernels, so they cannot be read inside the timed region: the number is a property of the same
+    command profiled once per round."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_gemm_traffic_{cfg_name}.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["gemm_f32_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg_name, seed, sample_steps, n_minibatches, budget_s, reference="motion_lib"):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", cfg_name, "--cpu-steps", str(sample_steps),
@@ -125,6 +138,8 @@ def main():
     from pulse_amd.parallel import DistContext
     _lib.load()                                                   # fail loudly before anything else if the HIP library is missing
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if os.environ.get("PULSE_BENCH_SHARE_GPU"):                   # functional test of the N>1 path on a 1-GPU box (with PULSE_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     dist = DistContext(enabled=world > 1)
@@ -182,7 +197,7 @@ def main():
         t = sum(v[1] for v in s.values())
         f = sum(v[2] for v in s.values())
         out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": f / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_f32_kernel",
+                           "frac": f / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": gemm_traffic(a.config), "kernel": "gemm_f32_kernel",
                            "launches": n, "avg_us": 1e6 * t / max(1, n), "kernel_time_frac_of_step": t / (elapsed / a.steps),
                            "instrumented_steps": 1,
                            "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in s.items()}}

@@ -35,7 +35,8 @@ class DistContext:
         self.world_size = ws_env
         if not dist.is_initialized():
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # PULSE_DIST_BACKEND=gloo lets a 1-GPU box exercise the multi-rank control flow (ranks share the device)
+                backend = os.environ.get("PULSE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

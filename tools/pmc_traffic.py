@@ -1,0 +1,28 @@
+"""HBM traffic of the GEMM kernel from rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM section):
+FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (TCC slots), both in KiB; on gfx950 FETCH_SIZE reports half the
+bytes of 16-B/lane streaming reads, so it is doubled.  WRITE_SIZE is uncalibrated (used as is).
+Usage: python tools/pmc_traffic.py <dir with *counter_collection.csv> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        key = "gemm_f32_kernel" if "gemm_f32_kernel" in k else ("other_pulse" if "pulse" in k else "torch")
+        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for key, cs in agg.items():
+    f, w = cs.get("FETCH_SIZE", []), cs.get("WRITE_SIZE", [])
+    if not f or not w:
+        continue
+    fetch = 2.0 * 1024.0 * sum(f) / len(f)          # KiB -> B, x2 gfx950 correction
+    write = 1024.0 * sum(w) / len(w)
+    res[key] = {"launches_fetch_pass": len(f), "launches_write_pass": len(w), "fetch_bytes_per_launch": fetch,
+                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -145,6 +145,29 @@ def motion_lib_class():
     return cls
 
 
+class _AttrDict(dict):
+    """easydict.EasyDict stand-in (easydict is not installed): attribute access on a dict."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def network_loader_functions():
+    """load_mlp / load_linear / load_z_encoder / load_z_decoder of phc/learning/network_loader.py:76-176 (the module imports
+    easydict and the PNN / VQ classes at top level, so the functions are extracted by name) and HumanoidZ.compute_z_actions
+    (phc/env/tasks/humanoid_z.py:81-155)."""
+    if "netload" in _cache:
+        return _cache["netload"]
+    ns = _namespace()
+    tu = torch_utils()
+    ns.update({"edict": _AttrDict, "project_to_norm": tu.project_to_norm, "F": __import__("torch").nn.functional})
+    srcs = _extract(os.path.join(REFERENCE_ROOT, "phc", "learning", "network_loader.py"), ["load_mlp", "load_linear", "load_z_encoder", "load_z_decoder"])
+    srcs.update(_extract(os.path.join(REFERENCE_ROOT, "phc", "env", "tasks", "humanoid_z.py"), ["compute_z_actions"], methods_of="HumanoidZ"))
+    for name, text in srcs.items():
+        exec(compile(text, f"<reference:{name}>", "exec"), ns)
+    _cache["netload"] = {k: ns[k] for k in srcs}
+    return _cache["netload"]
+
+
 def importable_modules():
     """Reference modules that import cleanly here (no shim needed)."""
     _ensure_paths()

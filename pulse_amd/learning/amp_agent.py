@@ -240,6 +240,58 @@ class AMPAgent(CommonAgent):
                 "disc_agent_acc": torch.mean((agent_logit.detach() < 0).float()), "disc_demo_acc": torch.mean((demo_logit.detach() > 0).float()),
                 "disc_agent_logit": agent_logit.detach().mean(), "disc_demo_logit": demo_logit.detach().mean()}
 
+    # ------------------------------------------------------------------ checkpoint surface (amp_agent.py:81-118, 181-190)
+    def get_stats_weights(self):
+        state = {}
+        if self.normalize_input:
+            state["running_mean_std"] = self.running_mean_std.state_dict()
+        if self.normalize_value:
+            state["reward_mean_std"] = self.value_mean_std.state_dict()
+        if self.enable_disc:
+            state["amp_input_mean_std"] = self._amp_input_mean_std.state_dict()
+        return state
+
+    def set_stats_weights(self, weights):
+        if self.normalize_input and weights["running_mean_std"]["running_mean"].shape == self.running_mean_std.running_mean.shape:
+            self.running_mean_std.load_state_dict(weights["running_mean_std"])
+        if self.normalize_value and "reward_mean_std" in weights:
+            self.value_mean_std.load_state_dict(weights["reward_mean_std"])
+        if self.enable_disc and "amp_input_mean_std" in weights:
+            if weights["amp_input_mean_std"]["running_mean"].shape == self._amp_input_mean_std.running_mean.shape:
+                self._amp_input_mean_std.load_state_dict(weights["amp_input_mean_std"])
+
+    def get_full_state_weights(self):
+        """The reference's checkpoint dict: 'model' holds EVERY a2c_network.* tensor (policy, critic, discriminator) under
+        the reference's names, the normalisers sit next to it.  The Adam moments are stored as flat buffers (the reference
+        stores torch.optim's index-keyed state, whose parameter order belongs to rl_games' module tree)."""
+        state = super().get_full_state_weights()
+        if self.enable_disc:
+            state["model"].update(self.disc.state_dict())
+            state["amp_input_mean_std"] = self._amp_input_mean_std.state_dict()
+            state["disc_optimizer"] = {"exp_avg": self.disc_exp_avg.clone(), "exp_avg_sq": self.disc_exp_avg_sq.clone()}
+        if self.save_kin_info:
+            state["kin_optimizer"] = {"exp_avg": self.kin_exp_avg.clone(), "exp_avg_sq": self.kin_exp_avg_sq.clone(), "step": self.kin_step}
+        return state
+
+    def set_full_state_weights(self, weights):
+        model = dict(weights["model"])
+        if self.enable_disc:
+            disc_keys = [k for k in model if "._disc_" in k]
+            self.disc.load_state_dict({k: model.pop(k) for k in disc_keys})
+            if "amp_input_mean_std" in weights:
+                self._amp_input_mean_std.load_state_dict(weights["amp_input_mean_std"])
+            if "disc_optimizer" in weights:
+                self.disc_exp_avg.copy_(weights["disc_optimizer"]["exp_avg"])
+                self.disc_exp_avg_sq.copy_(weights["disc_optimizer"]["exp_avg_sq"])
+        else:
+            model = {k: v for k, v in model.items() if "._disc_" not in k}
+        super().set_full_state_weights(dict(weights, model=model))
+        if self.save_kin_info and "kin_optimizer" in weights and "exp_avg" in weights["kin_optimizer"]:
+            self.kin_exp_avg.copy_(weights["kin_optimizer"]["exp_avg"])
+            self.kin_exp_avg_sq.copy_(weights["kin_optimizer"]["exp_avg_sq"])
+            self.kin_step = int(weights["kin_optimizer"]["step"])
+        self.running_mean_std_temp = self.running_mean_std.clone_frozen()
+
     # ------------------------------------------------------------------ epoch hooks (amp_agent.py:557-583)
     def pre_epoch(self, epoch_num):
         self.running_mean_std_temp = self.running_mean_std.clone_frozen()

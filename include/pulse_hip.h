@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 7
+#define PULSE_ABI_VERSION 8
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -256,6 +256,12 @@ typedef struct pulse_motion_state_args {
        rows of unmasked envs are left untouched (so the outputs can BE the simulator's state tensors). */
     const uint8_t* reset_mask; const float* reset_phase;
     float* reset_start_times; int64_t* reset_progress; int64_t* reset_clear0; int64_t* reset_clear1;
+    /* reset_time_interval != 0: start = long((phase * length) / (1/30)) * (1/30)   (sample_time_interval, motion_lib_base.py:413-421,
+       what HumanoidIm._sample_time uses, humanoid_im.py:652-654).  _reset_ref_state_init (humanoid_im.py:920-926) also clears the
+       per-env clock offset, global offset and cycle counter: reset_start_offsets[e] = 0, reset_global_offset[e,:] = 0,
+       reset_clear2[e] = 0 when given (and the state is then evaluated with them at zero). */
+    int32_t reset_time_interval;
+    float* reset_start_offsets; float* reset_global_offset; int64_t* reset_clear2;
 } pulse_motion_state_args;
 int pulse_sizeof_motion_state_args(void);
 int pulse_motion_state(const pulse_motion_state_args* args, pulse_stream_t s);

@@ -542,3 +542,73 @@ def oracle_disc_rewards(disc, amp_rms, amp_obs, disc_reward_scale=2.0):
         r = -torch.log(torch.maximum(1 - prob, torch.tensor(0.0001))) * disc_reward_scale
     amp_rms.train(was)
     return r
+
+
+class OracleAMPModel(nn.Module):
+    """ModelAMPContinuous.Network (phc/learning/amp_models.py:16-43) over the restated policy / discriminator nets: the
+    rl_games forward (OracleNet.forward) plus the three discriminator logits in training mode."""
+
+    def __init__(self, net, disc):
+        super().__init__()
+        self.a2c_network = net
+        self.disc = disc
+        net.eval_disc = disc.eval_disc
+
+    def forward(self, d):
+        res = self.a2c_network(d)
+        if d.get("is_train", True):
+            res["disc_agent_logit"] = self.disc.eval_disc(d["amp_obs"])
+            res["disc_agent_replay_logit"] = self.disc.eval_disc(d["amp_obs_replay"])
+            res["disc_demo_logit"] = self.disc.eval_disc(d["amp_obs_demo"])
+        return res
+
+
+def oracle_amp_calc_gradients(model, optimizer, rms, rms_temp, amp_rms, d, cfg):
+    """AMPAgent.calc_gradients, phc/learning/amp_agent.py:605-760 (PPO branch with the discriminator; fp32, single GPU):
+    frozen-copy observation normalisation while the live statistics update (:594-601), the first amp_minibatch_size rows of the
+    three AMP streams normalised in order (:621-629), loss = a + c_coef c - ent_coef H + b_coef b + disc_coef disc (:707-708),
+    clip_grad_norm_ over ALL parameters, Adam.  ``cfg``: e_clip, critic_coef, entropy_coef, bounds_loss_coef, disc_coef,
+    disc_logit_reg, disc_grad_penalty, disc_weight_decay, grad_norm, amp_minibatch_size, clip_value."""
+    obs = d["obs"]
+    obs_proc = rms_temp(obs)
+    rms(obs)                                                    # running through the live mean/std, value unused
+    b = cfg["amp_minibatch_size"]
+    amp_obs, amp_replay, amp_demo = amp_rms(d["amp_obs"][0:b]), amp_rms(d["amp_obs_replay"][0:b]), amp_rms(d["amp_obs_demo"][0:b])
+    amp_demo.requires_grad_(True)
+    res = model({"is_train": True, "prev_actions": d["actions"], "obs": obs_proc, "amp_obs": amp_obs, "amp_obs_replay": amp_replay,
+                 "amp_obs_demo": amp_demo})
+    nlp, values, mu, sigma = res["prev_neglogp"], res["values"], res["mus"], res["sigmas"]
+    ratio = torch.exp(d["old_logp_actions"] - nlp)
+    surr1 = d["advantages"] * ratio
+    surr2 = d["advantages"] * torch.clamp(ratio, 1.0 - cfg["e_clip"], 1.0 + cfg["e_clip"])
+    a_loss = torch.max(-surr1, -surr2)
+    if cfg.get("clip_value", False):
+        vpc = d["old_values"] + (values - d["old_values"]).clamp(-cfg["e_clip"], cfg["e_clip"])
+        c_loss = torch.max((values - d["returns"]) ** 2, (vpc - d["returns"]) ** 2)
+    else:
+        c_loss = (d["returns"] - values) ** 2
+    b_loss = (torch.clamp_max(mu + 1.0, 0.0) ** 2 + torch.clamp_min(mu - 1.0, 0.0) ** 2).sum(axis=-1)
+    a_loss, c_loss, b_loss, entropy = torch.mean(a_loss), torch.mean(c_loss), torch.mean(b_loss), torch.mean(res["entropy"])
+    agent_cat = torch.cat([res["disc_agent_logit"], res["disc_agent_replay_logit"]], dim=0)
+    demo_logit = res["disc_demo_logit"]
+    bce = torch.nn.BCEWithLogitsLoss()
+    disc_loss = 0.5 * (bce(agent_cat, torch.zeros_like(agent_cat)) + bce(demo_logit, torch.ones_like(demo_logit)))
+    disc = model.disc
+    logit_loss = torch.sum(torch.square(torch.flatten(disc._disc_logits.weight)))
+    disc_loss = disc_loss + cfg["disc_logit_reg"] * logit_loss
+    g = torch.autograd.grad(demo_logit, amp_demo, grad_outputs=torch.ones_like(demo_logit), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    penalty = torch.mean(torch.sum(torch.square(g), dim=-1))
+    disc_loss = disc_loss + cfg["disc_grad_penalty"] * penalty
+    if cfg["disc_weight_decay"] != 0:
+        ws = [torch.flatten(m.weight) for m in disc._disc_mlp.modules() if isinstance(m, nn.Linear)] + [torch.flatten(disc._disc_logits.weight)]
+        disc_loss = disc_loss + cfg["disc_weight_decay"] * torch.sum(torch.square(torch.cat(ws, dim=-1)))
+    loss = a_loss + cfg["critic_coef"] * c_loss - cfg["entropy_coef"] * entropy + cfg["bounds_loss_coef"] * b_loss + cfg["disc_coef"] * disc_loss
+    for p in model.parameters():
+        p.grad = None
+    loss.backward()
+    with torch.no_grad():
+        kl = policy_kl(mu.detach(), sigma.detach(), d["mu"], d["sigma"], True)
+    gn = nn.utils.clip_grad_norm_(model.parameters(), cfg["grad_norm"])
+    optimizer.step()
+    return {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl,
+            "disc_loss": disc_loss.detach(), "disc_grad_penalty": penalty.detach(), "grad_norm": gn}

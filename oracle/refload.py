@@ -56,9 +56,10 @@ def _extract(path, names, *, methods_of=None):
     lines = src.splitlines()
     body = tree.body
     if methods_of is not None:
-        cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == methods_of]
-        assert cls, f"class {methods_of} not found in {path}"
-        body = cls[0].body
+        for part in methods_of.split("."):                   # "AMPZBuilder.Network": nested classes
+            cls = [n for n in body if isinstance(n, ast.ClassDef) and n.name == part]
+            assert cls, f"class {methods_of} not found in {path}"
+            body = cls[0].body
     out = {}
     for node in body:
         if isinstance(node, ast.FunctionDef) and node.name in names:
@@ -66,6 +67,8 @@ def _extract(path, names, *, methods_of=None):
             if methods_of is not None:
                 import textwrap
                 text = textwrap.dedent(text)
+                if text.lstrip().startswith("@"):           # never the case here (decorators are excluded), kept for safety
+                    text = text[text.index("def "):]
             out[node.name] = text
     missing = set(names) - set(out)
     assert not missing, f"not found in {path}: {missing}"
@@ -143,6 +146,64 @@ def motion_lib_class():
     cls = type("ReferenceMotionLibQueries", (), {k: ns[k] for k in srcs})
     _cache["motion_lib"] = cls
     return cls
+
+
+AMP_AGENT_METHODS = ["_disc_loss", "_disc_loss_neg", "_disc_loss_pos", "_compute_disc_acc", "_calc_disc_rewards", "_calc_amp_rewards",
+                     "_eval_disc", "_preproc_amp_obs", "_combine_rewards", "_optimize_kin", "_assamble_kin_dict", "_norm_disc_reward",
+                     "calc_gradients", "_preproc_obs", "play_steps"]
+AMP_NET_METHODS = ["eval_disc", "get_disc_logit_weights", "get_disc_weights"]
+AMPZ_NET_METHODS = ["form_embedding", "compute_prior", "reparameterize", "eval_actor", "eval_critic"]
+
+
+def learning_methods():
+    """Methods of AMPAgent (phc/learning/amp_agent.py), AMPBuilder.Network (amp_network_builder.py) and AMPZBuilder.Network
+    (amp_network_z_builder.py) extracted by name: the modules import rl_games at top level, the method BODIES are plain torch.
+    Returns {'agent': {...}, 'amp_net': {...}, 'ampz_net': {...}} of functions taking an explicit ``self``."""
+    if "learning" in _cache:
+        return _cache["learning"]
+    import torch
+    ns = _namespace()
+    tu = torch_utils()
+    lf = importable_modules()["loss_functions"]
+    ns.update({"kl_multi": lf.kl_multi, "project_to_norm": tu.project_to_norm, "to_torch": ns.get("to_torch"),
+               "flags": types.SimpleNamespace(test=False, trigger_input=False, debug=False), "F": torch.nn.functional})
+    from . import agent_oracle as _ao                        # torch_ext.policy_kl is rl_games (absent): the restated form, SURVEY Appendix B
+    ns["torch_ext"] = types.SimpleNamespace(policy_kl=_ao.policy_kl)
+    ns["a2c_common"] = types.SimpleNamespace(swap_and_flatten01=_ao.swap_and_flatten01)   # rl_games a2c_common.swap_and_flatten01 (Appendix B)
+    base = os.path.join(REFERENCE_ROOT, "phc", "learning")
+    out = {}
+    for key, fname, cls, names in (("agent", "amp_agent.py", "AMPAgent", AMP_AGENT_METHODS),
+                                   ("amp_net", "amp_network_builder.py", "AMPBuilder.Network", AMP_NET_METHODS),
+                                   ("ampz_net", "amp_network_z_builder.py", "AMPZBuilder.Network", AMPZ_NET_METHODS)):
+        srcs = _extract(os.path.join(base, fname), names, methods_of=cls)
+        if key == "agent":                                   # inherited from CommonAgent
+            srcs.update(_extract(os.path.join(base, "common_agent.py"), ["_actor_loss", "_critic_loss", "bound_loss", "get_action_values", "_eval_critic",
+                                                                         "discount_values"], methods_of="CommonAgent"))
+        local = dict(ns)
+        for name, text in srcs.items():
+            exec(compile(text, f"<reference:{cls}.{name}>", "exec"), local)
+        out[key] = {k: local[k] for k in srcs}
+    _cache["learning"] = out
+    return out
+
+
+HUMANOID_IM_METHODS = ["_compute_task_obs", "_compute_reward", "_compute_reset", "_get_state_from_motionlib_cache"]
+
+
+def humanoid_im_methods():
+    """Step-composition methods of HumanoidIm (phc/env/tasks/humanoid_im.py:708-919, 950-964, 1119-1192) extracted by name; they call
+    the jit functions of env_functions() and a motion library with MotionLibBase's query surface."""
+    if "him" in _cache:
+        return _cache["him"]
+    ns = _namespace()
+    ns.update(env_functions())
+    ns["flags"] = types.SimpleNamespace(test=False, im_eval=False, no_collision_check=False, real_traj=False)   # run_hydra.py defaults
+    path = os.path.join(REFERENCE_ROOT, "phc", "env", "tasks", "humanoid_im.py")
+    srcs = _extract(path, HUMANOID_IM_METHODS, methods_of="HumanoidIm")
+    for name, text in srcs.items():
+        exec(compile(text, f"<reference:HumanoidIm.{name}>", "exec"), ns)
+    _cache["him"] = {k: ns[k] for k in srcs}
+    return _cache["him"]
 
 
 class _AttrDict(dict):

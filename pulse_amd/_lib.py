@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -77,7 +77,8 @@ class MotionStateArgs(Structure):
                 ("rb_records", c_void_p), ("rb_query_stride", c_int64),
                 ("frame_idx0", c_void_p), ("frame_idx1", c_void_p), ("blend", c_void_p),
                 ("reset_mask", c_void_p), ("reset_phase", c_void_p), ("reset_start_times", c_void_p), ("reset_progress", c_void_p),
-                ("reset_clear0", c_void_p), ("reset_clear1", c_void_p)]
+                ("reset_clear0", c_void_p), ("reset_clear1", c_void_p), ("reset_time_interval", c_int32),
+                ("reset_start_offsets", c_void_p), ("reset_global_offset", c_void_p), ("reset_clear2", c_void_p)]
 
 
 class RolloutRecordArgs(Structure):

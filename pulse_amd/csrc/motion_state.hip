@@ -38,14 +38,21 @@ __global__ void __launch_bounds__(kMsQueries * kMsLanes) motion_state_kernel(con
         // reference-state init of the masked envs (_reset_envs -> _sample_ref_state, humanoid_im.py:966-986): new start time
         // phase * motion length (sample_time, motion_lib_base.py:401-411), episode clock back to 0, state := reference at that time
         if (a.reset_mask[e] == 0) return;
-        const float st = a.reset_phase ? a.reset_phase[e] * T.motion_lengths[m] : 0.0f;
+        float st = a.reset_phase ? a.reset_phase[e] * T.motion_lengths[m] : 0.0f;
+        if (a.reset_phase && a.reset_time_interval) {
+            const float curr_fps = (float)(1.0 / 30.0);              // sample_time_interval: ((phase * len) / curr_fps).long() * curr_fps
+            st = (float)((long long)(st / curr_fps)) * curr_fps;
+        }
         t = (float)a.step_shift * a.dt + st;
-        if (a.start_offsets) t = t + a.start_offsets[e];
+        if (a.start_offsets && !a.reset_start_offsets) t = t + a.start_offsets[e];
         if (lane == 0) {
             if (a.reset_start_times) a.reset_start_times[e] = st;
             if (a.reset_progress) a.reset_progress[e] = 0;
             if (a.reset_clear0) a.reset_clear0[e] = 0;
             if (a.reset_clear1) a.reset_clear1[e] = 0;
+            if (a.reset_clear2) a.reset_clear2[e] = 0;
+            if (a.reset_start_offsets) a.reset_start_offsets[e] = 0.0f;
+            if (a.reset_global_offset) { a.reset_global_offset[3 * e] = 0.0f; a.reset_global_offset[3 * e + 1] = 0.0f; a.reset_global_offset[3 * e + 2] = 0.0f; }
         }
     } else {
         t = query_time(a, i, e);
@@ -57,7 +64,7 @@ __global__ void __launch_bounds__(kMsQueries * kMsLanes) motion_state_kernel(con
         if (a.blend) a.blend[i] = fp.blend;
     }
     const int J = T.num_bodies;
-    const float* off = a.offset ? a.offset + 3 * e : nullptr;
+    const float* off = (a.offset && !(a.reset_mask && a.reset_global_offset)) ? a.offset + 3 * e : nullptr;
     if (a.root_only) {
         if (lane == 0 && a.root_pos) {
             const V3 p = lerp3(fp.r0 + T.off_gts, fp.r1 + T.off_gts, fp.blend);

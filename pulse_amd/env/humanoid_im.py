@@ -146,10 +146,8 @@ class HumanoidIm:
         n, dev, lib = self.num_envs, self.device, self._motion_lib
         self._sampled_motion_ids = torch.arange(n, dtype=torch.int64, device=dev) % lib.num_motions()
         self._motion_len_env = lib.get_motion_length(self._sampled_motion_ids).contiguous()
-        e = torch.arange(n, device=dev)
-        side = int(n ** 0.5) + 1
-        spacing = float(env.get("envSpacing", 5.0))
-        self._global_offset = torch.stack([(e % side) * spacing, (e // side) * spacing, torch.zeros(n, device=dev)], dim=-1).float().contiguous()
+        # _global_offset is zero after a reset (humanoid_im.py:920-923) and only moves when a motion is cycled in place (:1125-1146)
+        self._global_offset = torch.zeros(n, 3, device=dev)
         self._clock_gen = torch.Generator(device=dev)
         self._clock_gen.manual_seed(int(env.get("motion_clock_seed", 2024)))
         self._state_init_random = env.get("stateInit", "Random") != "Start"              # HumanoidAMP.StateInit
@@ -260,6 +258,8 @@ class HumanoidIm:
 
     def pre_physics_step(self, actions):
         self.actions = actions
+        if self.cycle_motion and self._use_motion_lib:      # the counter only ever leaves zero in cycle / zero_out_far modes
+            self._update_cycle_count()
         self.sim.set_dof_position_target_tensor(self._action_to_pd_targets(actions))
 
     def _physics_step(self):
@@ -293,6 +293,26 @@ class HumanoidIm:
             obs=self._obs_store, obs_cols=self.obs_pitch, rew=self.rew_buf, rew_raw=self.reward_raw,
             reset=self.reset_buf, terminate=self._terminate_buf, clock=clock, motion=motion)
 
+    def _cycle_motion_update(self):
+        """humanoid_im.py:1125-1146 (cycle_motion, neither cycle_motion_xp nor zero_out_far): envs whose motion time ran past the clip
+        get a new start time, a clock offset that cancels progress_buf, 60 recovery steps and a global offset that puts the reference
+        root under the simulated root.  Sync-free masked form."""
+        lib, ids, p = self._motion_lib, self._sampled_motion_ids, self.progress_buf
+        t = p * self.dt + self._motion_start_times + self._motion_start_times_offset
+        ended = t >= self._motion_len_env
+        new_start = lib.sample_time_interval(ids, generator=self._clock_gen)
+        self._last_cycle_start = new_start                  # (tests replay the draw on the CPU twin)
+        torch.where(ended, -p * self.dt, self._motion_start_times_offset, out=self._motion_start_times_offset)
+        torch.where(ended, new_start, self._motion_start_times, out=self._motion_start_times)
+        self._cycle_counter.masked_fill_(ended, 60)
+        root = lib.get_root_pos_smpl(ids, self._motion_start_times)["root_pos"]
+        xy = self.sim.rigid_body_state[:, 0, 0:2] - root[:, 0:2]
+        self._global_offset[:, 0:2] = torch.where(ended[:, None], xy, self._global_offset[:, 0:2])
+
+    def _update_cycle_count(self):
+        """humanoid_im.py:1042-1045, called from pre_physics_step (:1112)."""
+        self._cycle_counter.sub_(1).clamp_(min=0)
+
     def _compute_reward(self, actions=None):
         self._im_step(PULSE_IM_REWARD)
 
@@ -306,7 +326,13 @@ class HumanoidIm:
     def post_physics_step(self):
         # progress += 1, pass_time, reward -> reset -> observations (humanoid.py:1316-1328): one launch.  With the motion library
         # the increment, the time-out test and the reference blend (t and t+1) all happen inside it.
-        if self._use_motion_lib:
+        if self._use_motion_lib and self.cycle_motion:
+            # cycle_motion (env_im_vae.yaml:55): the reward is taken on the OLD clock, then motions that ran out restart in place
+            # (_compute_reset, humanoid_im.py:1125-1146), then reset + observations use the new clock
+            self._im_step(PULSE_IM_REWARD, inc=1)
+            self._cycle_motion_update()
+            self._im_step(PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
+        elif self._use_motion_lib:
             self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, inc=1)
         else:
             self.progress_buf += 1
@@ -343,14 +369,15 @@ class HumanoidIm:
             # _reset_envs -> _sample_ref_state (humanoid_im.py:966-986) for the masked envs in ONE launch: new start time
             # (phase * motion length), clock and reset / terminate flags cleared, simulator state := reference state there
             if self._state_init_random:
-                self._reset_phase.uniform_(0.0, 1.0, generator=self._clock_gen)           # MotionLibBase.sample_time's torch.rand
+                self._reset_phase.uniform_(0.0, 1.0, generator=self._clock_gen)           # sample_time_interval's torch.rand (HumanoidIm._sample_time)
             sim = self.sim
             self._motion_lib.query(self._sampled_motion_ids, offset=self._global_offset, dt=self.dt, start_offsets=self._motion_start_times_offset,
                                    out={"rb_records": sim.rigid_body_state, "dof_pos": sim.dof_pos, "dof_vel": sim.dof_vel},
                                    fields=("rb_records", "dof_pos", "dof_vel"),
-                                   reset={"mask": mask, "phase": self._reset_phase if self._state_init_random else None,
+                                   reset={"mask": mask, "phase": self._reset_phase if self._state_init_random else None, "time_interval": True,
                                           "start_times": self._motion_start_times, "progress": self.progress_buf,
-                                          "clear0": self.reset_buf, "clear1": self._terminate_buf})
+                                          "clear0": self.reset_buf, "clear1": self._terminate_buf, "clear2": self._cycle_counter,
+                                          "zero_start_offsets": self._motion_start_times_offset, "zero_global_offset": self._global_offset})
             self._compute_observations(env_mask=mask)
             if self._enable_amp_obs:
                 self._init_amp_obs(mask)

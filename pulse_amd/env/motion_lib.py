@@ -171,11 +171,14 @@ class MotionLib:
             a.reset_mask, a.step_shift, a.dt = m.data_ptr(), int(step_shift), float(dt)
             ph = f32(reset.get("phase"), "reset.phase", (ne,))
             a.reset_phase = ph.data_ptr() if ph is not None else None
+            a.reset_time_interval = int(bool(reset.get("time_interval", False)))
             for field, key, dt_ in (("reset_start_times", "start_times", torch.float32), ("reset_progress", "progress", torch.int64),
-                                    ("reset_clear0", "clear0", torch.int64), ("reset_clear1", "clear1", torch.int64)):
+                                    ("reset_clear0", "clear0", torch.int64), ("reset_clear1", "clear1", torch.int64),
+                                    ("reset_clear2", "clear2", torch.int64), ("reset_start_offsets", "zero_start_offsets", torch.float32),
+                                    ("reset_global_offset", "zero_global_offset", torch.float32)):
                 t_ = reset.get(key)
                 if t_ is not None:
-                    if t_.dtype != dt_ or not t_.is_contiguous() or t_.numel() != ne:
+                    if t_.dtype != dt_ or not t_.is_contiguous() or t_.numel() != (3 * ne if key == "zero_global_offset" else ne):
                         raise TypeError(f"reset.{key}: contiguous {dt_} tensor of {ne} elements expected")
                     setattr(a, field, t_.data_ptr())
             so = f32(start_offsets, "start_offsets", (ne,))

@@ -20,10 +20,11 @@ def _twin(env, n, seed, time_steps=1):
     bank = {k: v.cpu() for k, v in task.sim.bank.items()}
     return OracleMotionEnv(lib, bank, task._sampled_motion_ids.cpu(), task._global_offset.cpu(), task._reset_bodies_id.cpu().long(),
                            task._track_bodies_id.cpu().long(), task.dt, time_steps=time_steps, traj_dt=task._traj_sample_timestep,
-                           obs_v=task.obs_v)
+                           obs_v=task.obs_v, cycle_motion=task.cycle_motion, max_episode_length=task.max_episode_length)
 
 
-@pytest.mark.parametrize("n,overrides", [(67, {}), (40, {"fut_tracks": True, "numTrajSamples": 3}), (33, {"obs_v": 7, "trackBodies": ["Head", "L_Hand", "R_Hand"]})])
+@pytest.mark.parametrize("n,overrides", [(67, {}), (40, {"fut_tracks": True, "numTrajSamples": 3}), (33, {"obs_v": 7, "trackBodies": ["Head", "L_Hand", "R_Hand"]}),
+                                         (52, {"cycle_motion": True, "episode_length": 45})])
 def test_motion_lib_env_lockstep_with_cpu_twin(dev, n, overrides):
     seed, horizon = 321, 24
     env, _ = configs.make_env(n, horizon, dev, seed=seed, reference="motion_lib", env_overrides=overrides)
@@ -40,7 +41,7 @@ def test_motion_lib_env_lockstep_with_cpu_twin(dev, n, overrides):
         act = torch.randn(n, 69, generator=g).to(dev)
         obs, rew, done, info = env.step(act)
         obs = obs["obs"] if isinstance(obs, dict) else obs
-        o_ref, r_ref, d_ref, i_ref = twin.step()
+        o_ref, r_ref, d_ref, i_ref = twin.step(cycle_start_times=task._last_cycle_start.cpu() if task.cycle_motion else None)
         np.testing.assert_allclose(rew.cpu().numpy(), r_ref.numpy(), atol=2e-5, rtol=1e-5, err_msg=f"reward step {step}")
         assert torch.equal(done.cpu(), d_ref), f"reset flags step {step}"
         assert torch.equal(info["terminate"].cpu(), i_ref["terminate"]), f"terminate step {step}"
@@ -53,7 +54,11 @@ def test_motion_lib_env_lockstep_with_cpu_twin(dev, n, overrides):
         o_ref = twin.reset(ids, task._motion_start_times.cpu())
         np.testing.assert_allclose(obs.cpu().numpy(), o_ref.numpy(), atol=5e-5, rtol=1e-5, err_msg=f"obs after reset {step}")
         assert torch.equal(task.progress_buf.cpu(), twin.progress)
+        assert torch.equal(task._cycle_counter.cpu(), twin.cycle_counter)
+        np.testing.assert_allclose(task._global_offset.cpu().numpy(), twin.offset.numpy(), atol=1e-5)
     assert n_done > 0, "the lockstep run never exercised a reset"
+    if task.cycle_motion:
+        assert (task._motion_start_times_offset != 0).any(), "no motion was cycled in place"
 
 
 def test_amp_demo_windows_from_motion_lib(dev):
@@ -151,10 +156,11 @@ def test_reset_mode_matches_separate_ops(dev):
     task.reset_masked(mask)
     task._clock_gen.set_state(state)
     phase = torch.zeros(n, device=dev).uniform_(0.0, 1.0, generator=task._clock_gen)
-    st = torch.where(mask, phase * task._motion_len_env, before["st"])
+    st = torch.where(mask, ((phase * task._motion_len_env) / (1 / 30)).long() * (1 / 30), before["st"])      # sample_time_interval
     assert torch.equal(task._motion_start_times, st)
     assert torch.equal(task.progress_buf, before["pg"] * (~mask))
     assert torch.equal(task.reset_buf, (~mask).long()) and torch.equal(task._terminate_buf, (~mask).long())
+    assert (task._global_offset[mask] == 0).all() and (task._motion_start_times_offset[mask] == 0).all() and (task._cycle_counter[mask] == 0).all()
     want = lib.query(task._sampled_motion_ids, st, task._global_offset, with_records=True)
     assert torch.equal(sim.rigid_body_state, torch.where(mask[:, None, None], want["rb_records"], before["rb"]))
     assert torch.equal(sim.dof_pos, torch.where(mask[:, None], want["dof_pos"], before["dp"]))

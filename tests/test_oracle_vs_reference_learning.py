@@ -1,0 +1,289 @@
+"""CPU, build container only: the restated learning math of oracle/agent_oracle.py against the REFERENCE's own method
+bodies (AST-extracted from phc/learning/amp_agent.py, amp_network_builder.py, amp_network_z_builder.py and executed with
+stub objects; the modules themselves import rl_games and cannot be imported).  Pins
+  * AMPAgent._disc_loss / _calc_disc_rewards / _combine_rewards  <-> oracle_disc_loss / oracle_disc_rewards
+  * AMPZBuilder.Network.eval_actor / compute_prior / eval_critic  <-> OracleNetZ
+  * AMPAgent._optimize_kin (PULSE distillation loss + its Adam step)  <-> oracle_optimize_kin
+so that the GPU parity tests, which compare against the oracle, inherit a reference pin for these pieces."""
+import copy
+import types
+
+import pytest
+import torch
+from torch import nn
+
+from oracle import agent_oracle as AO
+from oracle import refload
+
+pytestmark = pytest.mark.skipif(not refload.available(), reason="reference checkout not mounted")
+
+
+def _bind(obj, fns):
+    for k, f in fns.items():
+        setattr(obj, k, types.MethodType(f, obj))
+    return obj
+
+
+def test_disc_loss_and_rewards_match_reference_methods():
+    m = refload.learning_methods()
+    rms_mod = refload.importable_modules()["running_mean_std"]
+    torch.manual_seed(0)
+    d, b = 60, 37
+    disc = AO.OracleDisc(d, units=(48, 24))
+    with torch.no_grad():
+        disc._disc_logits.bias.fill_(0.1)
+    net = _bind(copy.deepcopy(disc), m["amp_net"])                      # same weights, the reference's eval_disc / weight getters
+    ref_rms = rms_mod.RunningMeanStd((d,))
+    orc_rms = AO.OracleRunningMeanStd((d,))
+    warm = torch.randn(200, d) * 2 + 0.5
+    ref_rms.train(); orc_rms.train()
+    ref_rms(warm); orc_rms(warm)
+    agent = types.SimpleNamespace(model=types.SimpleNamespace(a2c_network=net), _disc_logit_reg=0.01, _disc_grad_penalty=5.0,
+                                  _disc_weight_decay=0.0001, _disc_reward_scale=2.0, _task_reward_w=0.5, _disc_reward_w=0.5,
+                                  _normalize_amp_input=True, _amp_input_mean_std=ref_rms, ppo_device="cpu", vec_env=None)
+    _bind(agent, m["agent"])
+    agent._norm_disc_reward = lambda: False
+    xa, xr, xd = (torch.randn(b, d).clamp(-5, 5) for _ in range(3))
+    # reference: logits as calc_gradients builds them (amp_agent.py:700-712)
+    xd_ref = xd.clone().requires_grad_(True)
+    agent_logit = torch.cat([net.eval_disc(xa), net.eval_disc(xr)], dim=0)
+    demo_logit = net.eval_disc(xd_ref)
+    ref = agent._disc_loss(agent_logit, demo_logit, xd_ref)
+    ref["disc_loss"].backward()
+    got = AO.oracle_disc_loss(disc, xa, xr, xd, 0.01, 5.0, 0.0001)
+    got["disc_loss"].backward()
+    assert torch.equal(got["disc_loss"], ref["disc_loss"])
+    for k in ("disc_grad_penalty", "disc_logit_loss", "disc_agent_acc", "disc_demo_acc", "disc_agent_logit", "disc_demo_logit"):
+        assert torch.equal(got[k], ref[k]), k
+    for (n1, p1), (n2, p2) in zip(disc.named_parameters(), net.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1
+    # rewards (eval-mode normaliser) and the 0.5 / 0.5 mix
+    ref_rms.eval()
+    amp = torch.randn(50, d) * 2
+    with torch.no_grad():
+        r_ref = agent._calc_amp_rewards(amp)["disc_rewards"]
+    r_got = AO.oracle_disc_rewards(disc, orc_rms, amp, 2.0)
+    assert torch.equal(r_got, r_ref)
+    task_r = torch.rand(50, 1)
+    assert torch.equal(agent._combine_rewards(task_r, {"disc_rewards": r_ref}), 0.5 * task_r + 0.5 * r_ref)
+
+
+def _z_pair():
+    torch.manual_seed(1)
+    orc = AO.OracleNetZ(units=(72, 56, 40), task_units=(64, 48, 32))
+    m = refload.learning_methods()
+    ref = copy.deepcopy(orc)
+    _bind(ref, m["ampz_net"])
+    for k, v in dict(actor_cnn=nn.Sequential(), critic_cnn=nn.Sequential(), has_rnn=False, proj_norm=True, z_type="vae",
+                     use_vae_clamped_prior=True, vae_var_clamp_max=orc.var_clamp_max, use_vae_sphere_posterior=False, z_all=False,
+                     is_discrete=False, is_multi_discrete=False, is_continuous=True, mu_act=nn.Identity(), sigma_act=nn.Identity(),
+                     value_act=nn.Identity(), space_config={"fixed_sigma": True}, use_vae_prior=True, use_vae_fixed_prior=False,
+                     embedding_norm=1, z_noise=None).items():      # z_noise: left over from an earlier rollout forward in the reference
+        setattr(ref, k, v)
+    return orc, ref
+
+
+def test_pulse_vae_network_matches_reference_methods():
+    orc, ref = _z_pair()
+    b = 45
+    obs = torch.randn(b, 934).clamp(-5, 5)
+    noise = torch.randn(b, 32)
+    ref.train(); orc.train()
+    mu_r, sig_r, extra_r = ref.eval_actor({"obs": obs, "z_noise": noise}, return_extra=True)
+    mu_o, sig_o, extra_o = orc.eval_actor(obs, noise)
+    assert torch.equal(mu_o, mu_r) and torch.equal(extra_o["vae_mu"], extra_r["vae_mu"]) and torch.equal(extra_o["vae_log_var"], extra_r["vae_log_var"])
+    assert torch.equal(sig_o, sig_r)
+    pm_r, pv_r = ref.compute_prior({"obs": obs})
+    pm_o, pv_o = orc.compute_prior(obs)
+    assert torch.equal(pm_o, pm_r) and torch.equal(pv_o, pv_r)
+    assert torch.equal(orc.eval_critic(obs), ref.eval_critic({"obs": obs}))
+    assert (extra_r["vae_log_var"] <= orc.var_clamp_max).all() and (extra_r["vae_log_var"] >= -5).all()
+
+
+def test_optimize_kin_matches_reference_method():
+    orc, ref = _z_pair()
+    m = refload.learning_methods()
+    horizon, nseq = 8, 6
+    mb = horizon * nseq
+    torch.manual_seed(2)
+    obs = torch.randn(mb, 934).clamp(-5, 5)
+    noise = torch.randn(mb, 32)
+    gt = (0.4 * torch.randn(mb, 69)).clamp(-1, 1)
+    prog = (torch.arange(horizon).repeat(nseq, 1) + torch.randint(0, 50, (nseq, 1)))
+    prog[2, 4:] = torch.arange(horizon - 4)                                  # an episode seam inside a sequence
+    prog[4, :] = torch.arange(horizon)                                       # sequence that starts at progress 0 (<= 2 masking)
+    prog = prog.reshape(-1)
+    env = types.SimpleNamespace(distill=True, z_type="vae", use_vae_prior=True, use_vae_fixed_prior=False, use_ar1_prior=True,
+                                use_vae_prior_regu=True, kld_coefficient=0.01, ar1_coefficient=0.005, kld_anneal=True, kld_coefficient_min=0.001)
+    ref.train()
+    opt = torch.optim.Adam(ref.parameters(), 5e-4)
+    kin_flat = torch.cat([gt, prog.float().unsqueeze(-1)], dim=-1)
+    agent = types.SimpleNamespace(vec_env=types.SimpleNamespace(env=types.SimpleNamespace(task=env)), model=types.SimpleNamespace(a2c_network=ref, parameters=ref.parameters),
+                                  minibatch_size=mb, horizon_length=horizon, epoch_num=3000, grad_norm=50.0, kin_optimizer=opt,
+                                  kin_dict_info={"gt_action": ((mb, 69), (mb, 69)), "progress_buf": ((mb,), (mb, 1))})
+    _bind(agent, m["agent"])
+    before = {k: v.detach().clone() for k, v in ref.named_parameters()}
+    info_r = agent._optimize_kin({"obs": obs, "z_noise": noise, "kin_dict": kin_flat})
+    # oracle: same loss, gradients left in the net; replay the reference's clip + Adam step on them
+    orc.train()
+    info_o = AO.oracle_optimize_kin(orc, obs, gt, prog.float(), noise, horizon, kld_coefficient=0.01, ar1_coefficient=0.005,
+                                    use_ar1_prior=True, use_vae_prior_regu=True)
+    for k in ("kin_action_loss", "kin_KLD", "kin_ar1", "kin_loss"):
+        assert torch.allclose(info_o[k], info_r[k].detach(), rtol=0, atol=0), k
+    assert abs(env.kld_coefficient - ((0.01 - 0.001) * max((5000 - 3000) / 2500, 0) + 0.001)) < 1e-12      # annealing mutated the env (:826-832)
+    opt_o = torch.optim.Adam(orc.parameters(), 5e-4)
+    nn.utils.clip_grad_norm_(orc.parameters(), 50.0)
+    opt_o.step()
+    changed = 0
+    for (n1, p1), (n2, p2) in zip(orc.named_parameters(), ref.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+        changed += int(not torch.equal(p2, before[n2]))
+    assert changed > 10
+
+
+class _PassThroughScaler:
+    """torch.cuda.amp.GradScaler(enabled=False) behaviour: everything is the identity."""
+    def scale(self, x): return x
+    def unscale_(self, opt): pass
+    def step(self, opt): opt.step()
+    def update(self): pass
+
+
+def test_whole_calc_gradients_matches_reference_method():
+    """The reference's ENTIRE AMPAgent.calc_gradients body (PPO + discriminator branch) on stubs vs oracle_amp_calc_gradients:
+    parameters after the optimiser step, the three normalisers and the reported losses agree bit for bit."""
+    m = refload.learning_methods()
+    rms_mod = refload.importable_modules()["running_mean_std"]
+    torch.manual_seed(3)
+    obs_dim, amp_dim, mb, b, acts = 934, 40, 96, 32, 69
+    cfg = {"e_clip": 0.2, "critic_coef": 5.0, "entropy_coef": 0.0, "bounds_loss_coef": 10.0, "disc_coef": 5.0, "disc_logit_reg": 0.01,
+           "disc_grad_penalty": 5.0, "disc_weight_decay": 0.0001, "grad_norm": 50.0, "amp_minibatch_size": b, "clip_value": False}
+
+    def make():
+        torch.manual_seed(4)
+        net = AO.OracleNet(obs_dim, acts, [48, 32])
+        disc = AO.OracleDisc(amp_dim, units=(24, 16))
+        return AO.OracleAMPModel(net, disc)
+
+    model_o, model_r = make(), make()
+    _bind(model_r.disc, m["amp_net"])
+    model_r.a2c_network.eval_disc = model_r.disc.eval_disc
+    model_r.a2c_network.get_disc_logit_weights = model_r.disc.get_disc_logit_weights
+    model_r.a2c_network.get_disc_weights = model_r.disc.get_disc_weights
+    warm_obs, warm_amp = torch.randn(300, obs_dim) * 1.5 + 0.2, torch.randn(300, amp_dim) * 2 - 0.3
+
+    def norms(cls_obs, cls_amp):
+        r, a = cls_obs((obs_dim,)), cls_amp((amp_dim,))
+        r.train(); a.train()
+        r(warm_obs); a(warm_amp)
+        t = copy.deepcopy(r)
+        t.freeze()
+        return r, t, a
+
+    rms_o, tmp_o, amp_o = norms(AO.OracleRunningMeanStd, AO.OracleRunningMeanStd)
+    rms_r, tmp_r, amp_r = norms(rms_mod.RunningMeanStd, rms_mod.RunningMeanStd)
+    d = {"obs": torch.randn(mb, obs_dim) * 1.5, "actions": torch.randn(mb, acts) * 0.3, "old_values": torch.randn(mb, 1), "returns": torch.randn(mb, 1),
+         "old_logp_actions": torch.randn(mb) * 0.1 + 60.0, "advantages": torch.randn(mb), "mu": torch.randn(mb, acts) * 0.1,
+         "sigma": torch.full((mb, acts), 0.055), "amp_obs": torch.randn(mb, amp_dim) * 2, "amp_obs_replay": torch.randn(mb, amp_dim) * 2,
+         "amp_obs_demo": torch.randn(mb, amp_dim) * 2}
+    opt_o = torch.optim.Adam(model_o.parameters(), 2e-5, eps=1e-08)
+    opt_r = torch.optim.Adam(model_r.parameters(), 2e-5, eps=1e-08)
+    out_o = AO.oracle_amp_calc_gradients(model_o, opt_o, rms_o, tmp_o, amp_o, {k: v.clone() for k, v in d.items()}, cfg)
+    task = types.SimpleNamespace(_num_amp_obs_steps=10)
+    agent = types.SimpleNamespace(
+        vec_env=types.SimpleNamespace(env=types.SimpleNamespace(task=task)), model=model_r, optimizer=opt_r, scaler=_PassThroughScaler(),
+        running_mean_std=rms_r, running_mean_std_temp=tmp_r, _amp_input_mean_std=amp_r, normalize_input=True, _normalize_amp_input=True,
+        temp_running_mean=True, _amp_minibatch_size=b, last_lr=2e-5, e_clip=0.2, only_kin_loss=False, save_kin_info=False, is_rnn=False,
+        mixed_precision=False, multi_gpu=False, truncate_grads=True, grad_norm=50.0, critic_coef=5.0, entropy_coef=0.0, bounds_loss_coef=10.0,
+        clip_value=False, _disc_coef=5.0, _disc_logit_reg=0.01, _disc_grad_penalty=5.0, _disc_weight_decay=0.0001, horizon_length=32,
+        set_train=lambda: (model_r.train(), rms_r.train(), amp_r.train()))
+    _bind(agent, m["agent"])
+    agent.calc_gradients({k: v.clone() for k, v in d.items()})
+    tr = agent.train_result
+    for (n1, p1), (n2, p2) in zip(model_o.named_parameters(), model_r.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    for o, r in ((rms_o, rms_r), (amp_o, amp_r)):
+        assert torch.equal(o.running_mean, r.running_mean) and torch.equal(o.running_var, r.running_var) and torch.equal(o.count, r.count)
+    assert float(amp_r.count) == 301 + 3 * b and float(rms_r.count) == 301 + mb
+    for k in ("actor_loss", "critic_loss", "b_loss", "kl", "disc_loss", "disc_grad_penalty"):
+        assert torch.equal(out_o[k], tr[k].detach()), k
+
+
+class _ExperienceBuffer:
+    """rl_games ExperienceBuffer surface used by play_steps (update_data / tensor_dict / get_transformed_list), (T, N, .) tensors."""
+    def __init__(self, tensors):
+        self.tensor_dict = tensors
+
+    def update_data(self, name, index, val):
+        self.tensor_dict[name][index, :] = val
+
+    def get_transformed_list(self, op, names):
+        return {k: op(self.tensor_dict[k]) for k in names if k in self.tensor_dict}
+
+
+def test_whole_play_steps_matches_reference_method():
+    """The reference's ENTIRE AMPAgent.play_steps body (with CommonAgent.get_action_values / _eval_critic / discount_values, all from
+    source) on stubs vs OracleCommonAgent.play_steps over the same recorded env: every rollout tensor and the returns agree bit for bit."""
+    from pulse_amd import configs, synthetic as syn
+    from pulse_amd.env.sim import RecordedRollout
+    m = refload.learning_methods()
+    rms_mod = refload.importable_modules()["running_mean_std"]
+    cfg, _ = configs.agent_config("cfg1")
+    n, t, amp_dim = 24, 6, 20
+    cfg["horizon_length"] = t
+    cfg["minibatch_size"] = n * t
+    rollout = RecordedRollout(n, t + 1, seed=11, done_rate=0.15)
+    units = [40, 24]
+    torch.manual_seed(5)
+    orc = AO.OracleCommonAgent(cfg, AO.OracleEnv(copy.deepcopy(rollout), syn.RESET_BODY_IDS, list(range(24))), units, seed=1)
+    warm = torch.randn(100, 934)
+    orc.running_mean_std.train(); orc.running_mean_std(warm)
+    orc.value_mean_std.train(); orc.value_mean_std(torch.randn(100, 1) * 3 + 1)
+    # ---- reference side: same weights / statistics, real RunningMeanStd modules
+    model = copy.deepcopy(orc.model)
+    disc = _bind(AO.OracleDisc(amp_dim, units=(8, 8)), m["amp_net"])
+    # _eval_critic / _eval_disc reach model.a2c_network.{eval_critic(obs_dict), eval_disc}; model.is_rnn() is rl_games plumbing
+    net_eval_critic = model.eval_critic
+    object.__setattr__(model, "a2c_network", types.SimpleNamespace(eval_critic=lambda d: net_eval_critic(d["obs"]), eval_disc=disc.eval_disc))
+    object.__setattr__(model, "is_rnn", lambda: False)
+    rms, vms, arms = rms_mod.RunningMeanStd((934,)), rms_mod.RunningMeanStd((1,)), rms_mod.RunningMeanStd((amp_dim,))
+    for dst, src in ((rms, orc.running_mean_std), (vms, orc.value_mean_std)):
+        dst.running_mean, dst.running_var, dst.count = src.running_mean.clone(), src.running_var.clone(), src.count.clone()
+    env = AO.OracleEnv(copy.deepcopy(rollout), syn.RESET_BODY_IDS, list(range(24)))
+    amp_frames = torch.randn(t, n, amp_dim)
+    step_i = [0]
+
+    def env_step(actions):
+        obs, rew, dones, infos = env.step(torch.clamp(actions, -1.0, 1.0))          # A2CBase.env_step: clamp + rescale (+-1 spaces)
+        infos = dict(infos, amp_obs=amp_frames[step_i[0]])
+        step_i[0] += 1
+        return {"obs": obs}, rew.unsqueeze(1), dones, infos
+
+    z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype)
+    tensors = {"obses": z(t, n, 934), "rewards": z(t, n, 1), "values": z(t, n, 1), "neglogpacs": z(t, n), "dones": z(t, n, dtype=torch.uint8),
+               "actions": z(t, n, 69), "mus": z(t, n, 69), "sigmas": z(t, n, 69), "next_obses": z(t, n, 934), "next_values": z(t, n, 1),
+               "amp_obs": z(t, n, amp_dim)}
+    meter = types.SimpleNamespace(update=lambda v: None)
+    agent = types.SimpleNamespace(
+        vec_env=types.SimpleNamespace(env=types.SimpleNamespace(task=types.SimpleNamespace(viewer=None))), model=model,
+        experience_buffer=_ExperienceBuffer(tensors), update_list=["actions", "neglogpacs", "values", "mus", "sigmas"],
+        tensor_list=["actions", "neglogpacs", "values", "mus", "sigmas", "obses", "states", "dones", "next_obses", "amp_obs"],
+        horizon_length=t, num_actors=n, num_agents=1, device="cpu", ppo_device="cpu", batch_size=n * t, use_action_masks=False,
+        has_central_value=False, only_kin_loss=False, save_kin_info=False, rewards_shaper=lambda r: r, normalize_input=True, normalize_value=True,
+        running_mean_std=rms, value_mean_std=vms, _amp_input_mean_std=arms, _normalize_amp_input=True, rnn_states=None, gamma=cfg["gamma"],
+        tau=cfg["tau"], _task_reward_w=1.0, _disc_reward_w=0.0, _disc_reward_scale=2.0, current_rewards=z(n, 1), current_lengths=z(n),
+        game_rewards=meter, game_lengths=meter, algo_observer=types.SimpleNamespace(process_infos=lambda infos, idx: None),
+        env_reset=lambda ids: {"obs": env.reset(ids)}, env_step=env_step, dones=None, obs=None,
+        set_eval=lambda: (model.eval(), rms.eval(), vms.eval(), arms.eval()))
+    _bind(agent, m["agent"])
+    agent._norm_disc_reward = lambda: False
+    torch.manual_seed(6)
+    ref = agent.play_steps()
+    torch.manual_seed(6)
+    got = orc.play_steps()
+    for k in ("obses", "actions", "neglogpacs", "values", "mus", "sigmas", "dones", "next_obses", "returns"):
+        assert torch.equal(got[k], ref[k]), k
+    assert torch.equal(ref["mb_rewards"], AO.swap_and_flatten01(orc.tensor_dict["rewards"]))       # 1.0 * task + 0.0 * disc
+    assert torch.equal(orc.tensor_dict["next_values"], tensors["next_values"])
+    assert ref["dones"].sum() > 0 and ref["played_frames"] == n * t
+    assert torch.equal(ref["disc_rewards"].reshape(-1), AO.oracle_disc_rewards(disc, arms, AO.swap_and_flatten01(amp_frames), 2.0).reshape(-1))

@@ -612,3 +612,29 @@ def oracle_amp_calc_gradients(model, optimizer, rms, rms_temp, amp_rms, d, cfg):
     optimizer.step()
     return {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl,
             "disc_loss": disc_loss.detach(), "disc_grad_penalty": penalty.detach(), "grad_norm": gn}
+
+
+def oracle_pnn_teacher_action(pnn_model, composer_model, num_prim, activation, obs, running_mean, running_var):
+    """HumanoidImDistill.step's gt_action (phc/env/tasks/humanoid_im_distill.py:165-198, has_pnn branch, same obs settings for teacher
+    and student) over load_pnn / load_mcp_mlp-shaped state dicts (phc/learning/network_loader.py:11-73; PNN without lateral links,
+    phc/learning/pnn.py:125-131)."""
+    act = {"relu": nn.ReLU, "silu": nn.SiLU}[activation]
+
+    def seq(model, prefix, trailing_act):
+        layers, i = [], 0
+        while f"{prefix}.{2 * i}.weight" in model:
+            w, b = model[f"{prefix}.{2 * i}.weight"], model[f"{prefix}.{2 * i}.bias"]
+            lin = nn.Linear(w.shape[1], w.shape[0])
+            with torch.no_grad():
+                lin.weight.copy_(w); lin.bias.copy_(b)
+            layers += [lin, act()]
+            i += 1
+        if not trailing_act:
+            layers = layers[:-1]
+        return nn.Sequential(*layers)
+
+    with torch.no_grad():
+        full_obs = torch.clamp((obs - running_mean.float()) / torch.sqrt(running_var.float() + 1e-05), min=-5.0, max=5.0)
+        x_all = torch.stack([seq(pnn_model, f"a2c_network.pnn.actors.{k}", False)(full_obs) for k in range(num_prim)], dim=1)
+        weights = seq(composer_model, "a2c_network.composer", True)(full_obs)
+        return torch.sum(weights[:, :, None] * x_all, dim=1)

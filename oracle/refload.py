@@ -206,6 +206,29 @@ def humanoid_im_methods():
     return _cache["him"]
 
 
+def pnn_reference():
+    """load_pnn / load_mcp_mlp (phc/learning/network_loader.py:11-73) and the PNN class body (phc/learning/pnn.py:9-131), rebuilt on
+    nn.Module with the rl_games activation factory stubbed by torch_utils.activation_facotry."""
+    if "pnn" in _cache:
+        return _cache["pnn"]
+    import collections
+    import torch
+    ns = _namespace()
+    tu = torch_utils()
+    ns.update({"defaultdict": collections.defaultdict, "edict": None})
+    methods = _extract(os.path.join(REFERENCE_ROOT, "phc", "learning", "pnn.py"), ["__init__", "freeze_pnn", "_build_sequential_mlp", "forward"], methods_of="PNN")
+    body = {}
+    for name, text in methods.items():
+        exec(compile(text, f"<reference:PNN.{name}>", "exec"), ns, body)
+    body["activations_factory"] = types.SimpleNamespace(create=lambda name: tu.activation_facotry(name)())
+    ns["PNN"] = type("PNN", (torch.nn.Module,), body)
+    srcs = _extract(os.path.join(REFERENCE_ROOT, "phc", "learning", "network_loader.py"), ["load_mcp_mlp", "load_pnn"])
+    for name, text in srcs.items():
+        exec(compile(text, f"<reference:{name}>", "exec"), ns)
+    _cache["pnn"] = {"PNN": ns["PNN"], "load_pnn": ns["load_pnn"], "load_mcp_mlp": ns["load_mcp_mlp"]}
+    return _cache["pnn"]
+
+
 class _AttrDict(dict):
     """easydict.EasyDict stand-in (easydict is not installed): attribute access on a dict."""
     __getattr__ = dict.__getitem__

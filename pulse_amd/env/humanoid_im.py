@@ -135,9 +135,14 @@ class HumanoidIm:
         if self.save_kin_info:        # HumanoidImDistill.kin_dict (humanoid_im_distill.py:73-80, 204-205)
             self.kin_dict = {"gt_action": torch.zeros(n, self.num_actions, device=dev),
                              "progress_buf": torch.zeros(n, dtype=torch.int64, device=dev)}
+        self._teacher = None
         self.humanoid_type = "smpl"
         self.has_task = True
         self.viewer = None
+
+    def attach_teacher(self, teacher):
+        """HumanoidImDistill (humanoid_im_distill.py:44-63): the frozen policy whose action is the distillation target."""
+        self._teacher = teacher
 
     # ------------------------------------------------------------------ reference motion from the HBM-resident library
     def _init_motion_clock(self, env):
@@ -246,7 +251,8 @@ class HumanoidIm:
         if self.save_kin_info:
             # the distillation target for THIS observation is produced before physics advances
             # (HumanoidImDistill.step, humanoid_im_distill.py:143-231; the teacher itself is out of scope)
-            self.kin_dict["gt_action"] = self.sim.gt_action
+            # the frozen PHC teacher (learning/teacher.py) when one is attached; a recorded stand-in otherwise
+            self.kin_dict["gt_action"] = self._teacher.forward(self._obs_store) if self._teacher is not None else self.sim.gt_action
             self.kin_dict["progress_buf"] = self.progress_buf.clone()
             self.extras["kin_dict"] = self.kin_dict
         self.pre_physics_step(actions)

@@ -56,9 +56,14 @@ class ParamBook:
         self._n += rows * pitch
         return p
 
-    def finalize(self):
+    def finalize(self, trainable=True):
+        """``trainable=False``: a frozen network (teacher / decoder-in-env) only needs the parameter buffer."""
         self.n_flat = r4(self._n)
         z = lambda: torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
+        if not trainable:
+            self.flat = z()
+            self.grad = self.exp_avg = self.exp_avg_sq = self.slabs = None
+            return self
         self.flat, self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
         self.slabs = torch.zeros(self.split_k, self.n_flat, dtype=torch.float32, device=self.device)
         self.sq_partials = torch.zeros(256, device=self.device)
@@ -188,7 +193,8 @@ class MlpGraph:
         return lins
 
     # ---- plans -----------------------------------------------------------------------------------------
-    def forward_plan(self, tags=None):
+    def forward_plan(self, tags=None, store_pre=True):
+        """``store_pre=False``: inference only -- SiLU layers do not keep their pre-activation."""
         p = K.Plan()
         f = self.book.flat
         for op in self.ops:
@@ -196,7 +202,7 @@ class MlpGraph:
                 continue
             lin = op["lin"]
             x, y = self.act_bufs[op["src"]], self.act_bufs[op["dst"]]
-            c2 = self.pre(op["dst"]) if lin.act == ACT_SILU else None
+            c2 = self.pre(op["dst"]) if (lin.act == ACT_SILU and store_pre) else None
             p.gemm(x, f, y, M=self.m, N=lin.n, K=lin.k_phys, lda=x.stride(0), ldb=lin.w.pitch, ldc=y.stride(0), bias=f,
                    activation=lin.act, a_off=op["src_col"], b_off=lin.w.off, bias_off=lin.b.off, c_off=op["dst_col"],
                    C2=c2, ldc2=c2.stride(0) if c2 is not None else 0, c2_off=op["dst_col"], algo_k=lin.k_logical)

@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock bound of the CPU baseline subprocess (s)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket GEMM launches with events")
+    ap.add_argument("--keep-gc", action="store_true", help="leave Python's cyclic garbage collector running during the timed region")
     return ap.parse_args()
 
 
@@ -157,6 +158,14 @@ def main():
     if world > 1:
         dist.setup_algo(agent.model.flat, (agent.model.sigma, agent.exp_avg, agent.exp_avg_sq))
 
+    if not a.keep_gc:
+        # A generation-2 collection walks every live object (hundreds of thousands here: tensors, ctypes descriptors, plans) and
+        # stalls the launch thread for tens of ms -- long enough for the GPU queue to run dry.  The training loop creates no
+        # reference cycles that matter, so the collector is parked for the run (reference counting still frees everything).
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
     log(f"rank {rank}: agent ready, warmup")
     for _ in range(a.warmup):
         agent.train_epoch()
@@ -166,12 +175,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     play = upd = 0.0
+    per_step = []
     for step in range(a.steps):
         if step == a.steps - 1 and not a.no_roofline:
             prof.start()      # the LAST timed step carries the HIP-event brackets (an event pair costs ~10 us of stream time per GEMM)
         info = agent.train_epoch()
         play += info["play_time"]
         upd += info["update_time"]
+        per_step.append((round(1e3 * info["play_time"], 2), round(1e3 * info["update_time"], 2)))
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -189,7 +200,7 @@ def main():
                    "num_envs_per_gpu": num_envs, "horizon": T, "global_batch": T * num_envs * world, "parallelism": f"dp{world}",
                    "reference_motion": "HBM-resident motion library (1024 clips), queried every step" if a.reference == "motion_lib"
                    else "pre-recorded reference frames"},
-        "play_ms_per_step": 1e3 * play / a.steps, "update_ms_per_step": 1e3 * upd / a.steps,
+        "play_ms_per_step": 1e3 * play / a.steps, "update_ms_per_step": 1e3 * upd / a.steps, "per_step_play_update_ms": per_step,
     }
     if not a.no_roofline:
         s = prof.summary()

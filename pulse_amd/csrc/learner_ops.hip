@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __
 // 16-byte variant of the wide kernel: each thread owns groups of 4 adjacent columns (a wave reads 1 KiB
 // of a row per instruction).  Needs 16-byte aligned rows on both sides and y_cols % 4 == 0.
 constexpr int kRmsVecGroups = 3;   // 256 threads x 4 columns x 3 groups = 3072 columns
+constexpr int kRmsRowsPerPass = 64;
 
 __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,
@@ -108,27 +109,48 @@ __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __
             if (c < cols) { mu[j][k] = (float)mean[c]; den[j][k] = sqrtf((float)var[c] + eps); }
             else { mu[j][k] = 0.f; den[j][k] = 1.f; }
         }
-    for (int r = r0; r < r1; ++r) {
-        const long long src = row_idx ? row_idx[r] : (long long)r;
-        const float* xr = x + src * x_stride;
-        float* yr = y + (long long)r * y_stride;
+    // the gather indices of this block's rows go through LDS once (a dependent index load per row would put a full
+    // memory latency in front of every row), then rows are processed two at a time so two rows' loads are in flight
+    __shared__ long long s_src[kRmsRowsPerPass];
+    for (int rb = r0; rb < r1; rb += kRmsRowsPerPass) {
+        const int nr = min(kRmsRowsPerPass, r1 - rb);
+        __syncthreads();
+        if (tid < nr) s_src[tid] = row_idx ? row_idx[rb + tid] : (long long)(rb + tid);
+        __syncthreads();
+        for (int q = 0; q < nr; q += 2) {
+            const bool two = q + 1 < nr;
+            const float* xr0 = x + s_src[q] * x_stride;
+            const float* xr1 = x + s_src[two ? q + 1 : q] * x_stride;
+            float4 v0[kRmsVecGroups], v1[kRmsVecGroups];
 #pragma unroll
-        for (int j = 0; j < kRmsVecGroups; ++j) {
-            const int c = (tid + 256 * j) * 4;
-            if (c < y_cols) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < cols) v = *reinterpret_cast<const float4*>(xr + c);      // x rows are padded to the same pitch
-                float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+            for (int j = 0; j < kRmsVecGroups; ++j) {
+                const int c = (tid + 256 * j) * 4;
+                v0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                v1[j] = v0[j];
+                if (c < cols) { v0[j] = *reinterpret_cast<const float4*>(xr0 + c); v1[j] = *reinterpret_cast<const float4*>(xr1 + c); }
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (c + k < cols) {
-                        s1[j][k] += (double)in[k]; s2[j][k] += (double)in[k] * (double)in[k];
-                        o[k] = mode == 0 ? clampf((in[k] - mu[j][k]) / den[j][k], -clip, clip) : den[j][k] * clampf(in[k], -clip, clip) + mu[j][k];
-                    } else {
-                        o[k] = 0.f;
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two) break;
+                float* yr = y + (long long)(rb + q + h) * y_stride;
+#pragma unroll
+                for (int j = 0; j < kRmsVecGroups; ++j) {
+                    const int c = (tid + 256 * j) * 4;
+                    if (c < y_cols) {
+                        const float4 v = h == 0 ? v0[j] : v1[j];
+                        float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (c + k < cols) {
+                                s1[j][k] += (double)in[k]; s2[j][k] += (double)in[k] * (double)in[k];
+                                o[k] = mode == 0 ? clampf((in[k] - mu[j][k]) / den[j][k], -clip, clip) : den[j][k] * clampf(in[k], -clip, clip) + mu[j][k];
+                            } else {
+                                o[k] = 0.f;
+                            }
+                        }
+                        *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
-                *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -184,15 +206,15 @@ __global__ void __launch_bounds__(256) rms_normalize_narrow_kernel(const float* 
         for (int c = cols; c < y_cols; ++c) y[(long long)r * y_stride + c] = 0.f;
 }
 
-__global__ void __launch_bounds__(256) rms_update_kernel(double* __restrict__ mean, double* __restrict__ var, double* __restrict__ count_out,
+__global__ void __launch_bounds__(1024) rms_update_kernel(double* __restrict__ mean, double* __restrict__ var, double* __restrict__ count_out,
                                                         const double* __restrict__ partials, int nblk, int cols, double count,
                                                         double n) {
-    __shared__ double red[2][4][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;     // 64 columns x 16 groups over the partial blocks
     const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < cols) {
-        for (int b = pl; b < nblk; b += 4) {
+        for (int b = pl; b < nblk; b += 16) {
             s1 += partials[(long long)b * 2 * cols + c];
             s2 += partials[(long long)b * 2 * cols + cols + c];
         }
@@ -200,8 +222,9 @@ __global__ void __launch_bounds__(256) rms_update_kernel(double* __restrict__ me
     red[0][pl][cl] = s1; red[1][pl][cl] = s2;
     __syncthreads();
     if (pl == 0 && c < cols) {
-        s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        s1 = 0.0; s2 = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { s1 += red[0][g][cl]; s2 += red[1][g][cl]; }
         const double bm = s1 / n;
         // unbiased variance like torch.var: sum (x - mean)^2 / (n - 1)
         double bv = (s2 - n * bm * bm) / (n - 1.0);
@@ -480,7 +503,7 @@ int pulse_rms_update(double* mean, double* var, double* count_out, const double*
     if (cols == 0) return PULSE_OK;
     PULSE_REQUIRE(mean && var && moment_partials, "pulse_rms_update: null pointer");
     PULSE_REQUIRE(batch_count >= 2.0, "pulse_rms_update: batch of %g rows has no unbiased variance", batch_count);
-    hipLaunchKernelGGL(rms_update_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(s), mean, var, count_out, moment_partials, num_blocks,
+    hipLaunchKernelGGL(rms_update_kernel, dim3((cols + 63) / 64), dim3(1024), 0, as_stream(s), mean, var, count_out, moment_partials, num_blocks,
                        cols, count_old, batch_count);
     return check_launch("pulse_rms_update");
 }

@@ -142,7 +142,7 @@ def colsum_partial(x, m, n, ld, num_chunks, partial, ld_partial, x_off=0, partia
 def rms_normalize(x, mean, var, *, rows, cols, x_stride, y, y_stride, y_cols=None, row_idx=None, eps=1e-5, clip=5.0,
                   unnorm=False, moment_partials=None, num_blocks=None):
     if num_blocks is None:
-        num_blocks = max(1, min(256, rows // 32)) if moment_partials is None else moment_partials.shape[0]
+        num_blocks = max(1, min(512, rows // 16)) if moment_partials is None else moment_partials.shape[0]
     _lib.check(_lib.load().pulse_rms_normalize(_p(x), x_stride, _p(row_idx), rows, cols, _p(mean), _p(var), eps, clip,
                                                1 if unnorm else 0, _p(y), y_stride, cols if y_cols is None else y_cols,
                                                _p(moment_partials), num_blocks, _stream()), "pulse_rms_normalize")
@@ -229,3 +229,4 @@ def kinematic_sim_step(target_rb, noise_rb, rb, target_dof_pos, noise_dof_pos, d
     _lib.check(_lib.load().pulse_kinematic_sim_step(_p(target_rb), _p(noise_rb), _p(rb), n, j, _p(target_dof_pos), _p(noise_dof_pos),
                                                     _p(dof_pos), _p(target_dof_vel), _p(noise_dof_vel), _p(dof_vel), _p(force_src),
                                                     _p(dof_force), dof_pos.shape[1], _stream()), "pulse_kinematic_sim_step")
+

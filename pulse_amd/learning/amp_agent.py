@@ -83,7 +83,7 @@ class AMPAgent(CommonAgent):
         env_cfg = task.cfg.get("env", task.cfg)
         if config.get("use_seq_rl", False):
             self.dataset = rlg.AMPDataset(self.batch_size, self.minibatch_size, self.is_discrete, True, self.ppo_device, self.seq_len,
-                                          generator=self.dataset.generator)
+                                          generator=self.dataset.generator, permutation_device=self.dataset.permutation_device)
         self.save_kin_info = bool(env_cfg.get("save_kin_info", False))
         self.only_kin_loss = bool(env_cfg.get("only_kin_loss", False))
         self.temp_running_mean = bool(getattr(task, "temp_running_mean", True))

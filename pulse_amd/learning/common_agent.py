@@ -121,12 +121,13 @@ class CommonAgent:
         self.optimizer_step = 0
         self._sq_partials = torch.zeros(256, device=self.ppo_device)
         self._grad_norm = torch.zeros(1, device=self.ppo_device)
+        self._partials_ring, self._lazy_info, self._ring_pos = None, False, 0
         self._loss_partials = torch.zeros(max(1, min(512, self.minibatch_size // 16)), 8, device=self.ppo_device)
         self._adv_partials = torch.zeros(128, 2, dtype=torch.float64, device=self.ppo_device)
         perm_gen = torch.Generator()
         perm_gen.manual_seed(seed)
         self.dataset = rlg.AMPDataset(self.batch_size, self.minibatch_size, self.is_discrete, self.is_rnn, self.ppo_device, self.seq_len,
-                                      generator=perm_gen)
+                                      generator=perm_gen, permutation_device=config.get("permutation_device", "cuda"))
         self.game_rewards = rlg.AverageMeter((self.value_size,), self.games_to_track, self.ppo_device)
         self.game_lengths = rlg.AverageMeter((1,), self.games_to_track, self.ppo_device)
         self.train_result = {}
@@ -398,21 +399,63 @@ class CommonAgent:
                    old_neglogp=old_nlp, advantages=adv, old_values=old_val, returns=ret, rows=mb, num_actions=self.actions_num,
                    e_clip=self.e_clip, critic_coef=self.critic_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
                    dmu=ws["dmu"], dmu_stride=ws["dmu"].stride(0), dvalue=ws["dval"], dvalue_stride=ws["dval"].stride(0),
-                   partials=self._loss_partials)
+                   partials=self._loss_slot())
         net.backward(ws, mb, grad_scale=1.0 / self.world_size)
         extra_info = self._extra_gradients(input_dict, idx)               # AMPAgent: discriminator loss / gradients
         self._apply_gradients()
-        info = self._loss_partials.sum(0) / mb                          # [a_loss, c_loss, b_loss, clip_frac, kl]
+        info, gnorm = self._loss_info(mb)                               # [a_loss, c_loss, b_loss, clip_frac, kl]
         if self._entropy is None:
             ent = float((0.5 + 0.5 * math.log(2 * math.pi)) * self.actions_num) + float(net.sigma.sum().item())
             self._entropy = torch.tensor(ent, device=self.ppo_device)
         self.train_result = {"entropy": self._entropy, "kl": info[4], "last_lr": self.last_lr, "lr_mul": 1.0, "b_loss": info[2],
                              "actor_loss": info[0], "actor_clip_frac": info[3], "critic_loss": info[1],
-                             "grad_norm": self._grad_norm.clone()}
+                             "grad_norm": gnorm}
         self.train_result.update(extra_info)
 
     def _extra_gradients(self, input_dict, idx):
         return {}
+
+    # Per-minibatch loss statistics.  With a constant LR schedule nothing reads them inside the epoch, so the per-block partial
+    # sums of every minibatch are parked in a ring and reduced ONCE at the end of train_epoch (the dicts handed out meanwhile hold
+    # views of that epoch's result buffer); an adaptive schedule needs the KL right away and takes the eager path.
+    def _begin_loss_ring(self, slots):
+        self._lazy_info = not self.is_adaptive_lr
+        self._ring_pos, self._ring_mb = 0, []
+        if not self._lazy_info:
+            return
+        p = self._loss_partials.shape
+        if self._partials_ring is None or self._partials_ring.shape[0] < slots:
+            self._partials_ring = torch.zeros(slots, p[0], p[1], device=self.ppo_device)
+        self._info_all = torch.zeros(slots, p[1], device=self.ppo_device)        # fresh per epoch: last epoch's dicts stay valid
+        self._gn_all = torch.zeros(slots, device=self.ppo_device)
+
+    def _loss_slot(self):
+        if self._lazy_info and self._ring_pos < self._partials_ring.shape[0]:
+            return self._partials_ring[self._ring_pos]
+        return self._loss_partials
+
+    def _grad_norm_slot(self):
+        if self._lazy_info and self._ring_pos < self._gn_all.shape[0]:
+            return self._gn_all[self._ring_pos:self._ring_pos + 1]
+        return self._grad_norm
+
+    def _loss_info(self, mb):
+        if self._lazy_info and self._ring_pos < self._partials_ring.shape[0]:
+            i = self._ring_pos
+            self._ring_pos += 1
+            self._ring_mb.append(mb)
+            return self._info_all[i], self._gn_all[i]
+        return self._loss_partials.sum(0) / mb, self._grad_norm.clone()
+
+    def _end_loss_ring(self):
+        if self._lazy_info and self._ring_pos:
+            n = self._ring_pos
+            torch.sum(self._partials_ring[:n], dim=1, out=self._info_all[:n])
+            if len(set(self._ring_mb)) == 1:
+                self._info_all[:n] /= self._ring_mb[0]
+            else:
+                self._info_all[:n] /= torch.tensor(self._ring_mb, dtype=torch.float32, device=self.ppo_device)[:, None]
+        self._lazy_info = False
 
     def _param_groups(self):
         """(params, grads, exp_avg, exp_avg_sq, count) of every flat buffer the optimiser owns."""
@@ -434,7 +477,7 @@ class CommonAgent:
         for g in groups:
             K.adam_step(g[0], g[1], g[2], g[3], g[4], lr=self.last_lr, step=self.optimizer_step, weight_decay=self.weight_decay,
                         max_norm=self.grad_norm if self.truncate_grads else 0.0, sqnorm_partials=self._sq_partials,
-                        grad_norm_out=self._grad_norm)
+                        grad_norm_out=self._grad_norm_slot())
 
     # ------------------------------------------------------------------ epoch (common_agent.py:191-260)
     def train_epoch(self):
@@ -451,6 +494,7 @@ class CommonAgent:
         self.curr_frames = batch_dict.pop("played_frames")
         self.prepare_dataset(batch_dict)
         train_info = None
+        self._begin_loss_ring(self.mini_epochs_num * len(self.dataset))
         for _ in range(0, self.mini_epochs_num):
             for i in range(len(self.dataset)):
                 curr_train_info = self.train_actor_critic(self.dataset[i])
@@ -472,6 +516,7 @@ class CommonAgent:
                     av_kls = self.dist.average_value(av_kls, "ep_kls")
                 self.last_lr, self.entropy_coef = self.scheduler.update(self.last_lr, self.entropy_coef, self.epoch_num, 0, av_kls.item())
                 self.update_lr(self.last_lr)
+        self._end_loss_ring()
         torch.cuda.synchronize()
         update_time_end = time.time()
         self.epoch_counter += 1

@@ -78,7 +78,7 @@ class RunningMeanStd:
 
     # ---- forward ------------------------------------------------------------------------------
     def _moment_buffer(self, rows):
-        nblk = max(1, min(256, rows // 32))
+        nblk = max(1, min(512, rows // 16))
         if self._partials is None or self._partials.shape[0] != nblk:
             self._partials = torch.empty(nblk, 2, self.mean_size, dtype=torch.float64, device=self.device)
         return self._partials

@@ -26,7 +26,8 @@ def build_pair(name, dev, seed=7, epochs=1, **overrides):
     torch.manual_seed(seed)
     oenv = AO.OracleEnv(rollout_cpu, syn.RESET_BODY_IDS, list(range(24)))
     oracle = AO.OracleCommonAgent(cfg, oenv, cfg["network"]["mlp"]["units"], seed=seed, noise=noise)
-    agent, _ = configs.make_agent(name, device=str(dev), seed=seed, rollout=rollout_dev, **overrides)
+    # permutation_device="cpu": minibatches drawn on the host like the reference, so the shared seed reproduces the oracle's batches
+    agent, _ = configs.make_agent(name, device=str(dev), seed=seed, rollout=rollout_dev, permutation_device="cpu", **overrides)
     agent.model.load_state_dict(oracle.model.state_dict_ref())
     noise_dev = noise.to(dev)
     agent.noise_provider = lambda e, s: noise_dev[e, s]

@@ -1,0 +1,104 @@
+"""Per-kernel roofline of the HBM / latency-bound kernels at cfg2 sizes (dev tool; the official bench is bench.py).
+Each kernel is timed in isolation with HIP events on the launch stream; algorithmic bytes per launch are the ones DESIGN.md
+section 3 states.  Prints a markdown table (achieved GB/s vs the 8 TB/s HBM3E spec peak)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from pulse_amd import configs, kernels as K, ops
+from pulse_amd._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS
+
+dev = "cuda:0"
+PEAK = 8.0e12
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+rows = []
+
+
+def report(name, nbytes, t, unit_desc):
+    rows.append(f"| `{name}` | {unit_desc} | {nbytes / 1e6:.2f} | {t * 1e6:.1f} | {nbytes / t / 1e9:.0f} | {nbytes / t / PEAK:.3f} |")
+
+
+agent, _ = configs.make_agent("cfg2", device=dev, seed=1, reference="motion_lib")
+agent.init_tensors()
+agent.obs = agent.env_reset()
+task = agent.vec_env.env.task
+n, T = task.num_envs, agent.horizon_length
+for _ in range(3):
+    task.step(torch.zeros(n, 69, device=dev))
+full = PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS
+t = timeit(lambda: task._im_step(full, inc=0))
+report("im_step_kernel (library mode, reward+reset+obs)", n * (1248 + 552 + 4 * 1920 + 3840 + 40 + 1800 + 40), t, f"{n} envs")
+lib = task._motion_lib
+ids = task._sampled_motion_ids
+times = torch.rand(n, device=dev) * task._motion_len_env
+out = {}
+t = timeit(lambda: lib.query(ids, times, task._global_offset, out=out))
+report("motion_state_kernel (get_motion_state)", n * (2 * 1908 + 1848 + 20), t, f"{n} queries")
+rb, dp, dv = task.sim.rigid_body_state, task.sim.dof_pos, task.sim.dof_vel
+n2 = 8192
+rb2, dp2, dv2 = rb.repeat(2, 1, 1), dp.repeat(2, 1), dv.repeat(2, 1)
+key = torch.tensor([7, 3, 22, 17], dtype=torch.int32, device=dev)
+amp_out = torch.zeros(n2, 232, device=dev)
+t = timeit(lambda: ops.build_amp_observations_smpl(rb2, dp2, dv2, key, out=amp_out))
+report("amp_obs_kernel", n2 * (52 + 552 + 48 + 928), t, f"{n2} envs")
+mb = agent.minibatch_size
+eb = agent.experience_buffer
+idx = torch.randperm(n * T, device=dev)[:mb]
+ws = agent.model.workspace(mb, train=True)
+rms = agent.running_mean_std
+t = timeit(lambda: rms.forward(eb.flat("obses"), row_idx=idx, out=ws["x"], out_cols=agent.model.in_pitch, update=False))
+report("rms_normalize_vec4_kernel (gather + normalise, no moments)", mb * ((934 + 960) * 4 + 8), t, f"{mb} rows")
+t = timeit(lambda: rms.forward(eb.flat("obses"), row_idx=idx, out=ws["x"], out_cols=agent.model.in_pitch, update=True))
+report("rms_normalize_vec4 + rms_update (with fp64 moments)", mb * ((934 + 960) * 4 + 8), t, f"{mb} rows")
+td = eb.tensor_dict
+t = timeit(lambda: ops.discount_values(td["dones"], td["values"], td["rewards"], td["next_values"], 0.99, 0.95, return_returns=True))
+report("gae_kernel", n * T * 21, t, f"{T}x{n} elements")
+net = agent.model
+t = timeit(lambda: K.reduce_slabs(net._slabs, net.split_k, net.n_flat, net.n_flat, net.grad, scale=1.0))
+report("reduce_slabs_kernel (8 slabs)", net.n_flat * 4 * (net.split_k + 1), t, f"{net.n_flat} params")
+sq, gn = torch.zeros(256, device=dev), torch.zeros(1, device=dev)
+
+
+def opt():
+    K.sqnorm_partial(net.grad, net.n_flat, sq)
+    K.adam_step(net.flat, net.grad, agent.exp_avg, agent.exp_avg_sq, net.n_flat, lr=0.0, step=1, max_norm=50.0, sqnorm_partials=sq, grad_norm_out=gn)
+
+
+t = timeit(opt)
+report("sqnorm_partial + adam_kernel", net.n_flat * 4 * (1 + 4 + 3), t, f"{net.n_flat} params")
+vm = agent.value_mean_std
+wsr = net.workspace(n, train=False)
+mask = torch.zeros(n, dtype=torch.bool, device=dev)
+
+
+def rec():
+    K.rollout_record(rewards=task.rew_buf, dones=task.reset_buf, terminate=task._terminate_buf, value_raw=wsr["val"], value_stride=wsr["val"].stride(0),
+                     value_mean=vm.running_mean, value_var=vm.running_var, value_eps=vm.epsilon, buf_rewards=eb.phys["rewards"][:, 0],
+                     buf_next_values=eb.phys["next_values"][:, 0], buf_dones=eb.phys["dones"][:, 0], env_stride=T, current_rewards=agent.current_rewards,
+                     current_lengths=agent.current_lengths, meter_rewards=agent.game_rewards.state, meter_lengths=agent.game_lengths.state,
+                     meter_max_size=agent.games_to_track, done_mask=mask)
+
+
+t = timeit(rec)
+report("rollout_record_kernel (one workgroup)", n * 46, t, f"{n} envs")
+t = timeit(task.sim.simulate_and_refresh)
+report("kinematic_sim_kernel (physics stand-in)", n * (24 * 13 * 12 + 69 * 4 * 8), t, f"{n} envs")
+print("| kernel | units per launch | algorithmic MB per launch | us per launch | GB/s | frac of 8 TB/s |")
+print("|---|---|---|---|---|---|")
+print("\n".join(rows))

@@ -18,8 +18,13 @@ can call them exactly like the reference.
 
 Buffers: ``obs_buf`` (N, 934) float32 is a view of an (N, 960) allocation (GEMM-ready pitch, zero
 pad); ``rew_buf`` (N,), ``reset_buf`` / ``progress_buf`` / ``_terminate_buf`` (N,) int64.
-The simulator and the motion library are injected (pulse_amd/env/sim.py) because Isaac Gym is
-closed source and AMASS data is not redistributable -- both are OUT OF SCOPE of this build.
+The simulator is injected (pulse_amd/env/sim.py: Isaac Gym is closed source and OUT OF SCOPE).  The reference motion comes
+either from pre-recorded frames (RecordedMotion, what the CPU oracle agent replays) or from the HBM-resident ``MotionLib``
+(pulse_amd/env/motion_lib.py; AMASS data is not redistributable, so its clips are synthetic).  With the library the step
+kernel advances the episode clock, tests pass_time and blends its t / t+1 reference itself, a reset is one launch
+(new start time, flag clears, reference-state init), ``cycle_motion`` restarts finished motions in place and ``fut_tracks``
+samples future reference frames -- HumanoidIm.{_compute_task_obs, _compute_reward, _compute_reset, _reset_ref_state_init,
+_sample_time} (humanoid_im.py:652-654, 708-919, 920-926, 1119-1192) in three launches per control step.
 """
 import torch
 

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 8
+#define PULSE_ABI_VERSION 9
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -292,6 +292,7 @@ typedef struct pulse_rollout_record_args {
     float* meter_rewards; float* meter_lengths;          /* each: [mean, current_size] (AverageMeter state) */
     float meter_max_size;                                /* games_to_track */
     uint8_t* done_mask;               /* (N) out: dones != 0 (drives the next masked reset) */
+    uint8_t* buf_terminate;           /* optional, slot n like buf_dones: terminate != 0, for a bootstrap pass done after the rollout */
 } pulse_rollout_record_args;
 int pulse_sizeof_rollout_record_args(void);
 int pulse_rollout_record(const pulse_rollout_record_args* args, pulse_stream_t s);

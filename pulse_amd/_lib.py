@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -87,7 +87,7 @@ class RolloutRecordArgs(Structure):
                 ("value_mean", c_void_p), ("value_var", c_void_p), ("value_eps", c_float),
                 ("buf_rewards", c_void_p), ("buf_next_values", c_void_p), ("buf_dones", c_void_p), ("env_stride", c_int64),
                 ("current_rewards", c_void_p), ("current_lengths", c_void_p), ("meter_rewards", c_void_p), ("meter_lengths", c_void_p),
-                ("meter_max_size", c_float), ("done_mask", c_void_p)]
+                ("meter_max_size", c_float), ("done_mask", c_void_p), ("buf_terminate", c_void_p)]
 
 
 class GemmDesc(Structure):

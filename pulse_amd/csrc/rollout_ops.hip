@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(1024) rollout_record_kernel(const pulse_rollou
         const long long o = (long long)e * a.env_stride;
         a.buf_rewards[o] = (a.reward_scale == 1.f && a.reward_shift == 0.f) ? r : (r + a.reward_shift) * a.reward_scale;
         a.buf_dones[o] = done ? 1 : 0;
+        if (a.buf_terminate) a.buf_terminate[o] = a.terminate[e] != 0 ? 1 : 0;
         if (a.buf_next_values) {
             float v = a.value_raw[(long long)e * a.value_stride];
             if (a.value_mean) v = vs * fminf(fmaxf(v, -5.f), 5.f) + vm;
@@ -108,6 +109,7 @@ extern "C" int pulse_rollout_record(const pulse_rollout_record_args* args, pulse
     PULSE_REQUIRE(a.rewards && a.dones && a.buf_rewards && a.buf_dones && a.current_rewards && a.current_lengths && a.meter_rewards &&
                       a.meter_lengths && a.done_mask, "pulse_rollout_record: null pointer");
     PULSE_REQUIRE(a.buf_next_values == nullptr || (a.value_raw && a.terminate), "pulse_rollout_record: next_values needs value_raw and terminate");
+    PULSE_REQUIRE(a.buf_terminate == nullptr || a.terminate, "pulse_rollout_record: buf_terminate needs terminate");
     PULSE_REQUIRE((a.value_mean == nullptr) == (a.value_var == nullptr), "pulse_rollout_record: value_mean / value_var go together");
     PULSE_REQUIRE(a.env_stride >= 1 && a.meter_max_size >= 1.f, "pulse_rollout_record: bad env_stride / meter_max_size");
     hipLaunchKernelGGL(rollout_record_kernel, dim3(1), dim3(1024), 0, as_stream(s), a);

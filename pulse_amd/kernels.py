@@ -208,7 +208,7 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9,
 
 def rollout_record(*, rewards, dones, terminate, value_raw, value_stride, value_mean, value_var, value_eps, buf_rewards, buf_next_values,
                    buf_dones, env_stride, current_rewards, current_lengths, meter_rewards, meter_lengths, meter_max_size, done_mask,
-                   reward_scale=1.0, reward_shift=0.0):
+                   reward_scale=1.0, reward_shift=0.0, buf_terminate=None):
     """play_steps bookkeeping of one rollout step in one launch (include/pulse_hip.h section 2c)."""
     a = _lib.RolloutRecordArgs()
     a.num_envs = rewards.numel()
@@ -219,7 +219,7 @@ def rollout_record(*, rewards, dones, terminate, value_raw, value_stride, value_
     a.buf_rewards, a.buf_next_values, a.buf_dones, a.env_stride = _p(buf_rewards), _p(buf_next_values), _p(buf_dones), int(env_stride)
     a.current_rewards, a.current_lengths = _p(current_rewards), _p(current_lengths)
     a.meter_rewards, a.meter_lengths, a.meter_max_size = _p(meter_rewards), _p(meter_lengths), float(meter_max_size)
-    a.done_mask = _p(done_mask)
+    a.done_mask, a.buf_terminate = _p(done_mask), _p(buf_terminate)
     _lib.check(_lib.load().pulse_rollout_record(ctypes.byref(a), _stream()), "pulse_rollout_record")
 
 

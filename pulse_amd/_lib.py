@@ -178,6 +178,10 @@ def load():
     try:
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} does not exist")
+        # PyTorch ships its own libamdhip64; it must be the HIP runtime of the process (the streams and device pointers handed to
+        # this library are torch's).  Loading libpulse_hip.so first would pull in the system ROCm runtime instead and every launch
+        # would then fail with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -229,6 +229,24 @@ def pnn_reference():
     return _cache["pnn"]
 
 
+HUMANOID_AMP_METHODS = ["_update_hist_amp_obs", "_compute_amp_observations", "_compute_amp_observations_from_state", "_init_amp_obs",
+                        "_init_amp_obs_default", "_init_amp_obs_ref", "_get_state_from_motionlib_cache"]
+
+
+def humanoid_amp_methods():
+    """AMP-window methods of HumanoidAMP (phc/env/tasks/humanoid_amp.py:519-563, 622-680) extracted by name."""
+    if "hamp" in _cache:
+        return _cache["hamp"]
+    ns = _namespace()
+    ns.update(env_functions())
+    ns["flags"] = types.SimpleNamespace(test=False, real_traj=False)
+    srcs = _extract(os.path.join(REFERENCE_ROOT, "phc", "env", "tasks", "humanoid_amp.py"), HUMANOID_AMP_METHODS, methods_of="HumanoidAMP")
+    for name, text in srcs.items():
+        exec(compile(text, f"<reference:HumanoidAMP.{name}>", "exec"), ns)
+    _cache["hamp"] = {k: ns[k] for k in srcs}
+    return _cache["hamp"]
+
+
 class _AttrDict(dict):
     """easydict.EasyDict stand-in (easydict is not installed): attribute access on a dict."""
     __getattr__ = dict.__getitem__

@@ -222,11 +222,24 @@ class HumanoidIm:
                                         root_height_obs=self._amp_root_height_obs, out=self._curr_amp_obs_buf, env_mask=env_mask)
 
     def _init_amp_obs(self, mask):
-        """_init_amp_obs + _init_amp_obs_default (humanoid_amp.py:519-530): reset envs restart with a history of
-        copies of their first frame."""
+        """_init_amp_obs (humanoid_amp.py:519-563) for the masked envs.  Slot 0 is the current simulated frame.  With the motion
+        library the envs were reference-state initialised, so the history slots hold the AMP frames of the motion at
+        start - dt * (k + 1) (_init_amp_obs_ref, :531-563; times before the clip clamp to its first frame); with recorded
+        frames there is no motion to look back into and the history repeats the first frame (_init_amp_obs_default, :526-529)."""
         self._compute_amp_observations(env_mask=mask)
-        cur = self._curr_amp_obs_buf.unsqueeze(1).expand(-1, self._num_amp_obs_steps - 1, -1)
-        self._hist_amp_obs_buf.copy_(torch.where(mask[:, None, None], cur, self._hist_amp_obs_buf))
+        s = self._num_amp_obs_steps - 1
+        if self._use_motion_lib:
+            steps = -self.dt * (torch.arange(0, s, device=self.device) + 1)
+            times = (self._motion_start_times.unsqueeze(-1) + steps).view(-1)
+            n = self.num_envs
+            bufs = self._ref_bufs.setdefault("hist", {})
+            res = self._motion_lib.query(self._sampled_motion_ids.repeat_interleave(s), times, out=bufs, fields=("rb_records", "dof_pos", "dof_vel"))
+            hist = ops.build_amp_observations_smpl(res["rb_records"], res["dof_pos"], res["dof_vel"], self._key_body_ids, zero_joints=(),
+                                                   local_root_obs=self._local_root_obs, root_height_obs=self._amp_root_height_obs)
+            hist = hist.view(n, s, self._num_amp_obs_per_step)
+        else:
+            hist = self._curr_amp_obs_buf.unsqueeze(1).expand(-1, s, -1)
+        self._hist_amp_obs_buf.copy_(torch.where(mask[:, None, None], hist, self._hist_amp_obs_buf))
 
     def fetch_amp_obs_demo(self, num_samples):
         """humanoid_amp.py:215-284: AMP observation windows of reference motion (synthetic poses here)."""

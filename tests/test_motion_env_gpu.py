@@ -165,3 +165,32 @@ def test_reset_mode_matches_separate_ops(dev):
     assert torch.equal(sim.rigid_body_state, torch.where(mask[:, None, None], want["rb_records"], before["rb"]))
     assert torch.equal(sim.dof_pos, torch.where(mask[:, None], want["dof_pos"], before["dp"]))
     assert torch.equal(sim.dof_vel, torch.where(mask[:, None], want["dof_vel"], before["dv"]))
+
+
+def test_amp_window_lockstep_with_cpu_twin(dev):
+    """The (N, 10, 232) AMP observation window of the env (slot 0 = simulated frame, shifted every step, re-initialised from the
+    motion before the start time on reference-state resets) vs oracle/motion_oracle.py:OracleAmpHistory, which is pinned bit for
+    bit to HumanoidAMP's own methods (tests/test_oracle_env_vs_reference_methods.py)."""
+    from oracle.motion_oracle import OracleAmpHistory
+    n, seed = 45, 19
+    env, _ = configs.make_env(n, 12, dev, seed=seed, env_kind="amp", reference="motion_lib")
+    task = env.task
+    tabs = syn.synthetic_motion_library(syn.make_generator(seed + 5, 0), min(n, 1024))
+    twin = OracleAmpHistory(OracleMotionLib(tabs), task._sampled_motion_ids.cpu(), task._num_amp_obs_steps, task.dt, task._key_body_ids.cpu().long())
+    sim = task.sim
+    state = lambda: (sim.rigid_body_state.cpu().clone(), sim.dof_pos.cpu().clone(), sim.dof_vel.cpu().clone())
+    env.reset()
+    twin.reset(torch.arange(n), *state(), task._motion_start_times.cpu(), from_motion=True)
+    np.testing.assert_allclose(task._amp_obs_buf.cpu().numpy(), twin.buf.numpy(), atol=3e-5, rtol=1e-5)
+    assert not torch.equal(task._amp_obs_buf[:, 1], task._amp_obs_buf[:, 0])            # history comes from the motion, not copies of frame 0
+    n_reset = 0
+    for step in range(30):
+        obs, rew, done, info = env.step(torch.zeros(n, 69, device=dev))
+        want = twin.step(*state())
+        np.testing.assert_allclose(info["amp_obs"].cpu().numpy(), want.numpy(), atol=3e-5, rtol=1e-5, err_msg=f"amp_obs step {step}")
+        ids = torch.nonzero(done).flatten()
+        n_reset += ids.numel()
+        env.reset(ids)
+        twin.reset(ids.cpu(), *state(), task._motion_start_times.cpu(), from_motion=True)
+        np.testing.assert_allclose(task._amp_obs_buf.cpu().numpy(), twin.buf.numpy(), atol=3e-5, rtol=1e-5, err_msg=f"window after reset {step}")
+    assert n_reset > 0

@@ -80,3 +80,76 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps):
         assert checked_cycle > 0, "no motion was cycled in place"
     else:
         assert (twin.offset == 0).all()
+
+
+def test_amp_window_matches_reference_methods():
+    """OracleAmpHistory vs HumanoidAMP's own _compute_amp_observations / _update_hist_amp_obs / _init_amp_obs(_ref|_default) bodies."""
+    from oracle.motion_oracle import OracleAmpHistory
+    f = refload.humanoid_amp_methods()
+    n, S, dt = 21, 10, 2.0 / 60.0
+    g = syn.make_generator(8)
+    tabs = syn.synthetic_motion_library(g, n, 10, 24)
+    lib = _ref_motion_lib(tabs)
+    key = torch.tensor([7, 3, 22, 17])
+    twin = OracleAmpHistory(OracleMotionLib(tabs), torch.arange(n), S, dt, key)
+    W = 232
+    amp_buf = torch.zeros(n, S, W)
+    task = types.SimpleNamespace(
+        humanoid_type="smpl", dof_subset=None, _amp_obs_buf=amp_buf, _curr_amp_obs_buf=amp_buf[:, 0], _hist_amp_obs_buf=amp_buf[:, 1:],
+        _num_amp_obs_steps=S, dt=dt, device="cpu", _key_body_ids=key, _local_root_obs=True, _amp_root_height_obs=True, _has_dof_subset=False,
+        _has_shape_obs_disc=False, _has_limb_weight_obs_disc=False, _has_upright_start=True, amp_obs_v=1, humanoid_shapes=torch.zeros(n, 17),
+        humanoid_limb_and_weights=torch.zeros(n, 10), _motion_lib=lib, ref_motion_cache={}, gym=None, sim=None)
+    for k, fn in f.items():
+        setattr(task, k, types.MethodType(fn, task))
+
+    class _OverlapChecked:
+        """The history view with the partial-overlap check of the PyTorch the reference targets: `hist[:] = buf[:, 0:S-1]` raises
+        there ("some elements of the input tensor and the written-to tensor refer to a single memory location") and
+        _update_hist_amp_obs falls back to its `.clone()` form (humanoid_amp.py:624-627).  torch 2.10 on the CPU silently performs
+        the overlapping copy instead (a smeared, undefined result), which is not what the reference computes on its own stack."""
+
+        def __init__(self, view, whole):
+            self.view, self.whole = view, whole
+
+        def __setitem__(self, idx, val):
+            lo, hi = self.whole.data_ptr(), self.whole.data_ptr() + self.whole.numel() * 4
+            if isinstance(val, torch.Tensor) and lo <= val.data_ptr() < hi:
+                raise RuntimeError("unsupported operation: some elements of the input tensor and the written-to tensor refer to a single memory location")
+            self.view[idx] = val
+
+        def __getitem__(self, idx):
+            return self.view[idx]
+
+    task._hist_amp_obs_buf = _OverlapChecked(amp_buf[:, 1:], amp_buf)
+
+    def load_state(rb, dp, dv):
+        task._rigid_body_pos, task._rigid_body_rot, task._rigid_body_vel, task._rigid_body_ang_vel = rb[..., 0:3], rb[..., 3:7], rb[..., 7:10], rb[..., 10:13]
+        task._dof_pos, task._dof_vel = dp.clone(), dv.clone()                  # the reference zeroes toe / hand dofs IN PLACE
+
+    starts = OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g)
+    for step in range(6):
+        rb = syn.rigid_body_state(g, n)
+        dp, dv = 0.5 * torch.randn(n, 69, generator=g), torch.randn(n, 69, generator=g)
+        load_state(rb, dp, dv)
+        if step == 0:
+            env_ids = torch.arange(n)
+        elif step == 3:
+            env_ids = torch.tensor([1, 4, 5, 17])
+            starts = OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g)
+        else:
+            env_ids = None
+        if env_ids is not None:                                                # reset: _init_amp_obs with reference-state init
+            task._reset_default_env_ids, task._reset_ref_env_ids = [], env_ids
+            task._reset_ref_motion_ids, task._reset_ref_motion_times = torch.arange(n)[env_ids], starts[env_ids]
+            task._init_amp_obs(env_ids)
+            twin.reset(env_ids, rb, dp, dv, starts, from_motion=True)
+        else:                                                                  # HumanoidAMP.post_physics_step (:194-210)
+            task._update_hist_amp_obs()
+            task._compute_amp_observations()
+            twin.step(rb, dp, dv)
+        assert torch.equal(amp_buf, twin.buf), f"step {step}"
+    # default init (no motion to look back into)
+    task._reset_default_env_ids, task._reset_ref_env_ids = torch.tensor([0, 2]), []
+    task._init_amp_obs(torch.tensor([0, 2]))
+    twin.reset(torch.tensor([0, 2]), rb, dp, dv, starts, from_motion=False)
+    assert torch.equal(amp_buf, twin.buf)

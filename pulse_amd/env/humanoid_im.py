@@ -131,8 +131,19 @@ class HumanoidIm:
             self._amp_root_height_obs = bool(env.get("ampRootHeightObs", env.get("root_height_obs", True)))
             self._key_body_ids = torch.tensor([syn.SMPL_BODY_NAMES.index(b) for b in env.get("key_bodies", ["R_Ankle", "L_Ankle", "R_Wrist", "L_Wrist"])],
                                               dtype=torch.int32, device=dev)
-            self._amp_zero_joints = (3, 7, 17, 22)          # dofs 9:12, 21:24, 51:54, 66:69 read as zero (humanoid_amp.py:636-639)
-            self._num_amp_obs_per_step = ops.amp_obs_width(syn.NUM_DOF // 3, self._key_body_ids.numel(), self._amp_root_height_obs)
+            # dof_subset (humanoid.py:396-421): every joint but L_Hand / R_Hand / L_Toe / R_Toe; applied when the robot config says
+            # has_dof_subset (True in robot/smpl_humanoid.yaml:6) -> 19 joints, 196 floats per frame, 1960 per window.  For SMPL the
+            # subset tensor always exists, so the in-place zeroing of the toe / hand dofs (humanoid_amp.py:636-639, guarded by
+            # ``dof_subset is None``) never runs on this humanoid.
+            self._has_dof_subset = bool(env.get("has_dof_subset", True))
+            removed = {syn.SMPL_BODY_NAMES.index(b) - 1 for b in ("L_Hand", "R_Hand", "L_Toe", "R_Toe")}
+            nj = syn.NUM_DOF // 3
+            self._amp_joint_ids = [j for j in range(nj) if j not in removed] if self._has_dof_subset else None
+            self._amp_zero_joints = ()
+            self._num_amp_obs_per_step = ops.amp_obs_width(len(self._amp_joint_ids) if self._has_dof_subset else nj, self._key_body_ids.numel(),
+                                                           self._amp_root_height_obs)
+            if self._amp_joint_ids is not None:
+                self._amp_joint_ids = torch.tensor(self._amp_joint_ids, dtype=torch.int32, device=dev)
             self._amp_obs_buf = torch.zeros(n, self._num_amp_obs_steps, self._num_amp_obs_per_step, device=dev)
             self._curr_amp_obs_buf = self._amp_obs_buf[:, 0]
             self._hist_amp_obs_buf = self._amp_obs_buf[:, 1:]
@@ -218,7 +229,7 @@ class HumanoidIm:
     def _compute_amp_observations(self, env_mask=None):
         """humanoid_amp.py:632-667 -> current frame into slot 0 of the history."""
         ops.build_amp_observations_smpl(self.sim.rigid_body_state, self.sim.dof_pos, self.sim.dof_vel, self._key_body_ids,
-                                        zero_joints=self._amp_zero_joints, local_root_obs=self._local_root_obs,
+                                        joint_ids=self._amp_joint_ids, zero_joints=self._amp_zero_joints, local_root_obs=self._local_root_obs,
                                         root_height_obs=self._amp_root_height_obs, out=self._curr_amp_obs_buf, env_mask=env_mask)
 
     def _init_amp_obs(self, mask):
@@ -234,7 +245,7 @@ class HumanoidIm:
             n = self.num_envs
             bufs = self._ref_bufs.setdefault("hist", {})
             res = self._motion_lib.query(self._sampled_motion_ids.repeat_interleave(s), times, out=bufs, fields=("rb_records", "dof_pos", "dof_vel"))
-            hist = ops.build_amp_observations_smpl(res["rb_records"], res["dof_pos"], res["dof_vel"], self._key_body_ids, zero_joints=(),
+            hist = ops.build_amp_observations_smpl(res["rb_records"], res["dof_pos"], res["dof_vel"], self._key_body_ids, joint_ids=self._amp_joint_ids, zero_joints=(),
                                                    local_root_obs=self._local_root_obs, root_height_obs=self._amp_root_height_obs)
             hist = hist.view(n, s, self._num_amp_obs_per_step)
         else:
@@ -256,8 +267,7 @@ class HumanoidIm:
             rb, dp, dv = res["rb_records"], res["dof_pos"], res["dof_vel"]
         else:
             rb, dp, dv = self._motion_lib.sample_demo_states(num_samples * s)
-        # the toe / hand zeroing of :636-639 touches the SIMULATED dofs only; demo windows use the library dofs as they are
-        out = ops.build_amp_observations_smpl(rb, dp, dv, self._key_body_ids, zero_joints=(), local_root_obs=self._local_root_obs,
+        out = ops.build_amp_observations_smpl(rb, dp, dv, self._key_body_ids, joint_ids=self._amp_joint_ids, zero_joints=(), local_root_obs=self._local_root_obs,
                                               root_height_obs=self._amp_root_height_obs)
         return out.view(num_samples, s * self._num_amp_obs_per_step)
 

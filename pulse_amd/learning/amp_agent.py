@@ -345,7 +345,7 @@ class AMPAgent(CommonAgent):
         if self.enable_disc:
             # amp_agent.py:474-484: a fresh demo batch enters the demo ring, then T*N demo / replay rows are drawn.  Only the
             # first amp_minibatch_size rows of every minibatch are ever used (:621-628), so the draws are kept as ROW INDICES
-            # into the rings and gathered inside the normaliser kernel instead of materialising two (T*N, 2320) copies.
+            # into the rings and gathered inside the normaliser kernel instead of materialising two (T*N, 1960) copies.
             self._update_amp_demos()
             n = self.batch_size
             d["_amp_store"] = self.experience_buffer.flat("amp_obs")

@@ -81,7 +81,9 @@ def test_amp_demo_windows_from_motion_lib(dev):
     times = (t0.unsqueeze(-1) + (-task.dt * torch.arange(0, s))).view(-1)
     st = orc.get_motion_state(ids.repeat_interleave(s), times)
     key = task._key_body_ids.cpu().long()
-    want = E.amp_obs_smpl(st["root_pos"], st["root_rot"], st["root_vel"], st["root_ang_vel"], st["dof_pos"], st["dof_vel"], st["rg_pos"][:, key])
+    subset = torch.tensor([3 * int(j) + kk for j in task._amp_joint_ids.cpu() for kk in range(3)])
+    want = E.amp_obs_smpl(st["root_pos"], st["root_rot"], st["root_vel"], st["root_ang_vel"], st["dof_pos"], st["dof_vel"], st["rg_pos"][:, key],
+                          dof_subset=subset)
     np.testing.assert_allclose(demo.cpu().numpy(), want.view(k, -1).numpy(), atol=3e-5, rtol=1e-5)
 
 
@@ -168,7 +170,7 @@ def test_reset_mode_matches_separate_ops(dev):
 
 
 def test_amp_window_lockstep_with_cpu_twin(dev):
-    """The (N, 10, 232) AMP observation window of the env (slot 0 = simulated frame, shifted every step, re-initialised from the
+    """The (N, 10, 196) AMP observation window of the env (slot 0 = simulated frame, shifted every step, re-initialised from the
     motion before the start time on reference-state resets) vs oracle/motion_oracle.py:OracleAmpHistory, which is pinned bit for
     bit to HumanoidAMP's own methods (tests/test_oracle_env_vs_reference_methods.py)."""
     from oracle.motion_oracle import OracleAmpHistory
@@ -176,7 +178,10 @@ def test_amp_window_lockstep_with_cpu_twin(dev):
     env, _ = configs.make_env(n, 12, dev, seed=seed, env_kind="amp", reference="motion_lib")
     task = env.task
     tabs = syn.synthetic_motion_library(syn.make_generator(seed + 5, 0), min(n, 1024))
-    twin = OracleAmpHistory(OracleMotionLib(tabs), task._sampled_motion_ids.cpu(), task._num_amp_obs_steps, task.dt, task._key_body_ids.cpu().long())
+    assert task._num_amp_obs_per_step == 196 and task.get_num_amp_obs() == 1960            # robot/smpl_humanoid.yaml: has_dof_subset
+    subset = torch.tensor([3 * int(j) + k for j in task._amp_joint_ids.cpu() for k in range(3)])
+    twin = OracleAmpHistory(OracleMotionLib(tabs), task._sampled_motion_ids.cpu(), task._num_amp_obs_steps, task.dt, task._key_body_ids.cpu().long(),
+                            dof_subset=subset)
     sim = task.sim
     state = lambda: (sim.rigid_body_state.cpu().clone(), sim.dof_pos.cpu().clone(), sim.dof_vel.cpu().clone())
     env.reset()

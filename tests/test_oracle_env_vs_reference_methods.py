@@ -91,12 +91,15 @@ def test_amp_window_matches_reference_methods():
     tabs = syn.synthetic_motion_library(g, n, 10, 24)
     lib = _ref_motion_lib(tabs)
     key = torch.tensor([7, 3, 22, 17])
-    twin = OracleAmpHistory(OracleMotionLib(tabs), torch.arange(n), S, dt, key)
-    W = 232
+    # the shipped SMPL configuration: has_dof_subset True -> the 19 joints that are not toes / hands (humanoid.py:396-421)
+    joints19 = [j for j in range(23) if j not in (3, 7, 17, 22)]
+    subset = torch.tensor([3 * j + k for j in joints19 for k in range(3)])
+    twin = OracleAmpHistory(OracleMotionLib(tabs), torch.arange(n), S, dt, key, dof_subset=subset)
+    W = 196
     amp_buf = torch.zeros(n, S, W)
     task = types.SimpleNamespace(
-        humanoid_type="smpl", dof_subset=None, _amp_obs_buf=amp_buf, _curr_amp_obs_buf=amp_buf[:, 0], _hist_amp_obs_buf=amp_buf[:, 1:],
-        _num_amp_obs_steps=S, dt=dt, device="cpu", _key_body_ids=key, _local_root_obs=True, _amp_root_height_obs=True, _has_dof_subset=False,
+        humanoid_type="smpl", dof_subset=subset, _amp_obs_buf=amp_buf, _curr_amp_obs_buf=amp_buf[:, 0], _hist_amp_obs_buf=amp_buf[:, 1:],
+        _num_amp_obs_steps=S, dt=dt, device="cpu", _key_body_ids=key, _local_root_obs=True, _amp_root_height_obs=True, _has_dof_subset=True,
         _has_shape_obs_disc=False, _has_limb_weight_obs_disc=False, _has_upright_start=True, amp_obs_v=1, humanoid_shapes=torch.zeros(n, 17),
         humanoid_limb_and_weights=torch.zeros(n, 10), _motion_lib=lib, ref_motion_cache={}, gym=None, sim=None)
     for k, fn in f.items():

@@ -282,6 +282,48 @@ def gen_motion_lib(num_motions=9, n=203):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "motion_lib.npz"), **_np(out))
 
 
+def gen_tasks(n=61):
+    """Downstream-task functions (speed / reach / strike + the base reset) from the reference's own TorchScript sources."""
+    fn = refload.task_functions()
+    g = syn.make_generator(555)
+    rb = syn.rigid_body_state(g, n)
+    root = rb[:, 0].clone()
+    prev_root = root[:, 0:3] + 0.02 * torch.randn(n, 3, generator=g)
+    tar_speed = 1.0 + 2.0 * torch.rand(n, generator=g)
+    tar_pos = root[:, 0:3] + torch.randn(n, 3, generator=g)
+    tar_states = syn.rigid_body_state(g, n)[:, 0].clone()
+    tar_states[:5, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])                 # upright targets (tar_rot_err = 1) ...
+    tar_states[5:10, 3:7] = torch.tensor([1.0, 0.0, 0.0, 0.0])               # ... and knocked-over ones (success branch)
+    contact = torch.randn(n, 24, 3, generator=g) * (torch.rand(n, 24, 1, generator=g) < 0.3)
+    contact[::4] *= 100.0
+    tar_contact = torch.randn(n, 3, generator=g) * 60.0
+    progress = torch.randint(0, 305, (n,), generator=g)
+    progress[:3] = torch.tensor([0, 1, 2])
+    progress[-3:] = torch.tensor([298, 299, 304])                            # time-outs (>= max_episode_length - 1) ...
+    contact[-3:] = 0.0                                                       # ... on envs that have not fallen
+    body_pos = rb[..., 0:3].clone()
+    body_pos[::3, 5, 2] = 0.05                                               # a body below its termination height
+    term_h = torch.full((24,), 0.15)
+    contact_ids = torch.tensor([7, 3, 8, 4])
+    strike_ids = torch.tensor([23, 22, 21])
+    reset0 = torch.zeros(n, dtype=torch.long)
+    dt = 1.0 / 30.0
+    out = {"root_states": root, "prev_root_pos": prev_root, "tar_speed": tar_speed, "tar_pos": tar_pos, "tar_states": tar_states, "contact": contact,
+           "tar_contact": tar_contact, "progress": progress, "body_pos": body_pos, "term_h": term_h, "contact_ids": contact_ids, "strike_ids": strike_ids,
+           "reach_body_pos": rb[:, 23, 0:3].clone(), "strike_body_vel": rb[:, 23, 7:10].clone(), "dt": torch.tensor(dt)}
+    out["speed_obs"] = fn["compute_speed_observations"](root, tar_speed)
+    out["speed_rew"] = fn["compute_speed_reward"](root[:, 0:3], prev_root, root[:, 3:7], tar_speed, dt)
+    out["loc_obs"] = fn["compute_location_observations"](root, tar_pos)
+    out["reach_rew"] = fn["compute_reach_reward"](out["reach_body_pos"], root[:, 3:7], tar_pos, 1.0, dt)
+    out["strike_obs"] = fn["compute_strike_observations"](root, tar_states)
+    out["strike_rew"] = fn["compute_strike_reward"](tar_states[:, 0:3], tar_states[:, 3:7], root, prev_root, out["strike_body_vel"], dt, 1.4)
+    out["reset"], out["terminated"] = fn["compute_humanoid_reset"](reset0, progress, contact, contact_ids, body_pos, 300.0, True, term_h)
+    out["reset_noearly"], _ = fn["compute_humanoid_reset"](reset0, progress, contact, contact_ids, body_pos, 300.0, False, term_h)
+    out["strike_reset"], out["strike_terminated"] = fn["strike_compute_humanoid_reset"](reset0, progress, contact, contact_ids, body_pos, tar_contact,
+                                                                                    strike_ids, 300.0, True, term_h)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "tasks.npz"), **_np(out))
+
+
 def main():
     assert refload.available(), "reference tree not found; goldens can only be generated in the build container"
     os.makedirs(GOLDEN_DIR, exist_ok=True)
@@ -293,6 +335,7 @@ def main():
     gen_agent_math()
     gen_rms()
     gen_motion_lib()
+    gen_tasks()
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)), "bytes")
 

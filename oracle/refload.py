@@ -247,6 +247,26 @@ def humanoid_amp_methods():
     return _cache["hamp"]
 
 
+def task_functions():
+    """The downstream-task TorchScript functions (README's PULSE commands): compute_humanoid_reset (humanoid.py:1572-1608),
+    compute_speed_observations / _reward (humanoid_speed.py:310-343), compute_location_observations / compute_reach_reward
+    (humanoid_reach.py:224-250), compute_strike_observations / _reward / its compute_humanoid_reset (humanoid_strike.py:270-380)."""
+    if "tasks" in _cache:
+        return _cache["tasks"]
+    tasks = os.path.join(REFERENCE_ROOT, "phc", "env", "tasks")
+    out = {}
+    for fname, names, prefix in (("humanoid.py", ["compute_humanoid_reset"], ""),
+                                 ("humanoid_speed.py", ["compute_speed_observations", "compute_speed_reward"], ""),
+                                 ("humanoid_reach.py", ["compute_location_observations", "compute_reach_reward"], ""),
+                                 ("humanoid_strike.py", ["compute_strike_observations", "compute_strike_reward", "compute_humanoid_reset"], "strike_")):
+        ns = _namespace()
+        for name, text in _extract(os.path.join(tasks, fname), names).items():
+            exec(compile(text, f"<reference:{fname}:{name}>", "exec"), ns)
+            out[(prefix if name == "compute_humanoid_reset" else "") + name] = ns[name]
+    _cache["tasks"] = out
+    return out
+
+
 class _AttrDict(dict):
     """easydict.EasyDict stand-in (easydict is not installed): attribute access on a dict."""
     __getattr__ = dict.__getitem__

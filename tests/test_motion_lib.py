@@ -122,3 +122,26 @@ def test_motion_state_rejects_bad_arguments(dev):
     with pytest.raises(TypeError):
         lib.query(ids)
     assert lib.get_motion_state(ids[:0], torch.zeros(0, device=dev))["rg_pos"].shape == (0, 24, 3)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/phc/utils/motion_lib_base.py"), reason="reference checkout not mounted")
+def test_oracle_time_sampling_matches_reference_methods():
+    """sample_time / sample_time_interval / get_motion_length / get_motion_num_steps of the oracle vs MotionLibBase's own method bodies
+    (same torch RNG stream in, same times out)."""
+    from oracle import refload
+    _, tabs = _golden()
+    ref = refload.motion_lib_class()()
+    ref._motion_lengths, ref._motion_fps, ref._motion_num_frames, ref._device = tabs["motion_lengths"], tabs["motion_fps"], tabs["motion_num_frames"], "cpu"
+    orc = OracleMotionLib(tabs)
+    ids = torch.randint(0, tabs["motion_lengths"].shape[0], (500,), generator=torch.Generator().manual_seed(2))
+    for name in ("sample_time", "sample_time_interval"):
+        torch.manual_seed(11)
+        want = getattr(ref, name)(ids)
+        torch.manual_seed(11)
+        got = getattr(orc, name)(ids)
+        assert torch.equal(got, want), name
+    assert torch.equal(orc.get_motion_length(ids), ref.get_motion_length(ids)) and torch.equal(orc.get_motion_length(), ref.get_motion_length())
+    assert torch.equal(orc.get_motion_num_steps(), ref.get_motion_num_steps())
+    t = orc.sample_time_interval(ids, generator=torch.Generator().manual_seed(3))
+    q = t * 30
+    assert torch.allclose(q, q.round(), atol=1e-3)                            # multiples of 1/30 s (humanoid_im.py:652-654)

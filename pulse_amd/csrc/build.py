@@ -30,7 +30,9 @@ SOURCES = [
     ("motion_state.hip", NO_CONTRACT),
     ("rollout_ops.hip", NO_CONTRACT),
     ("gae.hip", NO_CONTRACT),
-    ("gemm_f32.hip", []),
+    # MFMA accumulators in VGPR form: no v_accvgpr moves (VALU slots are what the fp32 MFMA loop is short of) and the
+    # whole kernel fits the 256-register budget of two waves per SIMD
+    ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("learner_ops.hip", NO_CONTRACT),
 ]
 

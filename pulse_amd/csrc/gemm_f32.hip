@@ -6,23 +6,32 @@
 //   phc/learning/amp_network_z_builder.py:469-580 (PULSE VAE encoder / prior / decoder MLPs).
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 inputs, f32 accumulate, bit-identical to an fmaf chain,
-// 64 FLOP/clk/SIMD (157 TFLOP/s chip peak; gfx950 has no TF32/xf32 path).  The reference trains in
+// 64 FLOP/clk/SIMD (157 TFLOP/s chip peak at 2.4 GHz; gfx950 has no TF32/xf32 path).  The reference trains in
 // fp32 (mixed_precision: False, learning/im.yaml:50), so fp32 is kept end to end.
 //
 // One kernel, three operand-layout instantiations, C[m][n] = sum_k A(m,k) * B(n,k):
 //   <KC,KC>  forward   Y = X W^T      X [M][K],  W [N][K]      (both reduction-contiguous)
 //   <KC,MC>  dX        dX = dY W      dY [M][N], W [N][K]      (B stored [red][out])
 //   <MC,MC>  dW        dW = dY^T X    dY [M][N], X [M][K]      (both stored [red][out], split-K over M)
-// Tiling: 128x128x32 block tile, 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32 (64 accumulator
-// VGPRs).  Operands are staged global -> registers -> LDS with 16-byte loads, double-buffered in LDS
-// (one barrier per k-tile, next tile's global loads in flight during the 64 MFMAs of the current one).
-// LDS images: reduction-contiguous operands as [out][k] with a 36-float pitch (conflict-free
-// ds_read_b128: 16-lane groups land on 16 distinct 16-byte slots); [red][out] operands as [k][out]
-// read with ds_read_b32 (32 consecutive floats per half-wave).  Because k is a pure reduction index
-// the two wave halves take k-offsets {0..3} and {4..7} of every 8-k step, for A and B alike, which is
-// what lets a single ds_read_b128 feed four consecutive MFMAs.
-// 256 CUs / 8 XCDs: the 1-D grid is remapped so each XCD owns a contiguous band of m-tiles (A panels
-// stay in that XCD's L2; the small weight matrix is shared by all).
+// Tiling: 128x128x32 block tile, 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32 (64 accumulator registers), two
+// workgroups per CU (LDS-limited), so every SIMD holds two waves that fill each other's stalls.
+//
+// What the round-2 measurements (tools/gemm_bench --clocks: per-workgroup s_memtime stamps) said, and what this
+// version does about it:
+//   * beside an fp32-MFMA-saturating partner wave every VALU instruction of the other wave waits for a gap between
+//     two 64-cycle MFMAs, and every VALU instruction of the MFMA wave itself delays its next MFMA: VALU work is the
+//     scarce resource.  The old epilogue (~400 VALU per wave) took 29k cycles per tile beside a busy partner (9.8k
+//     alone) and the dW main loop lost 14 % to bias-gradient adds and address arithmetic.
+//   * so: global loads are buffer loads (per-lane byte offset computed ONCE, the k advance rides in the scalar
+//     offset), LDS addresses are per-lane constants + immediates (the LDS stage is a template parameter), the
+//     reduction-tail masks exist only in the tile that stages the last k-tile, the bias is the initial value of the
+//     accumulators, the fast epilogue is ds_write / ds_read_b128 / activation / buffer_store with scalar row offsets.
+//   * ONE LDS image for all layouts, [k-chunk of 4][out][4 k] in 16-byte slots, 129 slots per k-chunk block, slot =
+//     out ^ ((out >> 3) & 7): reduction-contiguous operands are stored as loaded, [red][out] operands are transposed
+//     4x4 in registers on the way in, and every fragment is one conflict-free ds_read_b128 feeding four MFMAs (k is a
+//     pure reduction index, so the two wave halves take k-chunks 2g and 2g+1 of every 8-k group, A and B alike).
+// 256 CUs / 8 XCDs: the 1-D grid is remapped so each XCD owns a contiguous band of m-tiles (A panels stay in that
+// XCD's L2; the small weight matrix is shared by all).
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -30,11 +39,16 @@
 namespace pulse {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PITCH_KC = BK + 4;    // [out][k] image
-constexpr int PITCH_MC = BM + 4;    // [k][out] image
-constexpr int TILE_FLOATS = BM * PITCH_KC;  // 4608 >= BK * PITCH_MC (4224)
+constexpr int KC_SLOTS = 129;                        // 16-byte slots per k-chunk block: 128 outs + 1 pad slot
+constexpr int IMG_BYTES = 8 * KC_SLOTS * 16;         // one operand tile: 8 k-chunks x 129 slots = 16,512 B
+constexpr int STAGE_BYTES = 2 * IMG_BYTES;           // A image + B image
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // two stages = 66,048 B -> two workgroups per CU
+constexpr int CP = BN;                               // epilogue transpose pitch (floats): 128 x 128 x 4 B = 65,536 B
+constexpr unsigned RSRC_FLAGS = 0x00020000u;         // raw buffer, 32-bit data format (gfx90a+ / gfx950)
 
 struct GemmArgs {
     const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux;
@@ -48,123 +62,104 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int vec_epi;                               // all epilogue pointers / pitches are 16-byte aligned
     float* rowsum; long long sRowsum;          // <MC,MC> only: per-slab sums over k of A(k, m)  (bias gradient)
+    long long* dbg;                            // optional per-workgroup clock stamps (tools/gemm_bench --clocks)
 };
 
-// ---- global -> register staging -------------------------------------------------------------
-// Loads are BRANCH-FREE (addresses are clamped to valid memory instead of predicated) so that nothing
-// consumes a loaded register before the MFMA block: the reduction-tail / out-of-range zeroing happens in
-// store_tile, after the compute of the current tile, when the data must have landed anyway.  (A first
-// version masked inside the load and the compiler had to put s_waitcnt vmcnt(0) right behind every load,
-// exposing the full HBM latency once per k-tile.)
-template <bool KC>
-__device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ P, int ld, int out0, int ext,
-                                          int k0, int kbeg, int kend, int tid) {
-    if constexpr (KC) {
-        int k = k0 + (tid & 7) * 4;
-        k = k < kend ? k : kbeg;                           // fully past the end: read something valid, masked later
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = out0 + (tid >> 3) + 32 * i;
-            row = row < ext ? row : ext - 1;              // rows beyond the extent are never stored
-            r[i] = *reinterpret_cast<const float4*>(P + (long long)row * ld + k);
-        }
-    } else {
-        int m = out0 + (tid & 31) * 4;
-        m = m < ext ? m : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int k = k0 + (tid >> 5) + 8 * i;
-            k = k < kend ? k : kend - 1;
-            r[i] = *reinterpret_cast<const float4*>(P + (long long)k * ld + m);
-        }
-    }
+__device__ __forceinline__ int slot_of(int out) { return out ^ ((out >> 3) & 7); }
+
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 lds_read(int byte_addr) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    return *reinterpret_cast<const f32x4*>(smem_c + byte_addr);
+}
+__device__ __forceinline__ void lds_write(int byte_addr, f32x4 v) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    *reinterpret_cast<f32x4*>(smem_c + byte_addr) = v;
 }
 
+// Per-thread staging state of one operand: 4 in-flight 16-byte loads, their (constant) buffer byte offsets and the
+// (constant) LDS byte addresses their data goes to.
+//   KC (reduction-contiguous): load i = row (tid >> 3) + 32 i, k-chunk tid & 7      -> one slot, stored as loaded
+//   MC ([red][out]):           load i = k row 4 (tid >> 5) + i, outs 4 (tid & 31).. -> 4x4 transpose, store j = out 4L + j
 template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int k0, int kend, int tid) {
-    if constexpr (KC) {
-        const int k = k0 + (tid & 7) * 4;
-        const bool full = k + 3 < kend;
+struct Stager {
+    f32x4 r[4];
+    int voff[4];
+    int lds[4];
+    int kpos;            // KC: first k of this thread's slot inside the tile (0, 4, .. 28); MC: first k row (0, 4, .. 28)
+
+    __device__ __forceinline__ void init(int tid, int ld, int ext_rel /* valid outs from the tile origin, >= 1 */, int img_off) {
+        if constexpr (KC) {
+            const int kc = tid & 7, row0 = tid >> 3;
+            kpos = kc * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v = r[i];
-            if (!full) {                                   // reduction tail: zero the lanes past K
-                if (k >= kend) v.x = 0.f;
-                if (k + 1 >= kend) v.y = 0.f;
-                if (k + 2 >= kend) v.z = 0.f;
-                v.w = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 32 * i;
+                const int rr = row < ext_rel ? row : ext_rel - 1;       // rows beyond the extent are never stored: read a valid one
+                voff[i] = (rr * ld + kc * 4) * 4;
+                lds[i] = img_off + (kc * KC_SLOTS + slot_of(row)) * 16;
             }
-            *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * PITCH_KC + (tid & 7) * 4) = v;
-        }
-    } else {
+        } else {
+            const int kch = tid >> 5, L = tid & 31;
+            kpos = kch * 4;
+            const int col = 4 * L < ext_rel ? 4 * L : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + (tid >> 5) + 8 * i;
-            float4 v = r[i];
-            if (k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * PITCH_MC + (tid & 31) * 4) = v;
+            for (int i = 0; i < 4; ++i) {
+                voff[i] = ((kch * 4 + i) * ld + col) * 4;
+                lds[i] = img_off + (kch * KC_SLOTS + slot_of(4 * L + i)) * 16;
+            }
         }
     }
-}
-
-// ---- per-unit forms (one 16-byte access each) for the interleaved main loop -------------------------------
-template <bool KC>
-__device__ __forceinline__ void load_unit(float4& r, const float* __restrict__ P, int ld, int out0, int ext, int k0, int kbeg, int kend,
-                                          int tid, int i) {
-    if constexpr (KC) {
-        int k = k0 + (tid & 7) * 4;
-        k = k < kend ? k : kbeg;
-        int row = out0 + (tid >> 3) + 32 * i;
-        row = row < ext ? row : ext - 1;
-        r = *reinterpret_cast<const float4*>(P + (long long)row * ld + k);
-    } else {
-        int m = out0 + (tid & 31) * 4;
-        m = m < ext ? m : 0;
-        int k = k0 + (tid >> 5) + 8 * i;
-        k = k < kend ? k : kend - 1;
-        r = *reinterpret_cast<const float4*>(P + (long long)k * ld + m);
-    }
-}
-
-template <bool KC>
-__device__ __forceinline__ void store_unit(float* __restrict__ s, const float4& r, int k0, int kend, int tid, int i) {
-    if constexpr (KC) {
-        const int k = k0 + (tid & 7) * 4;
-        float4 v = r;
-        if (k + 3 >= kend) {
-            if (k >= kend) v.x = 0.f;
-            if (k + 1 >= kend) v.y = 0.f;
-            if (k + 2 >= kend) v.z = 0.f;
-            v.w = 0.f;
+    // single short tile (K < 32 from the window start): lanes past the readable range re-read k position 0 (masked later)
+    __device__ __forceinline__ void clamp_short(int tid, int ld, int readable /* k positions that may be read */) {
+        if constexpr (KC) {
+            if (kpos >= readable) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) voff[i] -= kpos * 4;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (kpos + i >= readable) voff[i] -= (kpos + i) * ld * 4;
         }
-        *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * PITCH_KC + (tid & 7) * 4) = v;
-    } else {
-        const int k = k0 + (tid >> 5) + 8 * i;
-        float4 v = r;
-        if (k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(s + ((tid >> 5) + 8 * i) * PITCH_MC + (tid & 31) * 4) = v;
     }
-}
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff, int i) { r[i] = buf_load(rs, voff[i], soff); }
 
-// fragment for one 32-wide tile: the 4 k-values this lane feeds to 4 consecutive MFMAs
-template <bool KC>
-__device__ __forceinline__ float4 load_frag(const float* __restrict__ s, int out_in_tile, int kk, int half) {
-    if constexpr (KC) {
-        return *reinterpret_cast<const float4*>(s + out_in_tile * PITCH_KC + kk + 4 * half);
-    } else {
-        const float* p = s + (kk + 4 * half) * PITCH_MC + out_in_tile;
-        return make_float4(p[0], p[PITCH_MC], p[2 * PITCH_MC], p[3 * PITCH_MC]);
+    // store unit u (0..3) into the stage at byte offset st; MASKED zeroes k positions outside [lo, hi)
+    template <bool MASKED>
+    __device__ __forceinline__ void store(int st, int u, int lo, int hi) {
+        if constexpr (KC) {
+            f32x4 v = r[u];
+            if constexpr (MASKED) {
+                if (kpos < lo || kpos >= hi) v.x = 0.f;
+                if (kpos + 1 < lo || kpos + 1 >= hi) v.y = 0.f;
+                if (kpos + 2 < lo || kpos + 2 >= hi) v.z = 0.f;
+                if (kpos + 3 < lo || kpos + 3 >= hi) v.w = 0.f;
+            }
+            lds_write(st + lds[u], v);
+        } else {
+            f32x4 v = {r[0][u], r[1][u], r[2][u], r[3][u]};            // out 4L + u, k rows kpos .. kpos + 3
+            if constexpr (MASKED) {
+                if (kpos < lo || kpos >= hi) v.x = 0.f;
+                if (kpos + 1 < lo || kpos + 1 >= hi) v.y = 0.f;
+                if (kpos + 2 < lo || kpos + 2 >= hi) v.z = 0.f;
+                if (kpos + 3 < lo || kpos + 3 >= hi) v.w = 0.f;
+            }
+            lds_write(st + lds[u], v);
+        }
     }
-}
+};
 
 template <bool AKC, bool BKC>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // stage s: A image at smem + s*2*TILE_FLOATS, B image right after it
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5;
     const int l31 = lane & 31;
@@ -173,8 +168,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     const int ntile = g.tiles_m * g.tiles_n;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
-    const int q = ntile >> 3, rr = ntile & 7;
-    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    const int q8 = ntile >> 3, rr = ntile & 7;
+    const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
     const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -182,107 +177,158 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     const int bz = z / g.splitk, sp = z - bz * g.splitk;
     const int kbeg = sp * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
+    const int klen = kend - kbeg;
+    const int nkt = (klen + BK - 1) / BK;
 
-    const float* A = g.A + bz * g.sA;
-    const float* B = g.B + bz * g.sB;
+    long long dbg_c0 = 0, dbg_w0 = 0, dbg_c1 = 0, dbg_w1 = 0;
+    if (g.dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
 
+    // The last k-tile is read through a window that ENDS at roundup4(kend) (never past a row's pitch / the last k row):
+    // it may overlap the tile before it, so its image is valid for positions [lo, hi) only.
+    const int r4 = (klen + 3) & ~3;
+    const int wlast = r4 > BK ? r4 - BK : 0;                 // window start of the last tile, relative to kbeg
+    const int lo = nkt > 0 ? (nkt - 1) * BK - wlast : 0;
+    const int hi = klen - wlast;
+
+    // buffer resources based at this workgroup's tile origin and k start (all offsets stay far below 2^31)
+    const float* Ab = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
+    const float* Bb = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, 0xffffffffu, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, 0xffffffffu, RSRC_FLAGS);
+    const int kstepA = AKC ? 4 : g.lda * 4, kstepB = BKC ? 4 : g.ldb * 4;        // bytes per unit of k
+    auto koff = [&](int t) { return t == nkt - 1 ? wlast : t * BK; };              // scalar
+
+    Stager<AKC> sa;
+    Stager<BKC> sb;
+    sa.init(tid, g.lda, g.M - m0, 0);
+    sb.init(tid, g.ldb, g.N - n0, IMG_BYTES);
+    if (nkt == 1 && r4 < BK) { sa.clamp_short(tid, g.lda, AKC ? r4 : klen); sb.clamp_short(tid, g.ldb, BKC ? r4 : klen); }
+
+    // fragment read addresses: lane (l31, half) reads out (wm|wn) * 64 + {0, 32} + l31, k-chunk 2g + half
+    const int frA0 = (half * KC_SLOTS + slot_of(wm * 64 + l31)) * 16;
+    const int frA1 = (half * KC_SLOTS + slot_of(wm * 64 + 32 + l31)) * 16;
+    const int frB0 = IMG_BYTES + (half * KC_SLOTS + slot_of(wn * 64 + l31)) * 16;
+    const int frB1 = IMG_BYTES + (half * KC_SLOTS + slot_of(wn * 64 + 32 + l31)) * 16;
+
+    // accumulators start from the bias (EPI 0): the epilogue has no bias add left
     f32x16 acc[2][2];
+    {
+        float b0 = 0.f, b1 = 0.f;
+        if (g.epi == 0 && g.bias) {
+            const float* bias = g.bias + bz * g.sBias;
+            const int c0 = n0 + wn * 64 + l31;
+            if (c0 < g.N) b0 = bias[c0];
+            if (c0 + 32 < g.N) b1 = bias[c0 + 32];
+        }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
+    }
 
-    float4 ra[4], rb[4];
-    float4 fa[2][2], fb[2][2];                                   // two fragment sets: one feeding MFMAs, one in flight from LDS
+    f32x4 fa[2][2], fb[2][2];                                    // two fragment sets: one feeding MFMAs, one in flight from LDS
     float rsum[2] = {0.f, 0.f};
-    const int nkt = (kend - kbeg + BK - 1) / BK;
-    const int arow = wm * 64 + l31, brow = wn * 64 + l31;
+    const bool do_rs = !AKC && g.rowsum != nullptr && tn == 0 && wn == 0;      // wave-uniform
 
-    // fragment unit u of set SET: order fa0, fb0, fb1, fa1 = the order the MFMA pairs consume them
-    auto frag_unit = [&](int set, int u, const float* a_s, const float* b_s, int kk) {
-        if (u == 0) fa[set][0] = load_frag<AKC>(a_s, arow, kk, half);
-        else if (u == 1) fb[set][0] = load_frag<BKC>(b_s, brow, kk, half);
-        else if (u == 2) fb[set][1] = load_frag<BKC>(b_s, brow + 32, kk, half);
-        else fa[set][1] = load_frag<AKC>(a_s, arow + 32, kk, half);
+    // fragment unit u of set SET for k-group G of the stage at byte offset ST: order fa0, fb0, fb1, fa1 = consumption order
+    auto frag_unit = [&](int set, int u, int st, int G) {
+        const int o = st + 2 * G * KC_SLOTS * 16;
+        if (u == 0) fa[set][0] = lds_read(frA0 + o);
+        else if (u == 1) fb[set][0] = lds_read(frB0 + o);
+        else if (u == 2) fb[set][1] = lds_read(frB1 + o);
+        else fa[set][1] = lds_read(frA1 + o);
     };
-    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
 
-    // One k-tile = 64 MFMAs issued as 32 PAIRS (two accumulator chains alternate, so no MFMA waits on its predecessor).
-    // With ONE wave per SIMD doing all the work, everything else has to ride in the issue shadow of those MFMAs
-    // (each occupies the matrix pipe for 64 cycles): after every pair exactly one small unit of side work is issued --
-    //   pairs  0-3   fragment reads for pairs  8-15   (set 1, k +8)
-    //   pairs  8-11  fragment reads for pairs 16-23   (set 0, k +16)
-    //   pairs 16-19  fragment reads for pairs 24-31   (set 1, k +24)
-    //   pairs 19-26  the 8 register->LDS spills of tile t+1 (its global loads were issued a tile ago)
+    // One k-tile = 64 MFMAs issued as 32 PAIRS (two accumulator chains alternate, so no MFMA waits on its predecessor);
+    // after every pair exactly one small unit of side work (none of them VALU in the steady state for KC operands):
+    //   pairs  0-3   fragment reads for pairs  8-15   (set 1, k-group 1)
+    //   pairs  8-11  fragment reads for pairs 16-23   (set 0, k-group 2)
+    //   pairs 16-19  fragment reads for pairs 24-31   (set 1, k-group 3)
+    //   pairs 19-26  the 8 register->LDS stores of tile t+1 (its global loads were issued a tile ago)
     //   after pair 27  the ONE barrier of the tile
-    //   pairs 24-31  the 8 global loads of tile t+2 (load k re-uses the registers spill k just drained)
+    //   pairs 24-31  the 8 buffer loads of tile t+2 (load k re-uses the registers store k just drained; A's four stores
+    //                are done by pair 22, B's by pair 26)
     //   pairs 28-31  fragment reads for pairs 0-7 of tile t+1 (set 0, other LDS stage)
-    // sched_barrier(0) after every pair pins that order.
-    auto tile = [&](auto last_tag, int t) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        const int cur = t & 1;
-        const float* a_s = smem + cur * 2 * TILE_FLOATS;
-        const float* b_s = a_s + TILE_FLOATS;
-        float* a_o = smem + (cur ^ 1) * 2 * TILE_FLOATS;
-        float* b_o = a_o + TILE_FLOATS;
-        const int k_next = kbeg + (t + 1) * BK, k_next2 = kbeg + (t + 2) * BK;
+    // MODE 0 steady, 1 = stages the LAST tile (masked stores, no further loads), 2 = last tile (compute only).
+    auto tile = [&](auto mode_tag, auto stage_tag, int t) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int CUR = decltype(stage_tag)::value * STAGE_BYTES, OTH = STAGE_BYTES - CUR;
+        const int soA = koff(t + 2) * kstepA, soB = koff(t + 2) * kstepB;
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
             const int grp = p >> 3, set = grp & 1, q = p & 7, i = q >> 2, c = q & 3;
             if constexpr (!AKC) {                  // dW pass: the A fragments are dY -- their k-sums are the bias gradient
-                if (q == 0) {
+                if (q == 0 && do_rs) {
                     rsum[0] += (fa[set][0].x + fa[set][0].y) + (fa[set][0].z + fa[set][0].w);
                     rsum[1] += (fa[set][1].x + fa[set][1].y) + (fa[set][1].z + fa[set][1].w);
                 }
             }
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[set][i], c), comp(fb[set][0], c), acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[set][i], c), comp(fb[set][1], c), acc[i][1], 0, 0, 0);
-            if (p < 4) frag_unit(1, p, a_s, b_s, 8);
-            else if (p >= 8 && p < 12) frag_unit(0, p - 8, a_s, b_s, 16);
-            else if (p >= 16 && p < 20) frag_unit(1, p - 16, a_s, b_s, 24);
-            if constexpr (!LAST) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][c], fb[set][0][c], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][c], fb[set][1][c], acc[i][1], 0, 0, 0);
+            if (p < 4) frag_unit(1, p, CUR, 1);
+            else if (p >= 8 && p < 12) frag_unit(0, p - 8, CUR, 2);
+            else if (p >= 16 && p < 20) frag_unit(1, p - 16, CUR, 3);
+            if constexpr (MODE != 2) {
                 if (p >= 19 && p < 27) {
                     const int u = p - 19;
-                    if (u < 4) store_unit<AKC>(a_o, ra[u], k_next, kend, tid, u);
-                    else store_unit<BKC>(b_o, rb[u - 4], k_next, kend, tid, u - 4);
+                    if (u < 4) sa.template store<MODE == 1>(OTH, u, lo, hi);
+                    else sb.template store<MODE == 1>(OTH, u - 4, lo, hi);
                 }
                 if (p == 27) {
                     __builtin_amdgcn_sched_barrier(0);
                     __syncthreads();
                 }
-                if (p >= 24) {              // unconditional: past the last tile the clamped addresses re-read valid memory, never stored
-                    const int u = p - 24;
-                    if (u < 4) load_unit<AKC>(ra[u], A, g.lda, m0, g.M, k_next2, kbeg, kend, tid, u);
-                    else load_unit<BKC>(rb[u - 4], B, g.ldb, n0, g.N, k_next2, kbeg, kend, tid, u - 4);
+                if constexpr (MODE == 0) {
+                    if (p >= 24) {
+                        const int u = p - 24;
+                        if (u < 4) sa.load(rsA, soA, u);
+                        else sb.load(rsB, soB, u - 4);
+                    }
                 }
-                if (p >= 28) frag_unit(0, p - 28, a_o, b_o, 0);
+                if (p >= 28) frag_unit(0, p - 28, OTH, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
 
     if (nkt > 0) {
-        load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg, kbeg, kend, tid);
-        load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg, kbeg, kend, tid);
-        store_tile<AKC>(smem, ra, kbeg, kend, tid);
-        store_tile<BKC>(smem + TILE_FLOATS, rb, kbeg, kend, tid);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sa.load(rsA, koff(0) * kstepA, u); sb.load(rsB, koff(0) * kstepB, u); }
+        if (nkt == 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sa.template store<true>(0, u, lo, hi); sb.template store<true>(0, u, lo, hi); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sa.template store<false>(0, u, 0, BK); sb.template store<false>(0, u, 0, BK); }
+        }
     }
     __syncthreads();
     if (nkt > 1) {
-        load_tile<AKC>(ra, A, g.lda, m0, g.M, kbeg + BK, kbeg, kend, tid);
-        load_tile<BKC>(rb, B, g.ldb, n0, g.N, kbeg + BK, kbeg, kend, tid);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sa.load(rsA, koff(1) * kstepA, u); sb.load(rsB, koff(1) * kstepB, u); }
     }
     if (nkt > 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) frag_unit(0, u, smem, smem + TILE_FLOATS, 0);
+        for (int u = 0; u < 4; ++u) frag_unit(0, u, 0, 0);
     }
-    for (int t = 0; t + 1 < nkt; ++t) tile(std::false_type{}, t);
-    if (nkt > 0) tile(std::true_type{}, nkt - 1);
+    {
+        int t = 0;
+        for (; t + 3 < nkt; t += 2) { tile(I0{}, I0{}, t); tile(I0{}, I1{}, t + 1); }      // steady tiles t < nkt - 2, two per trip
+        if (t + 2 < nkt) {                                                               // one more steady tile: parity flips
+            tile(I0{}, I0{}, t);
+            tile(I1{}, I1{}, t + 1);
+            tile(I2{}, I0{}, t + 2);
+        } else if (t + 2 == nkt) {
+            tile(I1{}, I0{}, t);
+            tile(I2{}, I1{}, t + 1);
+        } else if (t + 1 == nkt) {
+            tile(I2{}, I0{}, t);
+        }
+    }
     if constexpr (!AKC) {
-        if (g.rowsum && tn == 0 && wn == 0) {
-            // this lane summed the k-offsets of its half; the other half's lane holds the rest of the same row
+        if (do_rs) {
+            // this lane summed the k-chunks of its half; the other half's lane holds the rest of the same row
             const float r0 = rsum[0] + __shfl_xor(rsum[0], 32, 64);
             const float r1 = rsum[1] + __shfl_xor(rsum[1], 32, 64);
             if (half == 0) {
@@ -294,23 +340,40 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
         }
     }
     __syncthreads();                                              // the epilogue reuses the staging buffers
-#undef PULSE_LOAD_FRAGS
-#undef PULSE_MFMA_GROUP
+    if (g.dbg) { dbg_c1 = clock64(); dbg_w1 = wall_clock64(); }
+    struct DbgStamp {
+        const GemmArgs& g; long long c0, w0, c1, w1;
+        __device__ ~DbgStamp() {
+            if (g.dbg && threadIdx.x == 0) {
+                long long* o = g.dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+                o[0] = c0; o[1] = w0; o[2] = c1; o[3] = w1; o[4] = clock64(); o[5] = wall_clock64();
+                o[7] = ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            }
+        }
+    } dbg_stamp{g, dbg_c0, dbg_w0, dbg_c1, dbg_w1};
 
     // ---- epilogue -----------------------------------------------------------------------------------
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* C = g.C + bz * g.sC + sp * g.sSplit;
     float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
-    const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
     const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
 
     if (g.vec_epi) {
-        // Wide path: the accumulators are transposed through LDS (the staging buffers are free after the main
-        // loop) so every global access of the epilogue -- C stores, aux loads, pre-activation stores -- is a
-        // 16-byte access covering 512 contiguous bytes of one row per half-wave, instead of 64 dword stores and
-        // 64 dword aux loads per lane.
-        constexpr int CP = BN + 4;                     // 132-float pitch: ds_read_b128 lane groups stay conflict-free
-        float* sC = smem;                              // 128 x 132 x 4 B = 67,584 B <= 73,728 B
+        const bool fast = m0 + BM <= g.M && n0 + BN <= g.N && (g.epi == 1 || (g.epi == 0 && g.act != 2));
+        const int c4 = (tid & 31) * 4;
+        const int rl0 = tid >> 5;
+        f32x4 ax[16];
+        if (fast && g.epi == 1) {                  // relu-grad: the 16 aux loads fly while the accumulators go through LDS
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
+                                                                                0xffffffffu, RSRC_FLAGS);
+            const int voX = (rl0 * g.ldaux + c4) * 4;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ax[q] = buf_load(rsX, voX, q * 8 * g.ldaux * 4);
+        }
+        // The accumulators are transposed through LDS (the staging buffers are free after the main loop) so every global
+        // access of the epilogue is a 16-byte access covering 512 contiguous bytes of one row per half-wave.
+        float* sC = smem;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -319,24 +382,43 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
                 for (int r = 0; r < 16; ++r)
                     sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
         __syncthreads();
-        const int c4 = (tid & 31) * 4;
+        if (g.dbg && tid == 0) g.dbg[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 6] = clock64();
+        if (fast) {
+            // fast path (full tile; none / relu / relu-grad): per 16-byte store one ds_read_b128, the activation, one
+            // buffer store whose row advance is a scalar offset -- no per-access address arithmetic on the VALU
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (long long)m0 * g.ldc + n0, 0, 0xffffffffu, RSRC_FLAGS);
+            const int voC = (rl0 * g.ldc + c4) * 4;
+            const int ldsC = (rl0 * CP + c4) * 4;
+            if (g.epi == 0) {
+                const bool relu = g.act == 1;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4 a = ax[q];
+                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
+                    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                }
+            }
+            return;
+        }
         const int col = n0 + c4;
         if (col < g.N) {
             const bool full = col + 3 < g.N;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias) {
-                if (full) bv = *reinterpret_cast<const float4*>(bias + col);
-                else { bv.x = bias[col]; if (col + 1 < g.N) bv.y = bias[col + 1]; if (col + 2 < g.N) bv.z = bias[col + 2]; }
-            }
 #pragma unroll 4
             for (int q = 0; q < 16; ++q) {
-                const int rl = (tid >> 5) + 8 * q;
+                const int rl = rl0 + 8 * q;
                 const int row = m0 + rl;
                 if (row >= g.M) continue;
                 float4 v = *reinterpret_cast<const float4*>(sC + rl * CP + c4);
                 float o[4] = {v.x, v.y, v.z, v.w};
                 if (g.epi == 0) {
-                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
                     if (g.act == 1) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
@@ -378,7 +460,6 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
         if (col >= g.N) continue;
-        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -387,7 +468,6 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
                 if (row >= g.M) continue;
                 float v = acc[i][j][r];
                 if (g.epi == 0) {
-                    v += bv;
                     if (g.act == 1) {
                         v = fmaxf(v, 0.f);
                     } else if (g.act == 2) {
@@ -475,9 +555,22 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 
 using namespace pulse;
 
+namespace {
+long long* g_dbg = nullptr;                    // tools/gemm_bench --clocks
+int g_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] extra LDS bytes per workgroup (occupancy experiments); others unused
+}
+
 extern "C" {
 
 int pulse_sizeof_gemm_desc(void) { return (int)sizeof(pulse_gemm_desc); }
+
+int pulse_gemm_set_debug_buffer(long long* device_buffer) { g_dbg = device_buffer; return PULSE_OK; }
+
+int pulse_gemm_set_option(int key, int value) {
+    PULSE_REQUIRE(key >= 0 && key < 8, "pulse_gemm_set_option: bad key");
+    g_opt[key] = value;
+    return PULSE_OK;
+}
 
 int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     PULSE_REQUIRE(d != nullptr, "pulse_gemm_f32: null descriptor");
@@ -515,22 +608,27 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
+    g.dbg = g_dbg;
+    // per-workgroup buffer offsets are 32-bit: tile-relative (128 rows) for reduction-contiguous operands, split-relative
+    // (kchunk rows) for [red][out] operands
+    PULSE_REQUIRE((long long)d->lda * (akc ? 129 : g.kchunk + 1) < (1LL << 28) && (long long)d->ldb * (bkc ? 129 : g.kchunk + 1) < (1LL << 28) &&
+                  (long long)d->ldc * 129 < (1LL << 28) && (long long)d->ldaux * 129 < (1LL << 28),
+                  "pulse_gemm_f32: pitch too large for 32-bit tile-relative offsets");
     auto al16 = [](const void* p, long long ld, long long st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0 && (st % 4) == 0; };
     g.vec_epi = al16(d->C, d->ldc, d->stride_c) && (d->split_stride % 4) == 0 && (!d->aux || al16(d->aux, d->ldaux, d->stride_aux)) &&
                 (!d->C2 || al16(d->C2, d->ldc2, d->stride_c2)) && (!d->bias || al16(d->bias, 4, d->stride_bias));
-    static const size_t lds_extra = getenv("PULSE_GEMM_LDS_EXTRA") ? (size_t)atoi(getenv("PULSE_GEMM_LDS_EXTRA")) : 0;   // tuning knob
-    const size_t lds = sizeof(float) * 4 * TILE_FLOATS + lds_extra;   // 73,728 B -> two workgroups per CU
+    const size_t lds = (size_t)LDS_BYTES + (size_t)g_opt[1];                  // 66,048 B -> two workgroups per CU
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
-    // The 72 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling
+    // The 64.5 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling
     // hipFuncSetAttribute on every launch serialises the host against the stream).
-    static bool attr_done[3] = {false, false, false};
+    static size_t attr_done[3] = {0, 0, 0};
     hipError_t e = hipSuccess;
 #define LAUNCH(IDX, AK, BK_)                                                                                       \
-    if (!attr_done[IDX]) {                                                                                        \
+    if (attr_done[IDX] != lds) {                                                                                      \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BK_>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_f32: LDS attribute: %s", hipGetErrorString(e)); \
-        attr_done[IDX] = true;                                                                                    \
+        attr_done[IDX] = lds;                                                                                     \
     }                                                                                                             \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
     if (akc && bkc) { LAUNCH(0, true, true); }

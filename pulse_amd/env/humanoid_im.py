@@ -258,7 +258,9 @@ class HumanoidIm:
         if self._use_motion_lib:
             lib = self._motion_lib
             ids = lib.sample_motions(num_samples, generator=self._clock_gen)
-            t0 = lib.sample_time(ids, generator=self._clock_gen)                       # _sample_time, humanoid_amp.py:223-224
+            # _sample_time (humanoid_amp.py:223-224) resolves to HumanoidIm._sample_time (humanoid_im.py:652-654; HumanoidAMP's own
+            # :376-380 does the same for smpl): start times on the 1/30 s grid, no frame blending
+            t0 = lib.sample_time_interval(ids, generator=self._clock_gen)
             steps = -self.dt * torch.arange(0, s, device=self.device)                  # build_amp_obs_demo, :256-262
             times = (t0.unsqueeze(-1) + steps).view(-1)
             bufs = self._ref_bufs["demo"] if self._ref_bufs["demo"].get("dof_pos", torch.empty(0)).shape[0] == num_samples * s else {}

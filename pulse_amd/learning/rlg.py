@@ -171,7 +171,9 @@ class AMPDataset:
         envs = self._idx_buf[idx * step:(idx + 1) * step]
         rows = (envs[:, None] * t + self._t_range[None, :]).reshape(-1)
         out = {"idx": rows, "dataset": self.values_dict, "num_seqs": step}
-        if (idx + 1) * step * t >= self.batch_size:
+        # amp_datasets.py:75-76 compares ``end`` -- an ENV index here -- with batch_size (= T * num_envs): that never fires, so the
+        # reference re-uses the env permutation drawn in update_values_dict for every mini-epoch of the epoch.  Mirrored.
+        if (idx + 1) * step >= self.batch_size:
             self._idx_buf = self._randperm(self._perm_n)
         return out
 

@@ -1,0 +1,271 @@
+"""GPU: agent-level parity beyond cfg1 / CommonAgent (round-1 verdict, "next round" item 1).
+
+  (a) AMPAgent with the frozen-copy observation normaliser (temp_running_mean) AND the discriminator on cfg5_small: the whole
+      epoch -- policy side of the rollout, discriminator reward mix, GAE, dataset, every calc_gradients of the 6 mini-epochs --
+      against OracleAMPAgent (oracle/amp_oracle.py), whose calc_gradients is pinned bit-for-bit to the reference's method body.
+      Reference: phc/learning/amp_agent.py:341-439, 557-603, 605-760, 1011-1041.
+  (b) cfg3_small: three consecutive _optimize_kin steps (own Adam, clip 50) and the KL-anneal boundary (amp_agent.py:771-849).
+  (c) cfg2 at FULL size: 4096 x 32 rollout + the first minibatch step against the CPU oracle (about 25 s of host time).
+  (d) two ranks sharing the GPU over gloo: the reduced gradient is the mean of the shard gradients and the parameters stay
+      identical across ranks for three optimiser steps (common_agent.py:112-113, 465-471).
+
+north_star bars: bit-exact integer outputs, fp32 rewards / advantages within 1e-5, policy grad-norm within 1e-4.
+"""
+import copy
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import agent_oracle as AO
+from oracle import amp_oracle as AMPO
+from oracle import env_oracle as E
+from pulse_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def cmp(a, b, atol, rtol=0.0, what=""):
+    a = torch.as_tensor(a).detach().cpu().double().numpy()
+    b = torch.as_tensor(b).detach().cpu().double().numpy()
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, err_msg=what)
+
+
+def stack(info, key):
+    return torch.stack([torch.as_tensor(t).float().reshape(()) for t in info[key]]).cpu().double().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ (a)
+def test_amp_agent_epoch_parity_frozen_stats_and_discriminator(dev):
+    seed = 13
+    torch.manual_seed(seed)
+    ag, _ = configs.make_agent("cfg5_small", device=str(dev), seed=seed, permutation_device="cpu")
+    assert ag.temp_running_mean and ag.enable_disc
+    ag.init_tensors()
+    ag.obs = ag.env_reset()
+    ag._tensors_ready = True
+    T, N, A = ag.horizon_length, ag.num_actors, ag.actions_num
+    noise = torch.randn(1, T, N, A, generator=torch.Generator().manual_seed(seed))
+    noise_dev = noise.to(dev)
+    ag.noise_provider = lambda e, s: noise_dev[e, s]
+    cfg = ag.config
+    orc = AMPO.OracleAMPAgent(cfg, ag.obs_shape[0], ag._amp_dim, ag.model.state_dict(), ag.disc.state_dict(),
+                              cfg["network"]["mlp"]["units"], (ag.disc.u1, ag.disc.u2))
+    # record the minibatch index lists the device epoch draws
+    index_lists = []
+    inner = ag.train_actor_critic
+
+    def spy(input_dict):
+        index_lists.append(input_dict["idx"].detach().cpu().clone())
+        return inner(input_dict)
+    ag.train_actor_critic = spy
+    ag.epoch_num = 1
+    info = ag.train_epoch()
+    eb = ag.experience_buffer
+    td = eb.tensor_dict
+    w = ag._amp_dim
+    rec = {"obses": td["obses"].cpu().clone(), "next_obses": td["next_obses"].cpu().clone(), "rewards": td["rewards"].cpu().clone(),
+           "dones": td["dones"].cpu().clone(), "terminates": td["terminates"].cpu().clone(), "amp_obs": td["amp_obs"].cpu().clone()[..., :w]}
+    assert rec["dones"].sum() > 0 and rec["amp_obs"].abs().sum() > 0
+    # ---- rollout, agent side
+    otd = orc.play_recorded(rec, noise[0])
+    cmp(td["mus"], otd["mus"], 2e-5, 1e-5, "mus")
+    cmp(td["actions"], otd["actions"], 2e-5, 1e-5, "actions")
+    cmp(td["values"], otd["values"], 2e-5, 1e-5, "values")
+    cmp(td["next_values"], otd["next_values"], 2e-5, 1e-5, "next_values")
+    cmp(td["neglogpacs"], otd["neglogpacs"], 2e-3, 1e-5, "neglogpacs")
+    cmp(info["disc_rewards"].transpose(0, 1), otd["disc_rewards"], 2e-5, 5e-5, "discriminator rewards")
+    cmp(info["mb_rewards"].transpose(0, 1), otd["mb_rewards"], 1e-5, 5e-5, "combined rewards (0.5 task + 0.5 disc)")
+    # advantages: 1e-5 on the SAME stored inputs, and end to end
+    adv_same = E.gae(td["dones"].float().cpu(), td["values"].cpu(), info["mb_rewards"].transpose(0, 1).cpu(), td["next_values"].cpu(),
+                     cfg["gamma"], cfg["tau"])
+    adv_dev = ag.discount_values(td["dones"], td["values"], info["mb_rewards"].transpose(0, 1), td["next_values"])
+    cmp(adv_dev, adv_same, 1e-5, what="advantages (same inputs)")
+    cmp(adv_dev, otd["advs"], 2e-4, 1e-5, "advantages (end to end)")
+    # ---- dataset
+    ovd = orc.prepare_dataset()
+    ds = ag.dataset.values_dict
+    cmp(ds["advantages"], ovd["advantages"], 5e-4, 1e-4, "normalised advantages")
+    cmp(ds["returns"], ovd["returns"], 2e-4, 1e-4, "normalised returns")
+    # ---- update: same index lists, same demo / replay rows
+    demo_rows = ag._amp_obs_demo_buffer.data[ds["_amp_demo_idx"]][:, :w].cpu()
+    assert ds["_amp_replay_idx"] is None                                   # first epoch: amp_obs_replay = amp_obs (amp_agent.py:478-480)
+    replay_rows = eb.flat("amp_obs")[:, :w].cpu()
+    n_mb = ag.mini_epochs_num * ag.num_minibatches
+    assert len(index_lists) == n_mb
+    oinfos = orc.update(index_lists, demo_rows, replay_rows)
+    gn_dev = stack(info, "grad_norm")
+    gn_ref = np.array([float(x["grad_norm"]) for x in oinfos])
+    np.testing.assert_allclose(gn_dev[0], gn_ref[0], rtol=1e-4)             # joint policy + discriminator grad-norm within 1e-4
+    np.testing.assert_allclose(gn_dev, gn_ref, rtol=3e-3)
+    for key in ("actor_loss", "critic_loss", "b_loss", "kl", "disc_loss", "disc_grad_penalty"):
+        np.testing.assert_allclose(stack(info, key), np.array([float(x[key]) for x in oinfos]), rtol=3e-3, atol=2e-4, err_msg=key)
+    # ---- the three normalisers: live observation statistics were updated on every minibatch of every mini-epoch (seen 6x),
+    #      the frozen copy that fed the network was not, the AMP statistics saw agent -> replay -> demo per minibatch
+    cmp(ag.running_mean_std.running_mean, orc.running_mean_std.running_mean, 1e-5, 1e-5, "live obs mean")
+    cmp(ag.running_mean_std.running_var, orc.running_mean_std.running_var, 1e-5, 1e-4, "live obs var")
+    assert ag.running_mean_std.count.item() == orc.running_mean_std.count.item() == 1 + n_mb * ag.minibatch_size
+    cmp(ag._amp_input_mean_std.running_mean, orc.amp_mean_std.running_mean, 1e-5, 1e-5, "amp mean")
+    cmp(ag._amp_input_mean_std.running_var, orc.amp_mean_std.running_var, 1e-5, 1e-4, "amp var")
+    assert ag._amp_input_mean_std.count.item() == orc.amp_mean_std.count.item() == 1 + 3 * n_mb * ag._amp_minibatch_size
+    cmp(ag.value_mean_std.running_mean, orc.value_mean_std.running_mean, 1e-5, 1e-5, "value mean")
+    # ---- final weights (policy + discriminator): bulk agreement, sign-flip outliers bounded by steps * 2 lr
+    bound = 2.0 * ag.last_lr * n_mb
+    got = dict(ag.model.state_dict())
+    got.update(ag.disc.state_dict())
+    want = dict(orc.net.state_dict_ref())
+    want.update(orc.disc.state_dict_ref())
+    for k, v in want.items():
+        if k.endswith("sigma"):
+            continue
+        d = (got[k].cpu().double().reshape(v.shape) - v.double()).abs()
+        assert d.max().item() <= bound, k
+        assert (d > 2e-6 + 1e-4 * v.double().abs()).double().mean().item() < 0.03, k
+
+
+# ------------------------------------------------------------------------------------------------ (b)
+def test_kin_three_steps_and_anneal_boundary(dev):
+    torch.manual_seed(21)
+    agent, _ = configs.make_agent("cfg3_small", device=str(dev), seed=21)
+    agent.init_tensors()
+    task = agent.vec_env.env.task
+    ref = AO.OracleNetZ()
+    agent.model.load_state_dict(ref.state_dict_ref())
+    opt = torch.optim.Adam(ref.parameters(), agent.kin_lr, eps=1e-08)
+    t, mb = agent.horizon_length, agent.minibatch_size
+    kld_w = float(task.kld_coefficient)
+    assert task.kld_anneal and kld_w == 0.01
+    agent.set_train()
+    epochs = [100, 2600, 4999]                                    # before, inside and at the end of the 2500..5000 anneal window
+    for step, epoch in enumerate(epochs):
+        g = torch.Generator().manual_seed(100 + step)
+        obs = torch.randn(mb, 934, generator=g).clamp(-5, 5)
+        gt = (0.4 * torch.randn(mb, 69, generator=g)).clamp(-1, 1)
+        prog = (torch.randint(0, 40, (mb // t, 1), generator=g) + torch.arange(t)[None, :]).reshape(-1, 1)
+        prog[2 * t + 3:3 * t] = torch.arange(t - 3)[:, None]                  # an episode seam inside sequence 2
+        noise = torch.randn(mb, 32, generator=g)
+        # oracle: loss + backward with the CURRENT coefficient, clip 50, Adam(kin_lr); THEN the anneal (amp_agent.py:826-845)
+        info_ref = AO.oracle_optimize_kin(ref, obs, gt, prog, noise, t, kld_coefficient=kld_w, ar1_coefficient=task.ar1_coefficient)
+        gn_ref = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), agent.grad_norm))
+        opt.step()
+        if epoch > 2500:
+            kld_w = (0.01 - task.kld_coefficient_min) * max((5000 - epoch) / 2500, 0) + task.kld_coefficient_min
+        agent.epoch_num = epoch
+        ws = agent.model.workspace(mb, train=True)
+        ws["x"].zero_()
+        ws["x"][:, :934] = obs.to(dev)
+        agent.z_noise_provider = lambda m, nz=noise: nz.to(dev)
+        info = agent._optimize_kin(ws, mb, {"gt_action": gt.to(dev), "progress_buf": prog.to(dev)})
+        tol = 2e-5 if step == 0 else 2e-4                                     # later steps inherit weight round-off through Adam
+        for k in ("kin_action_loss", "kin_KLD", "kin_ar1", "kin_loss"):
+            np.testing.assert_allclose(info[k].item(), info_ref[k].item(), rtol=tol, err_msg=f"step {step} {k}")
+        np.testing.assert_allclose(info["grad_norm"].item(), gn_ref, rtol=1e-4 if step == 0 else 2e-3, err_msg=f"step {step} grad norm")
+        np.testing.assert_allclose(info["kin_kld_w"], kld_w, rtol=1e-12, err_msg=f"step {step} annealed KL weight")
+        np.testing.assert_allclose(float(task.kld_coefficient), kld_w, rtol=1e-12)
+    assert abs(kld_w - (0.009 * (1 / 2500) + 0.001)) < 1e-12 and agent.kin_step == 3
+    sd = agent.model.state_dict()
+    bound = 2.0 * agent.kin_lr * 3
+    for k, v in ref.state_dict_ref().items():
+        if k.endswith("sigma"):
+            continue
+        d = (sd[k].cpu().double() - v.double()).abs()
+        assert d.max().item() <= bound, k
+        assert (d > 2e-6 + 1e-4 * v.double().abs()).double().mean().item() < 0.03, k
+
+
+# ------------------------------------------------------------------------------------------------ (c)
+def test_cfg2_full_size_rollout_and_first_minibatch(dev):
+    from tests.test_agent_parity_gpu import build_pair, info_batch
+    oracle, agent = build_pair("cfg2", dev, seed=3)
+    assert (agent.num_actors, agent.horizon_length, agent.minibatch_size) == (4096, 32, 16384)
+    ref = oracle.train_epoch(max_minibatches=1)                           # 4096 x 32 rollout + GAE + dataset + ONE minibatch on the host
+    info = agent.train_epoch()
+    td, rd = agent.experience_buffer.tensor_dict, oracle.tensor_dict
+    cmp(td["obses"], rd["obses"], 1e-5, 1e-5, "obses")
+    cmp(td["rewards"], rd["rewards"], 1e-5, what="rewards")
+    assert torch.equal(td["dones"].cpu(), rd["dones"]) and rd["dones"].sum() > 0, "dones must be bit-exact"
+    cmp(td["mus"], rd["mus"], 3e-5, 1e-5, "mus")
+    cmp(td["values"], rd["values"], 3e-5, 1e-5, "values")
+    cmp(td["next_values"], rd["next_values"], 3e-5, 1e-5, "next_values")
+    adv_same = E.gae(td["dones"].float().cpu(), td["values"].cpu(), td["rewards"].cpu(), td["next_values"].cpu(), 0.99, 0.95)
+    cmp(agent.discount_values(td["dones"], td["values"], td["rewards"], td["next_values"]), adv_same, 1e-5, what="advantages (same inputs)")
+    cmp(info_batch(agent)["advs_raw"], ref["batch_dict"]["advs_raw"], 3e-4, 1e-5, "advantages (end to end)")
+    cmp(agent.dataset.values_dict["advantages"], oracle.values_dict["advantages"], 5e-4, 1e-4, "normalised advantages")
+    gn_dev = torch.stack(info["grad_norm"]).reshape(-1).cpu().double().numpy()
+    np.testing.assert_allclose(gn_dev[0], oracle.grad_norms[0], rtol=1e-4)   # policy grad-norm within 1e-4 at full size
+    for key in ("actor_loss", "critic_loss", "b_loss", "kl"):
+        np.testing.assert_allclose(float(info[key][0]), float(ref["infos"][0][key]), rtol=2e-3, atol=2e-4, err_msg=key)
+
+
+# ------------------------------------------------------------------------------------------------ (d)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, outdir):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "PULSE_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    import torch as th
+    from pulse_amd import configs as C
+    th.cuda.set_device(0)
+    th.manual_seed(1000 + rank)                                            # different initial weights per rank: setup_algo must fix that
+    agent, _ = C.make_agent("cfg1", device="cuda:0", seed=7, rank=rank, multi_gpu=True, permutation_device="cpu")
+    assert agent.world_size == world and agent.rank == rank
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent._tensors_ready = True
+    flat_before = agent.model.flat.clone()
+    agent.dist.setup_algo(agent.model.flat, (agent.model.sigma, agent.exp_avg, agent.exp_avg_sq))
+    pre, post = [], []
+    inner = agent.dist.sync_gradients
+
+    def spy(g):
+        pre.append(g.detach().clone().cpu())
+        out = inner(g)
+        post.append(g.detach().clone().cpu())
+        return out
+    agent.dist.sync_gradients = spy
+    batch = agent.play_steps()
+    batch.pop("played_frames")
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    agent._begin_loss_ring(3)
+    for i in range(3):
+        agent.train_actor_critic(agent.dataset[i])
+    agent._end_loss_ring()
+    th.cuda.synchronize()
+    th.save({"before": flat_before.cpu(), "after_setup_rank0_view": None, "pre": pre, "post": post, "flat": agent.model.flat.cpu(),
+             "obs_sum": float(agent.experience_buffer.tensor_dict["obses"].double().sum())}, os.path.join(outdir, f"rank{rank}.pt"))
+    agent.dist.barrier()
+    agent.dist.shutdown()
+
+
+def test_two_ranks_share_gpu_gradient_mean_and_identical_parameters(dev):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, outdir)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        r0, r1 = (torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2))
+    assert not torch.equal(r0["before"], r1["before"])                      # ranks started from different weights ...
+    assert abs(r0["obs_sum"] - r1["obs_sum"]) > 1e-3                        # ... and own different env shards
+    assert len(r0["pre"]) == len(r1["pre"]) == 3
+    for s in range(3):
+        # every rank pre-scales its shard gradient by 1/world in the slab reduce; the SUM all-reduce therefore yields the mean
+        assert not torch.equal(r0["pre"][s], r1["pre"][s])
+        assert torch.equal(r0["post"][s], r1["post"][s]), f"step {s}: reduced gradient differs across ranks"
+        assert torch.equal(r0["post"][s], r0["pre"][s] + r1["pre"][s]), f"step {s}: reduced gradient is not the sum of the scaled shards"
+    assert torch.equal(r0["flat"], r1["flat"]), "parameters diverged across ranks"
+    assert not torch.equal(r0["flat"], r0["before"])

@@ -74,7 +74,8 @@ def test_amp_demo_windows_from_motion_lib(dev):
     task._clock_gen.set_state(state)
     lib = task._motion_lib
     ids = lib.sample_motions(k, generator=task._clock_gen).cpu()
-    t0 = lib.sample_time(ids.to(dev), generator=task._clock_gen).cpu()
+    t0 = lib.sample_time_interval(ids.to(dev), generator=task._clock_gen).cpu()       # HumanoidIm._sample_time (humanoid_im.py:652-654)
+    assert torch.allclose(t0 * 30, torch.round(t0 * 30), atol=1e-4)                     # demo windows start on the 1/30 s grid
     tabs = syn.synthetic_motion_library(syn.make_generator(seed + 5, 0), min(n, 1024))
     orc = OracleMotionLib(tabs)
     s = task._num_amp_obs_steps

@@ -135,6 +135,8 @@ class CommonAgent:
         self.epoch_counter = 0
         self._entropy = None
         self._tensors_ready = False
+        self._boot_idx = self._boot_val = None
+        self._rollout_noise = None
 
     # ------------------------------------------------------------------ construction helpers
     def _load_config_params(self, config):
@@ -212,8 +214,9 @@ class CommonAgent:
         return self.obs_to_tensors(self.vec_env.reset_masked(mask))
 
     def env_step(self, actions):
-        if self.clip_actions:
-            # rescale_actions(low, high, clamp(a, -1, 1)) with +-1 spaces is the clamp itself
+        if self.clip_actions and getattr(self.vec_env, "clip_actions", None) != 1.0:
+            # rescale_actions(low, high, clamp(a, -1, 1)) with +-1 spaces is the clamp itself; VecTaskPython.step applies the
+            # identical clamp again (vec_task.py:147), so when the wrapper clamps at 1.0 the first one is a no-op and is skipped
             actions = torch.clamp(actions, -1.0, 1.0)
         obs, rewards, dones, infos = self.vec_env.step(actions)
         if self.value_size == 1:
@@ -245,6 +248,8 @@ class CommonAgent:
         net.forward(ws, n)
         if self.noise_provider is not None:        # parity tests share pre-drawn noise with the CPU oracle
             noise = self.noise_provider(self.epoch_counter, s)
+        elif self._rollout_noise is not None:      # play_steps drew the whole rollout's noise in one launch
+            noise = self._rollout_noise[s]
         else:
             noise = torch.randn(n, self.actions_num, device=self.ppo_device, generator=self.noise_generator)
         vm = self.value_mean_std
@@ -283,6 +288,10 @@ class CommonAgent:
         self.set_eval()
         eb = self.experience_buffer
         done_mask = None
+        if self.noise_provider is None:            # Normal(mu, sigma).sample() of all T steps: one generator launch instead of T
+            if self._rollout_noise is None:
+                self._rollout_noise = torch.empty(self.horizon_length, self.num_actors, self.actions_num, device=self.ppo_device)
+            self._rollout_noise.normal_(generator=self.noise_generator)
         for n in range(self.horizon_length):
             self.obs = self._env_reset_masked(done_mask) if done_mask is not None else self.env_reset([])
             eb.update_data("obses", n, self.obs["obs"])
@@ -320,21 +329,42 @@ class CommonAgent:
 
     def _bootstrap_values(self):
         """next_values = value_mean_std.unnorm(critic(norm(next_obses))) * (1 - terminated) for every (env, t) of the rollout
-        (amp_agent.py:394-398, common_agent.py:551-562), in minibatch-sized chunks of the env-major flat buffers."""
+        (amp_agent.py:394-398, common_agent.py:551-562).
+
+        The critic and the normaliser statistics are frozen for the whole rollout, and for an env that was NOT reset after step
+        t the observation stored at t+1 IS next_obs[t] -- so its bootstrap value is the value already computed at t+1 (the same
+        fused-GEMM arithmetic, bit for bit: output elements do not depend on their tile position).  Only the rows that were
+        reset (done at t) and the last step need a critic pass of their own: ~7 k of 131 k rows at cfg2 instead of all of them.
+        The row list is compacted on the device; its length is the one host read of the rollout."""
         eb, net = self.experience_buffer, self.model
-        rows = self.num_actors * self.horizon_length
-        chunk = self.minibatch_size if rows % self.minibatch_size == 0 else self.num_actors
+        n, t = self.num_actors, self.horizon_length
         nxt, out, term = eb.flat("next_obses"), eb.flat("next_values"), eb.flat("terminates")
+        vals, dones = eb.flat("values"), eb.flat("dones")
+        out.view(n, t)[:, :-1].copy_(vals.view(n, t)[:, 1:])
+        need = dones.view(n, t) != 0
+        need[:, t - 1] = True
+        rows = torch.nonzero(need.reshape(-1)).reshape(-1)                 # (count,) -- device->host sync on the count, once per epoch
+        count = rows.numel()
+        chunk = min(self.minibatch_size, max(n, 1024))
         net.eval()
         ws = net.workspace(chunk, train=chunk == self.minibatch_size)     # the update's workspace doubles as the inference one
-        for c in range(0, rows, chunk):
-            self._preproc_obs(nxt[c:c + chunk], ws, chunk)
+        if self._boot_idx is None or self._boot_idx.numel() != chunk:
+            self._boot_idx = torch.zeros(chunk, dtype=torch.int64, device=self.ppo_device)
+            self._boot_val = torch.zeros(chunk, 1, device=self.ppo_device)
+        flat_out = out.view(-1)
+        for c in range(0, count, chunk):
+            m = min(chunk, count - c)
+            idx = self._boot_idx
+            idx[:m] = rows[c:c + m]
+            if m < chunk:
+                idx[m:] = rows[c]                                         # padding rows recompute a needed row (result identical)
+            self._preproc_obs(nxt, ws, chunk, row_idx=idx)
             net.eval_critic(ws, chunk)
-            v = out[c:c + chunk]
             if self.normalize_value:
-                self.value_mean_std.forward(ws["val"], unnorm=True, out=v, out_cols=1)
+                self.value_mean_std.forward(ws["val"], unnorm=True, out=self._boot_val, out_cols=1)
             else:
-                v.copy_(ws["val"])
+                self._boot_val.copy_(ws["val"])
+            flat_out[idx[:m]] = self._boot_val[:m, 0]
         out.mul_(1.0 - term.unsqueeze(-1).float())                       # next_vals *= (1 - terminated)
 
     def _action_for_env(self, res_dict):

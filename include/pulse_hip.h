@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 9
+#define PULSE_ABI_VERSION 10
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -146,10 +146,21 @@ typedef struct pulse_im_step_args {
 
     /* ---- options ---- */
     uint32_t what;            /* PULSE_IM_* mask */
-    int32_t obs_version;      /* 6 or 7 */
+    int32_t obs_version;      /* task observation: 1, 2, 3, 6, 7, 8 (time_steps 1), 9  (humanoid_im.py:1222-1540) */
     int32_t local_root_obs;   /* env_im.yaml:33 */
     int32_t root_height_obs;  /* env_im.yaml:34 */
     pulse_reward_specs specs;
+    int32_t upright_start;    /* robot/smpl_humanoid.yaml:7 has_upright_start; 0: heading from remove_base_rot(root), humanoid.py:1616-1620 */
+    int32_t enable_early_termination; /* env_im.yaml enableEarlyTermination (compute_humanoid_im_reset's flag) */
+    /* self observation variant (humanoid.py:1675-1849): 1 = _smpl_max; 3 = _smpl_max_v3 (force_sensor rows of force_sensor_width
+       floats appended); 2 = _smpl_max_v2: ``rb`` holds hist_steps records per env, oldest first ((num_envs, hist_steps, J, 13),
+       rb_env_stride >= hist_steps * J * 13), every step expressed in the heading frame of the newest root; reward / reset /
+       task observations use the newest record. */
+    int32_t self_obs_version; int32_t hist_steps;
+    const float* force_sensor; int32_t force_sensor_width;
+    /* obs_version 2 only (time_steps 1): simulated and reference dof positions, (num_envs, 3 (J-1)); the observation takes the
+       joints of the tracked bodies without the root (humanoid_im.py:755-758).  With use_motion the reference is blended in-kernel. */
+    const float* dof_pos; const float* ref_next_dof_pos;
 
     /* ---- outputs ---- */
     float* obs;               /* (num_envs, obs_stride): [self_obs | task_obs | zero pad] */
@@ -186,12 +197,58 @@ typedef struct pulse_im_step_args {
     float* track_dof_pos; float* track_dof_vel; /* (num_envs, (J-1)*3) */
 } pulse_im_step_args;
 
-/* width of the self / task observation for the given options */
 /* sizeof(pulse_im_step_args) as compiled, so a foreign-language binding can verify its mirror */
 int pulse_sizeof_im_step_args(void);
+/* width of the self / task observation for the given options (self_obs_version 1; _ex covers versions 2 / 3) */
 int pulse_self_obs_width(int num_bodies, int root_height_obs);
+int pulse_self_obs_width_ex(int num_bodies, int root_height_obs, int self_obs_version, int hist_steps, int force_sensor_width);
 int pulse_task_obs_width(int obs_version, int num_track, int time_steps);
 int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
+ * 2a'. Downstream tasks on a frozen PULSE decoder (speed / reach / strike):
+ *    compute_speed_observations / compute_speed_reward      phc/env/tasks/humanoid_speed.py:310-343 (+ power term :211-218)
+ *    compute_location_observations / compute_reach_reward   phc/env/tasks/humanoid_reach.py:224-250
+ *    compute_strike_observations / compute_strike_reward    phc/env/tasks/humanoid_strike.py:270-327
+ *    compute_humanoid_reset (+ strike variant)              phc/env/tasks/humanoid.py:1572-1608, humanoid_strike.py:330-380
+ * ------------------------------------------------------------------------- */
+#define PULSE_TASK_SPEED  1
+#define PULSE_TASK_REACH  2
+#define PULSE_TASK_STRIKE 3
+#define PULSE_TASK_OBS    1u
+#define PULSE_TASK_REWARD 2u
+#define PULSE_TASK_RESET  4u
+
+typedef struct pulse_task_step_args {
+    int32_t task;             /* PULSE_TASK_SPEED | _REACH | _STRIKE */
+    uint32_t what;            /* PULSE_TASK_OBS | _REWARD | _RESET mask */
+    int32_t num_envs;
+    const int64_t* env_ids; int32_t num_ids; const uint8_t* env_mask;   /* subset selection as in pulse_im_step */
+    const float* rb; int64_t rb_env_stride; int32_t num_bodies;        /* (num_envs, J, 13); record 0 is _humanoid_root_states */
+    const float* prev_root_pos;       /* (num_envs, 3)  _prev_root_pos (pre_physics_step) */
+    float dt;
+    const float* tar_speed;           /* speed: (num_envs) */
+    const float* tar_pos;             /* reach: (num_envs, 3) */
+    int32_t reach_body_id;            /* reach: _reach_body_id */
+    const float* tar_states;          /* strike: (num_envs, 13) target object root state */
+    const float* tar_contact_forces;  /* strike: (num_envs, 3) */
+    const int32_t* strike_body_ids; int32_t num_strike;
+    /* compute_humanoid_reset */
+    const float* contact_forces;      /* (num_envs, J, 3) */
+    const int32_t* contact_body_ids; int32_t num_contact_ids;
+    const float* termination_heights; /* (J) */
+    const int64_t* progress; float max_episode_length; int32_t enable_early_termination;
+    /* power term of the reward */
+    const float* dof_force; const float* dof_vel; int32_t num_dof; float power_coef; int32_t power_reward;
+    /* outputs */
+    float* obs; int64_t obs_stride; int32_t obs_offset;   /* task obs -> row e, columns [obs_offset, obs_offset + width) */
+    float* rew; float* rew_raw; int32_t rew_raw_width;    /* rew_raw optional: [task reward, power term] */
+    int64_t* reset; int64_t* terminate;
+} pulse_task_step_args;
+
+int pulse_sizeof_task_step_args(void);
+int pulse_task_obs_size(int task);    /* 3 / 3 / 15 */
+int pulse_task_step(const pulse_task_step_args* args, pulse_stream_t s);
 
 /* AMP per-frame observation: build_amp_observations_smpl (phc/env/tasks/humanoid_amp.py:925-969) +
  * dof_to_obs_smpl (phc/env/tasks/humanoid.py:1436-1446). */
@@ -352,6 +409,11 @@ typedef struct pulse_gemm_desc {
 
 int pulse_sizeof_gemm_desc(void);
 int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
+/* Diagnostics used by tools/gemm_bench (no effect on results).  Option 1 = extra dynamic-LDS bytes per workgroup (occupancy
+ * experiments).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
+ * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID. */
+int pulse_gemm_set_option(int key, int value);
+int pulse_gemm_set_debug_buffer(long long* device_buffer);
 /* out[i] = scale * sum_s slabs[s*slab_stride + i]  (deterministic split-K / partial-sum reduction) */
 int pulse_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count, float* out,
                        float scale, pulse_stream_t s);

@@ -91,6 +91,111 @@ def im_obs_v7(root_pos, root_rot, body_pos, body_vel, ref_pos, ref_vel, time_ste
     return torch.cat([d_pos.view(b, t, -1), d_vel.view(b, t, -1), rel.view(b, t, -1)], dim=-1).view(b, -1)
 
 
+def remove_base_rot(quat):
+    """remove_base_rot, phc/env/tasks/humanoid.py:1616-1620: q * conj([0.5, 0.5, 0.5, 0.5]) (SMPL's non-upright rest frame)."""
+    base = R.qconj(torch.tensor([[0.5, 0.5, 0.5, 0.5]]).to(quat))
+    return R.qmul(quat, base.repeat(quat.shape[0], 1))
+
+
+def _im_blocks(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_pos, ref_rot, ref_vel, ref_ang_vel, t, upright):
+    """The eight per-(sample, body) blocks every compute_imitation_observations* variant is assembled from
+    (phc/env/tasks/humanoid_im.py:1222-1540), each flattened (B*T*J, .)."""
+    b, j, _ = body_pos.shape
+    if not upright:
+        root_rot = remove_base_rot(root_rot)
+    h_inv = R.heading_q_inv(root_rot)
+    h = R.heading_q(root_rot)
+    h_inv_e = h_inv.unsqueeze(-2).repeat((1, j, 1)).repeat_interleave(t, 0).view(-1, 4)
+    h_e = h.unsqueeze(-2).repeat((1, j, 1)).repeat_interleave(t, 0).view(-1, 4)
+    d_pos = R.qrot(h_inv_e, (ref_pos.view(b, t, j, 3) - body_pos.view(b, 1, j, 3)).view(-1, 3))
+    d_rot = R.qmul(ref_rot.view(b, t, j, 4), R.qconj(body_rot[:, None].repeat_interleave(t, 1)))
+    d_rot6 = R.q_to_tan_norm(R.qmul(R.qmul(h_inv_e, d_rot.view(-1, 4)), h_e))
+    d_vel = R.qrot(h_inv_e, (ref_vel.view(b, t, j, 3) - body_vel.view(b, 1, j, 3)).view(-1, 3))
+    d_ang = R.qrot(h_inv_e, (ref_ang_vel.view(b, t, j, 3) - body_ang_vel.view(b, 1, j, 3)).view(-1, 3))
+    r_pos = R.qrot(h_inv_e, (ref_pos.view(b, t, j, 3) - root_pos.view(b, 1, 1, 3)).view(-1, 3))
+    r_rot6 = R.q_to_tan_norm(R.qmul(h_inv_e, ref_rot.view(-1, 4)))
+    r_vel = R.qrot(h_inv_e, ref_vel.view(-1, 3))
+    r_ang = R.qrot(h_inv_e, ref_ang_vel.view(-1, 3))
+    return {"d_pos": d_pos, "d_rot6": d_rot6, "d_vel": d_vel, "d_ang": d_ang, "r_pos": r_pos, "r_rot6": r_rot6, "r_vel": r_vel,
+            "r_ang": r_ang, "h_inv": h_inv}
+
+
+def im_obs_variant(version, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_pos, ref_rot, ref_vel, ref_ang_vel,
+                   time_steps=1, upright=True, dof_pos=None, ref_dof_pos=None):
+    """compute_imitation_observations (v1, :1222-1256), _v2 (:1259-1297, + dof differences), _v3 (:1300-1325, no velocities),
+    _v6 / _v7 (with ``upright``), _v8 (:1415-1481, one sample: T > 1 slices a column there) and _v9 (:1484-1540, root
+    velocity differences only).  cur (B, Jt, .), ref (B*T, Jt, .)."""
+    b, j, _ = body_pos.shape
+    t = time_steps
+    k = _im_blocks(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_pos, ref_rot, ref_vel, ref_ang_vel, t, upright)
+    v = lambda x: x.view(b, -1)
+    vt = lambda x: x.view(b, t, -1)
+    if version == 1:
+        return torch.cat([v(k["d_pos"]), v(k["d_rot6"]), v(k["d_vel"]), v(k["d_ang"])], dim=-1)
+    if version == 2:
+        d_dof = ref_dof_pos.view(b, t, -1) - dof_pos.view(b, t, -1)
+        return torch.cat([v(k["d_pos"]), v(k["d_rot6"]), v(k["d_vel"]), v(k["d_ang"]), v(d_dof)], dim=-1)
+    if version == 3:
+        return torch.cat([v(k["d_pos"]), v(k["d_rot6"])], dim=-1)
+    if version == 6:
+        return torch.cat([vt(k["d_pos"]), vt(k["d_rot6"]), vt(k["d_vel"]), vt(k["d_ang"]), vt(k["r_pos"]), vt(k["r_rot6"])], dim=-1).view(b, -1)
+    if version == 7:
+        return torch.cat([vt(k["d_pos"]), vt(k["d_vel"]), vt(k["r_pos"])], dim=-1).view(b, -1)
+    if version == 8:
+        assert t == 1, "v8 with future samples indexes a column of the flattened velocities in the reference (:1466-1474)"
+        return torch.cat([v(k["d_pos"]), v(k["d_rot6"]), v(k["d_vel"]), v(k["d_ang"]), v(k["r_pos"]), v(k["r_rot6"]), v(k["r_vel"]),
+                          v(k["r_ang"])], dim=-1)
+    if version == 9:
+        h_root = k["h_inv"].repeat_interleave(t, 0)
+        d_rv = R.qrot(h_root, (ref_vel.view(b, t, j, 3)[:, :, 0] - body_vel[:, None, 0]).reshape(-1, 3))
+        d_ra = R.qrot(h_root, (ref_ang_vel.view(b, t, j, 3)[:, :, 0] - body_ang_vel[:, None, 0]).reshape(-1, 3))
+        return torch.cat([vt(k["d_pos"]), vt(k["d_rot6"]), vt(d_rv), vt(d_ra), vt(k["r_pos"]), vt(k["r_rot6"])], dim=-1).view(b, -1)
+    raise ValueError(version)
+
+
+def self_obs_smpl_max_general(body_pos, body_rot, body_vel, body_ang_vel, local_root_obs=True, root_height_obs=True, upright=True,
+                              force_sensor=None):
+    """compute_humanoid_observations_smpl_max with ``upright`` False (humanoid.py:1675-1731: heading AND the non-local root 6-D block
+    from remove_base_rot(root)) and _max_v3 (:1789-1849: the same with the force-sensor readings appended)."""
+    n, j, _ = body_pos.shape
+    root_pos = body_pos[:, 0, :]
+    root_rot = body_rot[:, 0, :]
+    hr = root_rot if upright else remove_base_rot(root_rot)
+    h_inv_flat = R.heading_q_inv(hr).unsqueeze(-2).repeat((1, j, 1)).reshape(n * j, 4)
+    loc_pos = R.qrot(h_inv_flat, (body_pos - root_pos.unsqueeze(-2)).reshape(n * j, 3)).reshape(n, j * 3)[..., 3:]
+    rot6 = R.q_to_tan_norm(R.qmul(h_inv_flat, body_rot.reshape(n * j, 4))).reshape(n, j * 6)
+    if not local_root_obs:
+        rot6[..., 0:6] = R.q_to_tan_norm(hr)
+    loc_vel = R.qrot(h_inv_flat, body_vel.reshape(n * j, 3)).reshape(n, j * 3)
+    loc_ang = R.qrot(h_inv_flat, body_ang_vel.reshape(n * j, 3)).reshape(n, j * 3)
+    parts = [root_pos[:, 2:3]] if root_height_obs else []
+    parts += [loc_pos, rot6, loc_vel, loc_ang]
+    if force_sensor is not None:
+        parts.append(force_sensor)
+    return torch.cat(parts, dim=-1)
+
+
+def self_obs_smpl_max_v2(body_pos, body_rot, body_vel, body_ang_vel, local_root_obs=True, root_height_obs=True, upright=True):
+    """compute_humanoid_observations_smpl_max_v2, humanoid.py:1734-1786: a history of T simulated states (B, T, J, .), every step
+    expressed in the heading frame of the LATEST root, per step [height | pos | rot6 | vel | ang]."""
+    b, t, j, _ = body_pos.shape
+    root_pos = body_pos[:, -1, 0, :]
+    root_rot = body_rot[:, -1, 0, :]
+    if not upright:
+        root_rot = remove_base_rot(root_rot)
+    h_inv_e = R.heading_q_inv(root_rot).unsqueeze(-2).repeat((1, j, 1)).repeat_interleave(t, 0).view(-1, 4)
+    loc_pos = R.qrot(h_inv_e, (body_pos - root_pos.unsqueeze(-2).unsqueeze(-2)).view(-1, 3)).reshape(b, t, j * 3)[..., 3:]
+    rot6 = R.q_to_tan_norm(R.qmul(h_inv_e, body_rot.view(-1, 4))).view(b, t, j * 6)
+    if not local_root_obs:
+        raise NotImplementedError("the reference raises here (a (B*T, 6) block assigned into a (B, T, 6) slot, humanoid.py:1766-1768)")
+    loc_vel = R.qrot(h_inv_e, body_vel.view(-1, 3)).view(b, t, j * 3)
+    loc_ang = R.qrot(h_inv_e, body_ang_vel.view(-1, 3)).view(b, t, j * 3)
+    body_obs = torch.cat([loc_pos, rot6, loc_vel, loc_ang], dim=-1)
+    if root_height_obs:
+        body_obs = torch.cat([body_pos[:, :, 0, 2:3], body_obs], dim=-1)
+    return body_obs.view(b, -1)
+
+
 DEFAULT_REWARD_SPECS = {  # phc/env/tasks/humanoid_im.py:55
     "k_pos": 100.0, "k_rot": 10.0, "k_vel": 0.1, "k_ang_vel": 0.1,
     "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1,

@@ -140,6 +140,60 @@ def gen_env_im(n=67):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "env_im.npz"), **_np(out))
 
 
+def gen_env_variants(n=19):
+    """The remaining observation variants: obs_v 1 / 2 / 3 / 8 / 9 (humanoid_im.py:1222-1325,1415-1540),
+    self_obs_v 2 / 3 (humanoid.py:1734-1849), remove_base_rot (:1616-1620) and the non-upright forms of the shipped variants."""
+    fn = refload.env_functions()
+    g = syn.make_generator(777)
+    T = 3
+    rb = syn.rigid_body_state(g, n)
+    bp, br, bv, ba = rb[..., 0:3].clone(), rb[..., 3:7].clone(), rb[..., 7:10].clone(), rb[..., 10:13].clone()
+    ref = syn.rigid_body_state(g, n * T)
+    rp, rr, rv, ra = ref[..., 0:3].clone(), ref[..., 3:7].clone(), ref[..., 7:10].clone(), ref[..., 10:13].clone()
+    rp = rp.view(n, T, 24, 3) * 0.1 + bp.view(n, 1, 24, 3)                       # references near the simulated bodies
+    rp = rp.reshape(n * T, 24, 3)
+    tb = syn.VR_TRACK_BODY_IDS
+    dof_pos = torch.randn(n, 69, generator=g) * 0.5
+    ref_dof = torch.randn(n, 69, generator=g) * 0.5
+    sub = lambda x, ids: x[:, ids].contiguous()
+    one = lambda x: x.view(n, T, *x.shape[1:])[:, 0].contiguous()               # first future sample only (T = 1 inputs)
+    out = {"rb": rb, "ref_pos": rp, "ref_rot": rr, "ref_vel": rv, "ref_ang": ra, "dof_pos": dof_pos, "ref_dof_pos": ref_dof,
+           "T": torch.tensor(T)}
+    out["remove_base_rot"] = fn["remove_base_rot"](br[:, 0].contiguous())
+    for up in (True, False):
+        tag = "" if up else "_noup"
+        args = lambda ids, t: (bp[:, 0], br[:, 0], sub(bp, ids), sub(br, ids), sub(bv, ids), sub(ba, ids))
+        full = list(range(24))
+        for ver, name in ((1, "compute_imitation_observations"), (3, "compute_imitation_observations_v3"),
+                          (6, "compute_imitation_observations_v6"), (9, "compute_imitation_observations_v9")):
+            for ids, itag in ((full, ""), (tb, "_vr")):
+                r4 = (sub(rp, ids), sub(rr, ids), sub(rv, ids), sub(ra, ids))
+                if ver == 9:
+                    r4 = (r4[0], r4[1], r4[2][:, 0].contiguous(), r4[3][:, 0].contiguous())
+                out[f"v{ver}_T{T}{itag}{tag}"] = fn[name](*args(ids, T), *r4, T, up)
+        r1 = (one(rp), one(rr), one(rv), one(ra))
+        out[f"v8_T1{tag}"] = fn["compute_imitation_observations_v8"](*args(full, 1), *r1, 1, up)
+        out[f"v7_T1_vr{tag}"] = fn["compute_imitation_observations_v7"](bp[:, 0], br[:, 0], sub(bp, tb), sub(bv, tb), sub(r1[0], tb), sub(r1[2], tb), 1, up)
+        # v2 as HumanoidIm calls it (:755-758): dof subsets of the tracked bodies without the root
+        ids = full
+        dsel = lambda d: d.reshape(-1, 23, 3)[:, [i - 1 for i in ids[1:]], :].contiguous()
+        out[f"v2_T1{tag}"] = fn["compute_imitation_observations_v2"](*args(ids, 1), dsel(dof_pos), *r1, dsel(ref_dof), 1, up)
+        empty = torch.zeros(n, 0)
+        for lro in (True, False):
+            ltag = "" if lro else "_globalroot"
+            out[f"self_obs{ltag}{tag}"] = fn["compute_humanoid_observations_smpl_max"](bp, br, bv, ba, empty, empty, lro, True, up, False, False)
+            fs = torch.randn(n, 12, generator=torch.Generator().manual_seed(5))
+            out["force_sensor"] = fs
+            out[f"self_obs_v3{ltag}{tag}"] = fn["compute_humanoid_observations_smpl_max_v3"](bp, br, bv, ba, fs, empty, empty, lro, True, up, False, False)
+            hist = syn.rigid_body_state(torch.Generator().manual_seed(9), n * T).view(n, T, 24, 13)
+            out["rb_hist"] = hist
+            if lro:          # with local_root_obs False the reference assigns a (B*T, 6) block into a (B, T, 6) slot and raises (:1766-1768)
+                out[f"self_obs_v2{tag}"] = fn["compute_humanoid_observations_smpl_max_v2"](
+                    hist[..., 0:3].contiguous(), hist[..., 3:7].contiguous(), hist[..., 7:10].contiguous(), hist[..., 10:13].contiguous(),
+                    empty, empty, lro, True, up, False, False, T)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "env_variants.npz"), **_np(out))
+
+
 def gen_env_amp(n=67):
     """AMP per-frame observation from the reference's build_amp_observations_smpl (+ dof_to_obs_smpl)."""
     fn = refload.env_functions()
@@ -332,6 +386,7 @@ def main():
     gen_rotations()
     gen_env_im()
     gen_env_amp()
+    gen_env_variants()
     gen_agent_math()
     gen_rms()
     gen_motion_lib()

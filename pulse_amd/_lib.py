@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -50,6 +50,8 @@ class ImStepArgs(Structure):
         ("term_dist", c_void_p), ("reset_use_mean", c_int32), ("full_body_reward", c_int32),
         ("what", c_uint32), ("obs_version", c_int32), ("local_root_obs", c_int32), ("root_height_obs", c_int32),
         ("specs", RewardSpecs),
+        ("upright_start", c_int32), ("enable_early_termination", c_int32), ("self_obs_version", c_int32), ("hist_steps", c_int32),
+        ("force_sensor", c_void_p), ("force_sensor_width", c_int32), ("dof_pos", c_void_p), ("ref_next_dof_pos", c_void_p),
         ("obs", c_void_p), ("obs_stride", c_int64), ("obs_cols", c_int32),
         ("rew", c_void_p), ("rew_raw", c_void_p), ("reset", c_void_p), ("terminate", c_void_p),
         ("progress_rw", c_void_p), ("progress_inc", c_int32), ("clock_dt", c_float),
@@ -58,6 +60,24 @@ class ImStepArgs(Structure):
         ("use_motion", c_int32), ("motion", MotionTables), ("motion_ids", c_void_p), ("motion_offset", c_void_p), ("traj_dt", c_float),
         ("track_rb", c_void_p), ("track_rb_stride", c_int64), ("track_dof_pos", c_void_p), ("track_dof_vel", c_void_p),
     ]
+
+
+class TaskStepArgs(Structure):
+    _fields_ = [
+        ("task", c_int32), ("what", c_uint32), ("num_envs", c_int32), ("env_ids", c_void_p), ("num_ids", c_int32), ("env_mask", c_void_p),
+        ("rb", c_void_p), ("rb_env_stride", c_int64), ("num_bodies", c_int32), ("prev_root_pos", c_void_p), ("dt", c_float),
+        ("tar_speed", c_void_p), ("tar_pos", c_void_p), ("reach_body_id", c_int32), ("tar_states", c_void_p),
+        ("tar_contact_forces", c_void_p), ("strike_body_ids", c_void_p), ("num_strike", c_int32),
+        ("contact_forces", c_void_p), ("contact_body_ids", c_void_p), ("num_contact_ids", c_int32), ("termination_heights", c_void_p),
+        ("progress", c_void_p), ("max_episode_length", c_float), ("enable_early_termination", c_int32),
+        ("dof_force", c_void_p), ("dof_vel", c_void_p), ("num_dof", c_int32), ("power_coef", c_float), ("power_reward", c_int32),
+        ("obs", c_void_p), ("obs_stride", c_int64), ("obs_offset", c_int32),
+        ("rew", c_void_p), ("rew_raw", c_void_p), ("rew_raw_width", c_int32), ("reset", c_void_p), ("terminate", c_void_p),
+    ]
+
+
+TASK_SPEED, TASK_REACH, TASK_STRIKE = 1, 2, 3
+TASK_OBS, TASK_REWARD, TASK_RESET = 1, 2, 4
 
 
 class AmpObsArgs(Structure):
@@ -139,7 +159,13 @@ SIGNATURES = {
     "pulse_sizeof_im_step_args": (c_int, []),
     "pulse_self_obs_width": (c_int, [c_int, c_int]),
     "pulse_task_obs_width": (c_int, [c_int, c_int, c_int]),
+    "pulse_self_obs_width_ex": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "pulse_im_step": (c_int, [POINTER(ImStepArgs), P]),
+    "pulse_sizeof_task_step_args": (c_int, []),
+    "pulse_task_obs_size": (c_int, [c_int]),
+    "pulse_task_step": (c_int, [POINTER(TaskStepArgs), P]),
+    "pulse_gemm_set_option": (c_int, [c_int, c_int]),
+    "pulse_gemm_set_debug_buffer": (c_int, [P]),
     "pulse_sizeof_amp_obs_args": (c_int, []),
     "pulse_amp_obs_width": (c_int, [c_int, c_int, c_int]),
     "pulse_amp_obs": (c_int, [POINTER(AmpObsArgs), P]),

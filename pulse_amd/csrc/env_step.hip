@@ -26,23 +26,46 @@ namespace pulse {
 constexpr int kLanesPerEnv = 32;
 
 struct ObsLayout {
-    int self_w;      // width of the self observation
+    int self_w;      // width of the self observation (all history steps / force-sensor rows included)
+    int self_step;   // width of one history step of the self observation
     int off_pos, off_rot, off_vel, off_ang;
     int task_w;      // width of the task observation
-    int per_t;       // task obs floats per future sample
+    int per_t;       // task obs floats per future sample (t-major variants 6 / 7 / 9)
 };
 
-__host__ __device__ inline ObsLayout make_layout(int J, int root_height_obs, int obs_version, int Jt, int T) {
+// task observation widths, humanoid_im.py:452-496: v1 15 Jt T, v2 + 3 (Jt - 1), v3 9 Jt T, v6 24 Jt T, v7 9 Jt T, v8 30 Jt (T = 1),
+// v9 (18 Jt + 6) T
+__host__ __device__ inline int task_per_t(int v, int Jt) {
+    return v == 7 ? 9 * Jt : v == 9 ? 18 * Jt + 6 : v == 6 ? 24 * Jt : v == 1 ? 15 * Jt : v == 2 ? 15 * Jt + 3 * (Jt - 1) : v == 3 ? 9 * Jt : 30 * Jt;
+}
+
+__host__ __device__ inline ObsLayout make_layout(int J, int root_height_obs, int obs_version, int Jt, int T, int self_v = 1, int hist = 1,
+                                                 int fs_w = 0) {
     ObsLayout L;
     const int h0 = root_height_obs ? 1 : 0;
     L.off_pos = h0;
     L.off_rot = h0 + 3 * (J - 1);
     L.off_vel = L.off_rot + 6 * J;
     L.off_ang = L.off_vel + 3 * J;
-    L.self_w = L.off_ang + 3 * J;
-    L.per_t = (obs_version == 7 ? 9 : 24) * Jt;
+    L.self_step = L.off_ang + 3 * J;
+    L.self_w = self_v == 2 ? L.self_step * hist : self_v == 3 ? L.self_step + fs_w : L.self_step;
+    L.per_t = task_per_t(obs_version, Jt);
     L.task_w = L.per_t * T;
     return L;
+}
+
+// offset of block X of tracked body j, future sample t inside the task observation.  Block ids: 0 diff pos (3), 1 diff rot (6),
+// 2 diff vel (3), 3 diff ang vel (3), 4 ref pos (3), 5 ref rot (6), 6 ref vel (3), 7 ref ang vel (3); -1 = not in this version.
+__device__ __forceinline__ int task_off(int v, int blk, int Jt, int T, int t, int j) {
+    const int w = (blk == 1 || blk == 5) ? 6 : 3;
+    if (v == 6) { const int base[8] = {0, 3, 9, 12, 15, 18, -1, -1}; return base[blk] < 0 ? -1 : t * 24 * Jt + base[blk] * Jt + w * j; }
+    if (v == 7) { const int base[8] = {0, -1, 3, -1, 6, -1, -1, -1}; return base[blk] < 0 ? -1 : t * 9 * Jt + base[blk] * Jt + w * j; }
+    if (v == 9) { const int base[8] = {0, 3, -1, -1, 9, 12, -1, -1}; return base[blk] < 0 ? -1 : t * (18 * Jt + 6) + base[blk] * Jt + (blk >= 4 ? 6 : 0) + w * j; }
+    if (v == 8) { const int base[8] = {0, 3, 9, 12, 15, 18, 24, 27}; return (blk < 4 && t > 0) ? -1 : base[blk] * Jt + w * j; }
+    // block-major over all samples: v1 / v2 (A B C D), v3 (A B)
+    const int base[8] = {0, 3, 9, 12, -1, -1, -1, -1};
+    if (base[blk] < 0 || (v == 3 && blk > 1)) return -1;
+    return base[blk] * Jt * T + w * (t * Jt + j);
 }
 
 __device__ __forceinline__ float group_sum(float v) {
@@ -88,6 +111,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     float* s_df = s_rx + E * T * J13p;         // [E][ndp]
     float* s_dv = s_df + E * ndp;              // [E][ndp]
     float* s_obs = s_dv + E * ndp;             // [E][colsp]
+    float* s_rd = s_obs + E * colsp;           // [E][ndp]    reference dof positions (obs_version 2 only)
 
     const int tid = threadIdx.x;
     const int slot = tid / kLanesPerEnv;
@@ -126,7 +150,8 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     const bool do_rew = a.what & PULSE_IM_REWARD;
     const bool do_rst = a.what & PULSE_IM_RESET;
     const bool need_now = do_rew || do_rst;
-    const ObsLayout L = make_layout(J, a.root_height_obs, a.obs_version, a.num_track, T);
+    const int H = a.self_obs_version == 2 ? a.hist_steps : 1;
+    const ObsLayout L = make_layout(J, a.root_height_obs, a.obs_version, a.num_track, T, a.self_obs_version, H, a.force_sensor_width);
 
     float* rb_e = s_rb + slot * J13p;
     float* rn_e = s_rn + slot * J13p;
@@ -134,10 +159,11 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     float* df_e = s_df + slot * ndp;
     float* dv_e = s_dv + slot * ndp;
     float* obs_e = s_obs + slot * colsp;
+    float* rd_e = s_rd + slot * ndp;
 
     // ---------------- stage inputs (global -> LDS, coalesced) ----------------
     if (valid) {
-        const float* g_rb = a.rb + e * a.rb_env_stride;
+        const float* g_rb = a.rb + e * a.rb_env_stride + (H - 1) * J13;      // the newest record of the history
         stage(rb_e, g_rb, J13, lane, aligned16(g_rb));
         if (a.use_motion) {
             // reference motion straight from the packed library: lane j blends body j of the two frame records
@@ -180,11 +206,14 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                             rec[10] = b.w.x; rec[11] = b.w.y; rec[12] = b.w.z;
                         }
                     }
-                    if (k == 0 && a.track_dof_pos && lane < J - 1) {
+                    if (k == 0 && (a.track_dof_pos || a.obs_version == 2) && lane < J - 1) {
                         V3 dp, dv;
                         blend_dof(M, fp.r0, fp.r1, fp.blend, lane, &dp, &dv);
-                        float* o = a.track_dof_pos + e * (3 * (J - 1)) + 3 * lane;  o[0] = dp.x; o[1] = dp.y; o[2] = dp.z;
-                        o = a.track_dof_vel + e * (3 * (J - 1)) + 3 * lane;         o[0] = dv.x; o[1] = dv.y; o[2] = dv.z;
+                        if (a.track_dof_pos) {
+                            float* o = a.track_dof_pos + e * (3 * (J - 1)) + 3 * lane;  o[0] = dp.x; o[1] = dp.y; o[2] = dp.z;
+                            o = a.track_dof_vel + e * (3 * (J - 1)) + 3 * lane;         o[0] = dv.x; o[1] = dv.y; o[2] = dv.z;
+                        }
+                        if (a.obs_version == 2) { float* o = rd_e + 3 * lane; o[0] = dp.x; o[1] = dp.y; o[2] = dp.z; }
                     }
                 }
             }
@@ -215,6 +244,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                         stage(d + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
                     }
                 }
+                if (a.obs_version == 2) stage(rd_e, a.ref_next_dof_pos + e * nd, nd, lane, false);
             }
         }
         if (do_rew && a.specs.power_reward) {
@@ -238,77 +268,91 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
             if (a.pass_time_out) a.pass_time_out[e] = pass_time ? 1 : 0;
         }
         const V3 root_p{rb_e[0], rb_e[1], rb_e[2]};
-        const Q4 root_q{rb_e[3], rb_e[4], rb_e[5], rb_e[6]};
+        Q4 root_q{rb_e[3], rb_e[4], rb_e[5], rb_e[6]};
+        if (!a.upright_start) root_q = qmul(root_q, Q4{-0.5f, -0.5f, -0.5f, 0.5f});   // remove_base_rot, humanoid.py:1616-1620
         const Q4 hinv = heading_quat(root_q, true);   // calc_heading_quat_inv
         const Q4 hfwd = heading_quat(root_q, false);  // calc_heading_quat
 
         if (do_self) {
-            if (lane < J) {
-                const float* r = rb_e + 13 * lane;
-                const V3 p{r[0], r[1], r[2]};
-                const Q4 q{r[3], r[4], r[5], r[6]};
-                const V3 v{r[7], r[8], r[9]};
-                const V3 w{r[10], r[11], r[12]};
-                if (lane >= 1) {
-                    const V3 lp = qrot(hinv, V3{p.x - root_p.x, p.y - root_p.y, p.z - root_p.z});
-                    float* o = obs_e + L.off_pos + 3 * (lane - 1);
-                    o[0] = lp.x; o[1] = lp.y; o[2] = lp.z;
-                } else if (a.root_height_obs) {
-                    obs_e[0] = root_p.z;
-                }
-                float tn[6];
-                if (lane == 0 && !a.local_root_obs) q_to_tan_norm(root_q, tn);   // humanoid.py:1707-1709
-                else q_to_tan_norm(qmul(hinv, q), tn);
-                float* o = obs_e + L.off_rot + 6 * lane;
+            for (int hs = 0; hs < H; ++hs) {
+                // history steps older than the newest are read straight from global memory (13 floats per lane)
+                const float* src = hs == H - 1 ? rb_e : a.rb + e * a.rb_env_stride + hs * J13;
+                float* ob = obs_e + hs * L.self_step;
+                if (lane < J) {
+                    const float* r = src + 13 * lane;
+                    const V3 p{r[0], r[1], r[2]};
+                    const Q4 q{r[3], r[4], r[5], r[6]};
+                    const V3 v{r[7], r[8], r[9]};
+                    const V3 w{r[10], r[11], r[12]};
+                    if (lane >= 1) {
+                        // every step is expressed relative to the NEWEST root (humanoid.py:1737-1753)
+                        const V3 lp = qrot(hinv, V3{p.x - root_p.x, p.y - root_p.y, p.z - root_p.z});
+                        float* o = ob + L.off_pos + 3 * (lane - 1);
+                        o[0] = lp.x; o[1] = lp.y; o[2] = lp.z;
+                    } else if (a.root_height_obs) {
+                        ob[0] = p.z;
+                    }
+                    float tn[6];
+                    if (lane == 0 && !a.local_root_obs) q_to_tan_norm(root_q, tn);   // humanoid.py:1707-1709 (after remove_base_rot)
+                    else q_to_tan_norm(qmul(hinv, q), tn);
+                    float* o = ob + L.off_rot + 6 * lane;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = tn[k];
-                const V3 lv = qrot(hinv, v);
-                o = obs_e + L.off_vel + 3 * lane;
-                o[0] = lv.x; o[1] = lv.y; o[2] = lv.z;
-                const V3 lw = qrot(hinv, w);
-                o = obs_e + L.off_ang + 3 * lane;
-                o[0] = lw.x; o[1] = lw.y; o[2] = lw.z;
+                    for (int k = 0; k < 6; ++k) o[k] = tn[k];
+                    const V3 lv = qrot(hinv, v);
+                    o = ob + L.off_vel + 3 * lane;
+                    o[0] = lv.x; o[1] = lv.y; o[2] = lv.z;
+                    const V3 lw = qrot(hinv, w);
+                    o = ob + L.off_ang + 3 * lane;
+                    o[0] = lw.x; o[1] = lw.y; o[2] = lw.z;
+                }
             }
+            if (a.self_obs_version == 3)                            // force-sensor readings appended (humanoid.py:1838)
+                for (int c = lane; c < a.force_sensor_width; c += kLanesPerEnv)
+                    obs_e[L.self_step + c] = a.force_sensor[e * a.force_sensor_width + c];
         }
 
         if (do_task && lane < a.num_track) {
-            const int Jt = a.num_track;
+            const int Jt = a.num_track, ov = a.obs_version;
             const int tb = a.track_ids[lane];
             const float* r = rb_e + 13 * tb;
             const V3 p{r[0], r[1], r[2]};
             const Q4 q{r[3], r[4], r[5], r[6]};
             const V3 v{r[7], r[8], r[9]};
             const V3 w{r[10], r[11], r[12]};
+            float* tob = obs_e + L.self_w;
+            auto put3 = [&](int off, const V3& x) { if (off >= 0) { float* o = tob + off; o[0] = x.x; o[1] = x.y; o[2] = x.z; } };
+            auto put6 = [&](int off, const float* x) { if (off >= 0) { float* o = tob + off; for (int k = 0; k < 6; ++k) o[k] = x[k]; } };
             for (int t = 0; t < T; ++t) {
                 const float* x = rx_e + t * J13p;
                 const V3 pr{x[3 * tb], x[3 * tb + 1], x[3 * tb + 2]};
                 const V3 vr{x[J * 7 + 3 * tb], x[J * 7 + 3 * tb + 1], x[J * 7 + 3 * tb + 2]};
-                float* ob = obs_e + L.self_w + t * L.per_t;
-                const V3 d1 = qrot(hinv, V3{pr.x - p.x, pr.y - p.y, pr.z - p.z});
-                const V3 d3 = qrot(hinv, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z});
-                const V3 d5 = qrot(hinv, V3{pr.x - root_p.x, pr.y - root_p.y, pr.z - root_p.z});
-                if (a.obs_version == 7) {
-                    float* o = ob + 3 * lane;            o[0] = d1.x; o[1] = d1.y; o[2] = d1.z;
-                    o = ob + 3 * Jt + 3 * lane;          o[0] = d3.x; o[1] = d3.y; o[2] = d3.z;
-                    o = ob + 6 * Jt + 3 * lane;          o[0] = d5.x; o[1] = d5.y; o[2] = d5.z;
-                } else {
+                put3(task_off(ov, 0, Jt, T, t, lane), qrot(hinv, V3{pr.x - p.x, pr.y - p.y, pr.z - p.z}));
+                put3(task_off(ov, 2, Jt, T, t, lane), qrot(hinv, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z}));
+                put3(task_off(ov, 4, Jt, T, t, lane), qrot(hinv, V3{pr.x - root_p.x, pr.y - root_p.y, pr.z - root_p.z}));
+                put3(task_off(ov, 6, Jt, T, t, lane), qrot(hinv, vr));
+                if (ov != 7) {
                     const Q4 qr{x[J * 3 + 4 * tb], x[J * 3 + 4 * tb + 1], x[J * 3 + 4 * tb + 2], x[J * 3 + 4 * tb + 3]};
                     const V3 wr{x[J * 10 + 3 * tb], x[J * 10 + 3 * tb + 1], x[J * 10 + 3 * tb + 2]};
-                    float* o = ob + 3 * lane;            o[0] = d1.x; o[1] = d1.y; o[2] = d1.z;
                     float tn[6];
-                    q_to_tan_norm(qmul(qmul(hinv, qmul(qr, qconj(q))), hfwd), tn);   // change of basis
-                    o = ob + 3 * Jt + 6 * lane;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) o[k] = tn[k];
-                    o = ob + 9 * Jt + 3 * lane;          o[0] = d3.x; o[1] = d3.y; o[2] = d3.z;
-                    const V3 d4 = qrot(hinv, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z});
-                    o = ob + 12 * Jt + 3 * lane;         o[0] = d4.x; o[1] = d4.y; o[2] = d4.z;
-                    o = ob + 15 * Jt + 3 * lane;         o[0] = d5.x; o[1] = d5.y; o[2] = d5.z;
-                    q_to_tan_norm(qmul(hinv, qr), tn);
-                    o = ob + 18 * Jt + 6 * lane;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) o[k] = tn[k];
+                    int off = task_off(ov, 1, Jt, T, t, lane);
+                    if (off >= 0) { q_to_tan_norm(qmul(qmul(hinv, qmul(qr, qconj(q))), hfwd), tn); put6(off, tn); }   // change of basis
+                    put3(task_off(ov, 3, Jt, T, t, lane), qrot(hinv, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z}));
+                    off = task_off(ov, 5, Jt, T, t, lane);
+                    if (off >= 0) { q_to_tan_norm(qmul(hinv, qr), tn); put6(off, tn); }
+                    put3(task_off(ov, 7, Jt, T, t, lane), qrot(hinv, wr));
+                    if (ov == 9 && lane == 0) {          // root velocity differences (tracked body 0), humanoid_im.py:1510-1517
+                        const int base = t * (18 * Jt + 6) + 9 * Jt;
+                        put3(base, qrot(hinv, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z}));
+                        put3(base + 3, qrot(hinv, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z}));
+                    }
                 }
+            }
+            if (ov == 2 && lane >= 1) {                  // dof differences of the tracked joints (humanoid_im.py:755-758, 1293-1294)
+                const int d0 = 3 * (tb - 1);
+                const float* cur = a.dof_pos + e * nd + d0;
+                const float* ref = rd_e + d0;
+                float* o = tob + 15 * Jt * T + 3 * (lane - 1);
+                o[0] = ref[0] - cur[0]; o[1] = ref[1] - cur[1]; o[2] = ref[2] - cur[2];
             }
         }
 
@@ -377,7 +421,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
             }
             if (lane == 0) {
                 const bool pt = pass_time;
-                int64_t term = (fallen && prog > 1) ? 1 : 0;
+                int64_t term = (a.enable_early_termination && fallen && prog > 1) ? 1 : 0;
                 int64_t rst = pt ? 1 : term;
                 if (a.cycle_counter && !pt && a.cycle_counter[e] > 0) { rst = 0; term = 0; }
                 a.reset[e] = rst;
@@ -413,6 +457,9 @@ int pulse_sizeof_im_step_args(void) { return (int)sizeof(pulse_im_step_args); }
 int pulse_self_obs_width(int num_bodies, int root_height_obs) {
     return make_layout(num_bodies, root_height_obs, 6, 0, 1).self_w;
 }
+int pulse_self_obs_width_ex(int num_bodies, int root_height_obs, int self_obs_version, int hist_steps, int force_sensor_width) {
+    return make_layout(num_bodies, root_height_obs, 6, 0, 1, self_obs_version, hist_steps, force_sensor_width).self_w;
+}
 int pulse_task_obs_width(int obs_version, int num_track, int time_steps) {
     return make_layout(1, 0, obs_version, num_track, time_steps).task_w;
 }
@@ -428,7 +475,13 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
     PULSE_REQUIRE(a.rb_env_stride >= (int64_t)a.num_bodies * 13, "pulse_im_step: rb_env_stride too small");
     PULSE_REQUIRE(a.time_steps >= 1, "pulse_im_step: time_steps < 1");
     const bool do_obs = a.what & (PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS);
-    const ObsLayout L = make_layout(a.num_bodies, a.root_height_obs, a.obs_version, a.num_track, a.time_steps);
+    PULSE_REQUIRE(a.self_obs_version >= 1 && a.self_obs_version <= 3, "pulse_im_step: self_obs_version %d unsupported (1|2|3)", a.self_obs_version);
+    const int hist = a.self_obs_version == 2 ? a.hist_steps : 1;
+    PULSE_REQUIRE(hist >= 1, "pulse_im_step: hist_steps < 1");
+    PULSE_REQUIRE(a.rb_env_stride >= (int64_t)hist * a.num_bodies * 13, "pulse_im_step: rb_env_stride does not cover the history");
+    PULSE_REQUIRE(a.self_obs_version != 3 || (a.force_sensor != nullptr && a.force_sensor_width >= 0), "pulse_im_step: self_obs_version 3 needs force_sensor");
+    const ObsLayout L = make_layout(a.num_bodies, a.root_height_obs, a.obs_version, a.num_track, a.time_steps, a.self_obs_version, hist,
+                                    a.force_sensor_width);
     if (do_obs) {
         PULSE_REQUIRE(a.obs != nullptr, "pulse_im_step: null obs");
         PULSE_REQUIRE(a.obs_cols >= L.self_w + ((a.what & PULSE_IM_TASK_OBS) ? L.task_w : 0),
@@ -436,7 +489,12 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
         PULSE_REQUIRE(a.obs_stride >= a.obs_cols, "pulse_im_step: obs_stride < obs_cols");
     }
     if (a.what & PULSE_IM_TASK_OBS) {
-        PULSE_REQUIRE(a.obs_version == 6 || a.obs_version == 7, "pulse_im_step: obs_version %d unsupported (6|7)", a.obs_version);
+        const int ov = a.obs_version;
+        PULSE_REQUIRE(ov == 1 || ov == 2 || ov == 3 || ov == 6 || ov == 7 || ov == 8 || ov == 9, "pulse_im_step: obs_version %d unsupported (1|2|3|6|7|8|9)", ov);
+        PULSE_REQUIRE((ov != 8 && ov != 2) || a.time_steps == 1, "pulse_im_step: obs_version %d takes one reference sample (the reference indexes a column for T > 1)", ov);
+        if (ov == 2) {
+            PULSE_REQUIRE(a.dof_pos && a.num_dof == 3 * (a.num_bodies - 1) && (a.use_motion || a.ref_next_dof_pos), "pulse_im_step: obs_version 2 needs dof_pos / ref_next_dof_pos");
+        }
         PULSE_REQUIRE(a.track_ids != nullptr && a.num_track >= 1 && a.num_track <= a.num_bodies, "pulse_im_step: bad track ids");
         if (!a.use_motion) {
             PULSE_REQUIRE(a.ref_next_pos && a.ref_next_vel, "pulse_im_step: null ref_next");
@@ -473,7 +531,7 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
     const int J13p = (a.num_bodies * 13 + 3) & ~3;
     const int ndp = (a.num_dof + 3) & ~3;
     const int colsp = do_obs ? ((a.obs_cols + 3) & ~3) : 0;
-    const size_t lds = sizeof(float) * (size_t)E * ((2 + a.time_steps) * J13p + 2 * ndp + colsp);
+    const size_t lds = sizeof(float) * (size_t)E * ((2 + a.time_steps) * J13p + 3 * ndp + colsp);
     PULSE_REQUIRE(lds <= 160 * 1024, "pulse_im_step: LDS request %zu > 160 KiB", lds);
     const unsigned grid = (unsigned)((count + E - 1) / E);
     if (lds > 48 * 1024) {

@@ -189,7 +189,8 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
             reset_use_mean=False, full_body_reward=True, obs_version=6, local_root_obs=True,
             root_height_obs=True, specs=None, power_coef=0.0005, power_reward=True,
             env_ids=None, env_mask=None, obs=None, obs_cols=None, rew=None, rew_raw=None, reset=None,
-            terminate=None, clock=None, motion=None):
+            terminate=None, clock=None, motion=None, upright=True, enable_early_termination=True, self_obs_version=1,
+            force_sensor=None, dof_pos=None, ref_next_dof_pos=None):
     """``clock``: dict(progress_rw, inc, dt, start_times, start_offsets, motion_len, cycle_motion, max_episode_length,
     pass_time_out) -- the episode clock advanced / evaluated in-kernel.  ``motion``: dict(lib, ids, offset, traj_dt, track_rb,
     track_dof_pos, track_dof_vel) -- the reference evaluated in-kernel from a MotionLib instead of ref_now / ref_next.
@@ -198,9 +199,20 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
     not supplied are allocated.  Returns dict(obs, rew, rew_raw, reset, terminate)."""
     lib = _lib.load()
     rb = _dev(rb, "rb")
-    if rb.dim() != 3 or rb.shape[-1] != 13 or rb.stride()[-1] != 1 or rb.stride()[-2] != 13:
-        raise ValueError("rb must be (N, J, 13) with contiguous body records")
-    n, j = rb.shape[0], rb.shape[1]
+    hist = 1
+    if self_obs_version == 2:                      # (N, H, J, 13) history, oldest first (compute_humanoid_observations_smpl_max_v2)
+        if rb.dim() != 4 or not rb[0].is_contiguous():
+            raise ValueError("self_obs_version 2 takes rb as (N, H, J, 13) with contiguous per-env histories")
+        hist = rb.shape[1]
+        rb = rb.view(rb.shape[0], hist * rb.shape[2], 13) if rb.is_contiguous() else rb
+    if rb.dim() == 4:
+        n, j = rb.shape[0], rb.shape[2]
+        rb_stride = rb.stride()[0]
+    else:
+        if rb.dim() != 3 or rb.shape[-1] != 13 or rb.stride()[-1] != 1 or rb.stride()[-2] != 13:
+            raise ValueError("rb must be (N, J, 13) with contiguous body records")
+        n, j = rb.shape[0], rb.shape[1] // hist
+        rb_stride = rb.stride()[0]
     dev = rb.device
     a = ImStepArgs()
     keep = []  # keep temporaries alive until the call returns
@@ -212,7 +224,16 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         keep.append(t)
         return t.data_ptr()
 
-    a.rb, a.rb_env_stride, a.num_envs, a.num_bodies = rb.data_ptr(), rb.stride()[0], n, j
+    a.rb, a.rb_env_stride, a.num_envs, a.num_bodies = rb.data_ptr(), rb_stride, n, j
+    a.upright_start, a.enable_early_termination = int(bool(upright)), int(bool(enable_early_termination))
+    a.self_obs_version, a.hist_steps = int(self_obs_version), hist
+    fsw = 0
+    if force_sensor is not None:
+        a.force_sensor, a.force_sensor_width = P(force_sensor, "force_sensor"), force_sensor.shape[-1]
+        fsw = force_sensor.shape[-1]
+    a.dof_pos, a.ref_next_dof_pos = P(dof_pos, "dof_pos"), P(ref_next_dof_pos, "ref_next_dof_pos")
+    if dof_pos is not None and dof_force is None:
+        a.num_dof = dof_pos.shape[-1]
     if env_ids is not None:
         env_ids = _c(env_ids, "env_ids", torch.int64)
         keep.append(env_ids)
@@ -230,7 +251,8 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         a.ref_next_rot, a.ref_next_ang = P(ref_next.get("rot"), "ref_next.rot"), P(ref_next.get("ang"), "ref_next.ang")
     a.time_steps = time_steps
     a.dof_force, a.dof_vel = P(dof_force, "dof_force"), P(dof_vel, "dof_vel")
-    a.num_dof = dof_force.shape[-1] if dof_force is not None else 0
+    if dof_force is not None:
+        a.num_dof = dof_force.shape[-1]
     a.progress = P(progress, "progress", torch.int64)
     if pass_time is not None:
         pt = pass_time.view(torch.uint8) if pass_time.dtype == torch.bool else pass_time
@@ -252,7 +274,7 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
 
     out = {}
     if what & (PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS):
-        sw = lib.pulse_self_obs_width(j, int(root_height_obs))
+        sw = lib.pulse_self_obs_width_ex(j, int(root_height_obs), int(self_obs_version), hist, fsw)
         tw = lib.pulse_task_obs_width(obs_version, a.num_track, time_steps) if what & PULSE_IM_TASK_OBS else 0
         width = sw + tw
         if obs is None:
@@ -301,11 +323,38 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
 def compute_humanoid_observations_smpl_max(body_pos, body_rot, body_vel, body_ang_vel, smpl_params=None,
                                            limb_weight_params=None, local_root_obs=True, root_height_obs=True,
                                            upright=True, has_smpl_params=False, has_limb_weight_params=False):
-    """phc/env/tasks/humanoid.py:1675-1731 (upright start, no shape / limb obs)."""
-    if not upright or has_smpl_params or has_limb_weight_params:
-        raise NotImplementedError("only upright=True without shape / limb-weight observations is supported")
+    """phc/env/tasks/humanoid.py:1675-1731 (no shape / limb obs); upright=False applies remove_base_rot (:1616-1620)."""
+    if has_smpl_params or has_limb_weight_params:
+        raise NotImplementedError("shape / limb-weight observations are not supported")
     rb = pack_rb(body_pos, body_rot, body_vel, body_ang_vel)
-    return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=local_root_obs, root_height_obs=root_height_obs)["obs"]
+    return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=local_root_obs, root_height_obs=root_height_obs, upright=upright)["obs"]
+
+
+def compute_humanoid_observations_smpl_max_v2(body_pos, body_rot, body_vel, body_ang_vel, smpl_params=None, limb_weight_params=None,
+                                              local_root_obs=True, root_height_obs=True, upright=True, has_smpl_params=False,
+                                              has_limb_weight_params=False, time_steps=1):
+    """phc/env/tasks/humanoid.py:1734-1786: (B, T, J, .) history in the heading frame of the newest root."""
+    if has_smpl_params or has_limb_weight_params or not local_root_obs:
+        raise NotImplementedError("the reference itself raises for these options (humanoid.py:1766-1783)")
+    rb = torch.cat([body_pos, body_rot, body_vel, body_ang_vel], dim=-1).contiguous()
+    return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=True, root_height_obs=root_height_obs, upright=upright, self_obs_version=2)["obs"]
+
+
+def compute_humanoid_observations_smpl_max_v3(body_pos, body_rot, body_vel, body_ang_vel, force_sensor_readings, smpl_params=None,
+                                              limb_weight_params=None, local_root_obs=True, root_height_obs=True, upright=True,
+                                              has_smpl_params=False, has_limb_weight_params=False):
+    """phc/env/tasks/humanoid.py:1789-1849: _smpl_max + the force-sensor readings."""
+    if has_smpl_params or has_limb_weight_params:
+        raise NotImplementedError("shape / limb-weight observations are not supported")
+    rb = pack_rb(body_pos, body_rot, body_vel, body_ang_vel)
+    return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=local_root_obs, root_height_obs=root_height_obs, upright=upright,
+                   self_obs_version=3, force_sensor=force_sensor_readings)["obs"]
+
+
+def remove_base_rot(quat):
+    """phc/env/tasks/humanoid.py:1616-1620."""
+    base = torch.tensor([[-0.5, -0.5, -0.5, 0.5]], dtype=torch.float32, device=quat.device).repeat(quat.shape[0], 1)
+    return quat_mul(quat, base)
 
 
 def _split_task_only(full, self_w):
@@ -316,23 +365,57 @@ def compute_imitation_observations_v6(root_pos, root_rot, body_pos, body_rot, bo
                                       ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps, upright=True):
     """phc/env/tasks/humanoid_im.py:1328-1378.  body_* are the tracked subset (B, Jt, .); the root
     is passed separately exactly as in the reference."""
-    if not upright:
-        raise NotImplementedError("upright=False (remove_base_rot) is not supported")
     return _task_obs(6, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
-                     ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps)
+                     ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps, upright)
+
+
+def compute_imitation_observations(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+                                   ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps, upright=True):
+    """obs_v 1, phc/env/tasks/humanoid_im.py:1222-1256."""
+    return _task_obs(1, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_body_pos, ref_body_rot, ref_body_vel,
+                     ref_body_ang_vel, time_steps, upright)
+
+
+def compute_imitation_observations_v2(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, dof_pos, ref_body_pos, ref_body_rot,
+                                      ref_body_vel, ref_body_ang_vel, ref_dof_pos, time_steps, upright=True):
+    """obs_v 2, phc/env/tasks/humanoid_im.py:1259-1297: v1 + dof differences (dof_pos / ref_dof_pos: (B, Jt - 1, 3) subsets)."""
+    return _task_obs(2, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_body_pos, ref_body_rot, ref_body_vel,
+                     ref_body_ang_vel, time_steps, upright, dof_pos=dof_pos, ref_dof_pos=ref_dof_pos)
+
+
+def compute_imitation_observations_v3(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+                                      ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps, upright=True):
+    """obs_v 3, phc/env/tasks/humanoid_im.py:1300-1325."""
+    return _task_obs(3, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_body_pos, ref_body_rot, ref_body_vel,
+                     ref_body_ang_vel, time_steps, upright)
+
+
+def compute_imitation_observations_v8(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+                                      ref_body_pos, ref_body_rot, ref_body_vel, ref_body_ang_vel, time_steps, upright=True):
+    """obs_v 8, phc/env/tasks/humanoid_im.py:1415-1481 (time_steps 1)."""
+    return _task_obs(8, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_body_pos, ref_body_rot, ref_body_vel,
+                     ref_body_ang_vel, time_steps, upright)
+
+
+def compute_imitation_observations_v9(root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel,
+                                      ref_body_pos, ref_body_rot, ref_root_vel, ref_root_ang_vel, time_steps, upright=True):
+    """obs_v 9, phc/env/tasks/humanoid_im.py:1484-1540: the reference passes only the ROOT reference velocities."""
+    b, jt = body_pos.shape[0], body_pos.shape[1]
+    rv = torch.zeros(b * time_steps, jt, 3, dtype=torch.float32, device=body_pos.device)
+    ra = torch.zeros_like(rv)
+    rv[:, 0], ra[:, 0] = ref_root_vel.reshape(-1, 3), ref_root_ang_vel.reshape(-1, 3)
+    return _task_obs(9, root_pos, root_rot, body_pos, body_rot, body_vel, body_ang_vel, ref_body_pos, ref_body_rot, rv, ra, time_steps, upright)
 
 
 def compute_imitation_observations_v7(root_pos, root_rot, body_pos, body_vel, ref_body_pos, ref_body_vel, time_steps, upright=True):
     """phc/env/tasks/humanoid_im.py:1381-1413."""
-    if not upright:
-        raise NotImplementedError("upright=False (remove_base_rot) is not supported")
     z4 = torch.zeros(body_pos.shape[:-1] + (4,), dtype=torch.float32, device=body_pos.device)
     z4[..., 3] = 1.0
     z3 = torch.zeros_like(body_pos)
-    return _task_obs(7, root_pos, root_rot, body_pos, z4, body_vel, z3, ref_body_pos, None, ref_body_vel, None, time_steps)
+    return _task_obs(7, root_pos, root_rot, body_pos, z4, body_vel, z3, ref_body_pos, None, ref_body_vel, None, time_steps, upright)
 
 
-def _task_obs(version, root_pos, root_rot, bp, br, bv, ba, rp, rr, rv, ra, time_steps):
+def _task_obs(version, root_pos, root_rot, bp, br, bv, ba, rp, rr, rv, ra, time_steps, upright=True, dof_pos=None, ref_dof_pos=None):
     # The kernel indexes bodies through a track list and reads the root from body 0, so build
     # a (B, 1 + Jt, 13) record array: slot 0 = root, slots 1.. = the tracked subset.
     b, jt = bp.shape[0], bp.shape[1]
@@ -354,8 +437,16 @@ def _task_obs(version, root_pos, root_rot, bp, br, bv, ba, rp, rr, rv, ra, time_
     sw = lib.pulse_self_obs_width(j, 1)
     tw = lib.pulse_task_obs_width(version, jt, time_steps)
     full = torch.empty(b, sw + tw, dtype=torch.float32, device=dev)
+    kw = {}
+    if version == 2:
+        # joint (track id - 1) of the packed array = subset joint of tracked body i >= 1 (the root carries no dof)
+        def dof_full(d):
+            f = torch.zeros(b, 3 * (j - 1), dtype=torch.float32, device=dev)
+            f[:, 3:] = d.reshape(b, -1)
+            return f
+        kw = {"dof_pos": dof_full(dof_pos), "ref_next_dof_pos": dof_full(ref_dof_pos)}
     im_step(rb, what=PULSE_IM_TASK_OBS, ref_next=ref_next, time_steps=time_steps, obs_version=version,
-            track_ids=list(range(1, j)), obs=full)
+            track_ids=list(range(1, j)), obs=full, upright=upright, **kw)
     return full[:, sw:]
 
 
@@ -392,6 +483,78 @@ def compute_humanoid_im_reset(reset_buf, progress_buf, contact_buf, contact_body
     out = im_step(rb, what=PULSE_IM_RESET, ref_now=ref, progress=progress_buf, pass_time=pass_time,
                   reset_ids=list(range(jr)), term_dist=td.contiguous(), reset_use_mean=use_mean)
     return out["reset"], out["terminate"]
+
+
+# --------------------------------------------------------------------------- #
+# downstream tasks (speed / reach / strike): one launch of pulse_task_step
+# --------------------------------------------------------------------------- #
+def task_step(task, rb, *, what, prev_root_pos=None, dt=1.0 / 30.0, tar_speed=None, tar_pos=None, reach_body_id=0, tar_states=None,
+              tar_contact_forces=None, strike_body_ids=None, contact_forces=None, contact_body_ids=None, termination_heights=None,
+              progress=None, max_episode_length=300.0, enable_early_termination=True, dof_force=None, dof_vel=None, power_coef=0.0005,
+              power_reward=False, obs=None, obs_offset=0, rew=None, rew_raw=None, reset=None, terminate=None, env_ids=None, env_mask=None):
+    """``task``: 'speed' | 'reach' | 'strike'.  ``rb`` (N, J, 13).  Returns dict(obs, rew, rew_raw, reset, terminate) of what was asked."""
+    from ._lib import TASK_OBS, TASK_REACH, TASK_RESET, TASK_REWARD, TASK_SPEED, TASK_STRIKE, TaskStepArgs
+    lib = _lib.load()
+    rb = _dev(rb, "rb")
+    n, j = rb.shape[0], rb.shape[1]
+    dev = rb.device
+    a = TaskStepArgs()
+    keep = []
+
+    def P(t, name, dtype=torch.float32):
+        if t is None:
+            return None
+        t = _c(t, name, dtype)
+        keep.append(t)
+        return t.data_ptr()
+
+    a.task = {"speed": TASK_SPEED, "reach": TASK_REACH, "strike": TASK_STRIKE}[task]
+    a.what, a.num_envs = what, n
+    a.rb, a.rb_env_stride, a.num_bodies = rb.data_ptr(), rb.stride()[0], j
+    if env_ids is not None:
+        env_ids = _c(env_ids, "env_ids", torch.int64)
+        keep.append(env_ids)
+        a.env_ids, a.num_ids = env_ids.data_ptr(), env_ids.numel()
+    if env_mask is not None:
+        a.env_mask = P(env_mask.view(torch.uint8) if env_mask.dtype == torch.bool else env_mask, "env_mask", torch.uint8)
+    a.prev_root_pos, a.dt = P(prev_root_pos, "prev_root_pos"), float(dt)
+    a.tar_speed, a.tar_pos, a.reach_body_id = P(tar_speed, "tar_speed"), P(tar_pos, "tar_pos"), int(reach_body_id)
+    a.tar_states, a.tar_contact_forces = P(tar_states, "tar_states"), P(tar_contact_forces, "tar_contact_forces")
+    for name, ids in (("strike", strike_body_ids), ("contact", contact_body_ids)):
+        if ids is not None:
+            t = _ids32(ids, dev)
+            keep.append(t)
+            if name == "strike":
+                a.strike_body_ids, a.num_strike = t.data_ptr(), t.numel()
+            else:
+                a.contact_body_ids, a.num_contact_ids = t.data_ptr(), t.numel()
+    a.contact_forces, a.termination_heights = P(contact_forces, "contact_forces"), P(termination_heights, "termination_heights")
+    a.progress, a.max_episode_length = P(progress, "progress", torch.int64), float(max_episode_length)
+    a.enable_early_termination = int(bool(enable_early_termination))
+    a.dof_force, a.dof_vel = P(dof_force, "dof_force"), P(dof_vel, "dof_vel")
+    a.num_dof = dof_force.shape[-1] if dof_force is not None else 0
+    a.power_coef, a.power_reward = float(power_coef), int(bool(power_reward))
+    out = {}
+    if what & TASK_OBS:
+        w = lib.pulse_task_obs_size(a.task)
+        if obs is None:
+            obs = torch.empty(n, obs_offset + w, dtype=torch.float32, device=dev)
+        _dev(obs, "obs")
+        a.obs, a.obs_stride, a.obs_offset = obs.data_ptr(), obs.stride()[0], int(obs_offset)
+        out["obs"] = obs
+    if what & TASK_REWARD:
+        rw = 2 if power_reward else 1
+        rew = torch.empty(n, dtype=torch.float32, device=dev) if rew is None else _dev(rew, "rew")
+        rew_raw = torch.empty(n, rw, dtype=torch.float32, device=dev) if rew_raw is None else _dev(rew_raw, "rew_raw")
+        a.rew, a.rew_raw, a.rew_raw_width = rew.data_ptr(), rew_raw.data_ptr(), rew_raw.shape[-1]
+        out["rew"], out["rew_raw"] = rew, rew_raw
+    if what & TASK_RESET:
+        reset = torch.empty(n, dtype=torch.int64, device=dev) if reset is None else _dev(reset, "reset", torch.int64)
+        terminate = torch.empty(n, dtype=torch.int64, device=dev) if terminate is None else _dev(terminate, "terminate", torch.int64)
+        a.reset, a.terminate = reset.data_ptr(), terminate.data_ptr()
+        out["reset"], out["terminate"] = reset, terminate
+    _lib.check(lib.pulse_task_step(ctypes.byref(a), _stream()), "pulse_task_step")
+    return out
 
 
 # --------------------------------------------------------------------------- #

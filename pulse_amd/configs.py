@@ -41,6 +41,17 @@ ENV_IM_VAE = dict(ENV_IM, **{   # phc/data/cfg/env/env_im_vae.yaml:19-55 (PULSE 
     "use_vae_clamped_prior": True, "vae_var_clamp_max": 2, "kld_coefficient": 0.01, "kld_coefficient_min": 0.001, "kld_anneal": True,
     "ar1_coefficient": 0.005, "only_kin_loss": True, "distill": True, "save_kin_info": True, "cycle_motion": True})
 
+NETWORK_Z_READER = {      # phc/data/cfg/learning/pulse_z_task.yaml:10-44 (network: amp_z_reader)
+    "name": "amp_z_reader", "separate": True,
+    "space": {"continuous": {"mu_activation": "None", "sigma_activation": "None", "mu_init": {"name": "default"},
+                             "sigma_init": {"name": "const_initializer", "val": -1.0}, "fixed_sigma": True, "learn_sigma": False}},
+    "mlp": {"units": [2048, 1024, 512], "activation": "silu", "d2rl": False, "initializer": {"name": "default"}},
+}
+
+ENV_SPEED_Z = {"local_root_obs": True, "root_height_obs": True, "enableEarlyTermination": True, "episode_length": 300, "enableTaskObs": True,
+               "tarSpeedMin": 0.0, "tarSpeedMax": 5.0, "speedChangeStepsMin": 100, "speedChangeStepsMax": 200, "power_reward": True,
+               "embedding_size": 32, "z_type": "vae"}     # phc/data/cfg/env/env_pulse_amp.yaml (HumanoidSpeedZ)
+
 CONFIGS = {
     # BASELINE.json configs[0]: 64-env synthetic rollout (horizon 16), 2x512 MLP, one PPO+GAE epoch
     "cfg1": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "units": [512, 512]},
@@ -57,6 +68,10 @@ CONFIGS = {
     "cfg5_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "units": [512, 512], "env": "amp", "agent": "amp",
                    "extra": {"enable_disc": True, "amp_minibatch_size": 64, "amp_obs_demo_buffer_size": 4096, "amp_replay_buffer_size": 4096,
                              "amp_batch_size": 128}},
+    # downstream task on a frozen PULSE decoder: HumanoidSpeedZ, policy = amp_z_reader (learning=pulse_z_task), latent action 32
+    "speed_z": {"num_envs": 4096, "horizon_length": 32, "minibatch_size": 16384, "network": "amp_z_reader", "env": "speed_z", "agent": "amp"},
+    "speed_z_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_z_reader", "env": "speed_z", "agent": "amp",
+                      "units": [256, 128]},
     # small shapes of the same graphs for tests
     "cfg3_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_z", "env": "vae", "agent": "amp",
                    "extra": {"use_seq_rl": True}},
@@ -68,6 +83,10 @@ def agent_config(name, **overrides):
     c = CONFIGS[name]
     if c.get("network") == "amp_z":
         net = copy.deepcopy(NETWORK_Z)
+    elif c.get("network") == "amp_z_reader":
+        net = copy.deepcopy(NETWORK_Z_READER)
+        if "units" in c:
+            net["mlp"]["units"] = list(c["units"])
     else:
         net = copy.deepcopy(NETWORK_IM)
         net["mlp"]["units"] = list(c["units"])
@@ -83,6 +102,22 @@ def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kin
     """``reference``: 'recorded' = pre-recorded rigid-body / reference frames (RecordedRollout, what the CPU oracle agent replays);
     'motion_lib' = reference motion queried from the HBM-resident MotionLib every step, physics stand-in tracking it."""
     from .env.humanoid_im import HumanoidIm, VecTaskPythonWrapper
+    if env_kind in ("speed_z", "reach_z", "strike_z"):
+        # HumanoidSpeedZ & co: synthetic task physics, the frozen decoder initialised from a (random-init) PULSE checkpoint
+        import torch
+        from .env import humanoid_tasks as HT
+        from .learning.network_z import AMPZNetwork
+        env_cfg = dict(ENV_SPEED_Z)
+        env_cfg.update(env_overrides or {})
+        sim = HT.SyntheticTaskSim(num_envs, horizon + 1, device, seed=seed, rank=rank)
+        cls = {"speed_z": HT.HumanoidSpeedZ, "reach_z": HT.HumanoidReachZ, "strike_z": HT.HumanoidStrikeZ}[env_kind]
+        task = cls({"env": env_cfg}, sim, device=device)
+        znet = AMPZNetwork(NETWORK_Z, actions_num=69, self_obs_size=task.get_self_obs_size(), task_obs_size=576,
+                           task_obs_size_detail={"embedding_size": 32, "z_type": "vae", "use_vae_prior": True, "use_vae_clamped_prior": True,
+                                                 "vae_var_clamp_max": 2}, device=device)
+        rms = {"running_mean": torch.zeros(934, dtype=torch.float64), "running_var": torch.ones(934, dtype=torch.float64)}
+        task.initialize_z_models({"model": znet.state_dict(), "running_mean_std": rms}, NETWORK_Z)
+        return VecTaskPythonWrapper(task, rl_device=device), None
     env_cfg = dict(ENV_IM_VAE) if env_kind in ("vae", "vae_ppo") else dict(ENV_IM)
     if env_kind == "vae_ppo":
         env_cfg.update({"only_kin_loss": False, "save_kin_info": False, "distill": False})

@@ -54,14 +54,22 @@ class HumanoidIm:
         self.dt = 2.0 / 60.0                                                   # controlFrequencyInv 2 @ 60 Hz
         self.obs_v = int(env.get("obs_v", 6))
         self.self_obs_v = int(env.get("self_obs_v", 1))
-        if self.self_obs_v != 1 or self.obs_v not in (6, 7):
-            raise NotImplementedError("self_obs_v 1 with obs_v 6 | 7 are built (SURVEY.md 8a); others are listed as next")
+        if self.self_obs_v not in (1, 2, 3) or self.obs_v not in (1, 2, 3, 6, 7, 8, 9):
+            raise NotImplementedError("self_obs_v 1 | 2 | 3 with obs_v 1 | 2 | 3 | 6 | 7 | 8 | 9 (4 / 5 need the 10-step / one-hot inputs of "
+                                      "humanoid_im.py:467-475, which no shipped config enables)")
+        self._has_upright_start = bool(env.get("has_upright_start", True))      # robot/smpl_humanoid.yaml:7
+        self.past_track_steps = int(env.get("past_track_steps", 5))            # humanoid.py:330 (self_obs_v 2)
+        self.force_sensor_joints = list(env.get("force_sensor_joints", ["L_Ankle", "R_Ankle"]))   # humanoid.py:263 (self_obs_v 3)
         self._fut_tracks = bool(env.get("fut_tracks", False))
         self._num_traj_samples = int(env.get("numTrajSamples", 3)) if self._fut_tracks else 1
         self._traj_sample_timestep = 1.0 / float(env.get("trajSampleTimestepInv", 30))   # humanoid_im.py:80-82
         self._use_motion_lib = hasattr(motion_lib, "query")           # HBM-resident MotionLib vs recorded reference frames
         if self._fut_tracks and not self._use_motion_lib:
             raise NotImplementedError("fut_tracks samples future reference frames: needs the MotionLib reference source")
+        if self.obs_v in (2, 8) and self._num_traj_samples != 1:
+            raise NotImplementedError("obs_v 2 / 8 take one reference sample (the reference views a column for T > 1, humanoid_im.py:1293,1466)")
+        if self.obs_v == 2 and not self._use_motion_lib:
+            raise NotImplementedError("obs_v 2 needs the reference dof positions: MotionLib reference source")
         self._local_root_obs = bool(env.get("local_root_obs", True))
         self._root_height_obs = bool(env.get("root_height_obs", True))
         self._full_body_reward = bool(env.get("full_body_reward", True))        # humanoid_im.py:37
@@ -82,9 +90,13 @@ class HumanoidIm:
         self._pd_action_scale = torch.ones(self._dof_size, device=self.device)
         self.clip_obs = float("inf")                                            # parse_task.py:68
         # ---- sizes (humanoid.py:653, humanoid_im.py:457-491)
-        self._self_obs_size = 1 + 15 * self.num_bodies - 3 if self._root_height_obs else 15 * self.num_bodies - 3
+        lib = ops._lib.load()
+        self._force_sensor_width = 6 * len(self.force_sensor_joints) if self.self_obs_v == 3 else 0     # humanoid.py:666-667
+        self._hist_steps = self.past_track_steps + 1 if self.self_obs_v == 2 else 1                     # humanoid.py:502-503
+        self._self_obs_size = lib.pulse_self_obs_width_ex(self.num_bodies, int(self._root_height_obs), self.self_obs_v, self._hist_steps,
+                                                          self._force_sensor_width)
         jt = self._track_bodies_id.numel()
-        self._task_obs_size = (24 if self.obs_v == 6 else 9) * jt * self._num_traj_samples
+        self._task_obs_size = lib.pulse_task_obs_width(self.obs_v, jt, self._num_traj_samples)
         self.num_obs = self._self_obs_size + self._task_obs_size
         self.num_actions = self._dof_size
         self.obs_pitch = (self.num_obs + 31) // 32 * 32
@@ -101,6 +113,13 @@ class HumanoidIm:
         self._motion_start_times = torch.zeros(n, device=dev)
         self._motion_start_times_offset = torch.zeros(n, device=dev)
         self._pass_time = torch.zeros(n, dtype=torch.bool, device=dev)
+        # self_obs_v 2: the last past_track_steps simulated states + the current one, oldest first (humanoid.py:224-228, 1301-1312)
+        self._rb_hist = torch.zeros(n, self._hist_steps, self.num_bodies, 13, device=dev) if self.self_obs_v == 2 else None
+        # self_obs_v 3: force-sensor readings (vec_sensor_tensor, humanoid.py:179-187) -- the physics stand-in has none: zeros unless
+        # the sim object provides ``force_sensor``
+        self._force_sensor = (getattr(sim, "force_sensor", None) if self.self_obs_v == 3 else None)
+        if self.self_obs_v == 3 and self._force_sensor is None:
+            self._force_sensor = torch.zeros(n, self._force_sensor_width, device=dev)
         self._motion_len_env = motion_lib._motion_lengths
         if self._use_motion_lib:
             self._init_motion_clock(env)
@@ -318,8 +337,18 @@ class HumanoidIm:
             clock = motion = None
             ref_now = self._ref_now() if need_now else None
             ref_next = (ref_next if ref_next is not None else self._ref_next()) if what & PULSE_IM_TASK_OBS else None
+        rb = self.sim.rigid_body_state
+        extra = {}
+        if self.self_obs_v == 2:
+            self._rb_hist[:, -1] = rb                      # slot H-1 = the current state; reward / reset / task obs read it there
+            rb = self._rb_hist
+        elif self.self_obs_v == 3:
+            extra["force_sensor"] = self._force_sensor
+        if self.obs_v == 2:
+            extra["dof_pos"] = self.sim.dof_pos
         return ops.im_step(
-            self.sim.rigid_body_state, what=what, ref_now=ref_now, ref_next=ref_next,
+            rb, what=what, ref_now=ref_now, ref_next=ref_next, upright=self._has_upright_start,
+            enable_early_termination=self._enable_early_termination, self_obs_version=self.self_obs_v, **extra,
             time_steps=self._num_traj_samples, dof_force=self.sim.dof_force, dof_vel=self.sim.dof_vel,
             progress=self.progress_buf, pass_time=self._pass_time, cycle_counter=self._cycle_counter,
             track_ids=self._track_bodies_id, reset_ids=self._reset_bodies_id, term_dist=self._termination_distances,
@@ -359,7 +388,20 @@ class HumanoidIm:
     def _compute_observations(self, env_ids=None, env_mask=None, ref_next=None):
         self._im_step(PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, env_ids=env_ids, env_mask=env_mask, ref_next=ref_next)
 
+    def _update_tensor_history(self):
+        """humanoid.py:1308-1312, called before the tensors are refreshed (:1320-1321): the state the LAST observation was computed
+        from (slot H-1) moves into the history, the oldest step drops out."""
+        h = self._rb_hist
+        h[:, :-1] = h[:, 1:].clone()
+
+    def _init_tensor_history(self, mask):
+        """humanoid.py:1301-1306 for the masked envs: the history is the reset state repeated."""
+        cur = self.sim.rigid_body_state.unsqueeze(1).expand(-1, self._hist_steps, -1, -1)
+        torch.where(mask[:, None, None, None], cur, self._rb_hist, out=self._rb_hist)
+
     def post_physics_step(self):
+        if self.self_obs_v == 2:
+            self._update_tensor_history()
         # progress += 1, pass_time, reward -> reset -> observations (humanoid.py:1316-1328): one launch.  With the motion library
         # the increment, the time-out test and the reference blend (t and t+1) all happen inside it.
         if self._use_motion_lib and self.cycle_motion:
@@ -414,6 +456,8 @@ class HumanoidIm:
                                           "start_times": self._motion_start_times, "progress": self.progress_buf,
                                           "clear0": self.reset_buf, "clear1": self._terminate_buf, "clear2": self._cycle_counter,
                                           "zero_start_offsets": self._motion_start_times_offset, "zero_global_offset": self._global_offset})
+            if self.self_obs_v == 2:
+                self._init_tensor_history(mask)
             self._compute_observations(env_mask=mask)
             if self._enable_amp_obs:
                 self._init_amp_obs(mask)
@@ -424,6 +468,8 @@ class HumanoidIm:
         ref_next = self._motion_lib.next_after_reset()
         self.reset_buf.mul_(keep)
         self._terminate_buf.mul_(keep)
+        if self.self_obs_v == 2:
+            self._init_tensor_history(mask)
         self._compute_observations(env_mask=mask, ref_next=ref_next)
         if self._enable_amp_obs:
             self._init_amp_obs(mask)
@@ -467,6 +513,7 @@ class VecTaskPythonWrapper:
         info = {"action_space": self.act_space, "observation_space": self.obs_space, "task_obs_size": self.task.get_task_obs_size()}
         if getattr(self.task, "_enable_amp_obs", False):
             info["amp_observation_space"] = self.task._amp_obs_space
+            info["enc_amp_observation_space"] = self.task._amp_obs_space      # RLGPUEnv.get_env_info, run_hydra.py:236-239
         return info
 
     def fetch_amp_obs_demo(self, num_samples):

@@ -160,6 +160,13 @@ class CommonAgent:
             return AMPZModel(params, actions_num=net_config["actions_num"], self_obs_size=task.get_self_obs_size(),
                              task_obs_size=task.get_task_obs_size(), task_obs_size_detail=task.get_task_obs_size_detail(),
                              device=self.ppo_device, split_k=int(self.config.get("split_k", 8)), generator=self.noise_generator)
+        if params.get("name", "amp") == "amp_z_reader":
+            # AMPZReaderBuilder.Network (amp_network_z_reader_builder.py:21-57) IS AMPBuilder.Network -- the plain actor / critic MLP
+            # whose 32-d "action" is the latent a frozen PULSE decoder turns into joint targets inside env.step -- unless
+            # vae_prior_policy swaps sigma for the decoder's prior log-variance (:46-55; no shipped config sets it)
+            detail = self.vec_env.env.task.get_task_obs_size_detail() if hasattr(self.vec_env.env.task, "get_task_obs_size_detail") else {}
+            if detail.get("vae_prior_policy", False):
+                raise NotImplementedError("amp_z_reader with vae_prior_policy (sigma from the frozen prior)")
         return A2CNetwork(params, actions_num=net_config["actions_num"], input_shape=net_config["input_shape"],
                           value_size=net_config["value_size"], device=self.ppo_device, split_k=int(self.config.get("split_k", 8)))
 

@@ -362,6 +362,30 @@ int pulse_kinematic_sim_step(const float* target_rb, const float* noise_rb, floa
                              const float* target_dof_vel, const float* noise_dof_vel, float* dof_vel,
                              const float* force_src, float* dof_force, int32_t num_dof, pulse_stream_t s);
 
+/* Physics STAND-IN whose state DEPENDS ON THE ACTION (return-parity experiments; Isaac Gym is out of scope): every joint j carries a
+ * 3-d error state e_j (simulated minus reference exp-map dof) driven by PD control towards  sag_j + action_scale * action_j  with a
+ * recorded disturbance, integrated semi-implicitly over ``substeps`` per control step:
+ *     acc = kp (sag + action_scale a - e) - kd e' + noise;   e' += h acc;   e += h e'            (h = dt / substeps)
+ * Body b >= 1 (joint b - 1) is the tracked reference body displaced by that error:
+ *     rot = exp_map_to_quat(e) * ref_rot,  pos = ref_pos + lever (e x u_b),  vel = ref_vel + lever (e' x u_b),  ang = ref_ang + e'
+ * the root follows the reference; dof_pos / dof_vel = reference + e / e'; dof_force = the PD torque.  reset_mask (optional, bytes):
+ * masked envs restart with e = e' = 0.  One thread per (env, body).  The CPU twin is oracle/pd_sim_oracle.py. */
+typedef struct pulse_pd_sim_args {
+    int64_t num_envs; int32_t num_bodies;            /* J; num_dof = 3 (J - 1) */
+    const float* target_rb;                          /* (num_envs, J, 13) reference at the next control step */
+    const float* target_dof_pos; const float* target_dof_vel;   /* (num_envs, 3 (J-1)) */
+    const float* action;                             /* (num_envs, 3 (J-1)) pd targets (clamped actions) */
+    const float* noise_acc;                          /* (num_envs, 3 (J-1)) recorded disturbance */
+    const float* sag;                                /* (3 (J-1)) */
+    const float* lever_dir;                          /* (J, 3) unit vectors u_b */
+    float kp, kd, dt, action_scale, lever; int32_t substeps;
+    float* err; float* err_vel;                      /* (num_envs, 3 (J-1)) state, updated in place */
+    float* rb; float* dof_pos; float* dof_vel; float* dof_force;   /* outputs */
+    const uint8_t* reset_mask;
+} pulse_pd_sim_args;
+int pulse_sizeof_pd_sim_args(void);
+int pulse_pd_sim_step(const pulse_pd_sim_args* args, pulse_stream_t s);
+
 /* ------------------------------------------------------------------------- *
  * 3. GAE: CommonAgent.discount_values + returns, phc/learning/common_agent.py:493-505,
  *    :346-347.  Element (t, n) of every array lives at t*stride_t + n*stride_n.

@@ -236,7 +236,7 @@ class OracleCommonAgent:
         for n in range(self.horizon_length):
             self.obs = self.env.reset(done_indices)
             td["obses"][n, :] = self.obs
-            noise = self.noise[self.epoch, n] if self.noise is not None else None
+            noise = (self.noise(self.epoch, n) if callable(self.noise) else self.noise[self.epoch, n]) if self.noise is not None else None
             res = self.get_action_values(self.obs, noise)
             for k in self.update_list:
                 td[k][n, :] = res[k]

@@ -110,6 +110,14 @@ class RolloutRecordArgs(Structure):
                 ("meter_max_size", c_float), ("done_mask", c_void_p), ("buf_terminate", c_void_p)]
 
 
+class PdSimArgs(Structure):
+    _fields_ = [("num_envs", c_int64), ("num_bodies", c_int32), ("target_rb", c_void_p), ("target_dof_pos", c_void_p), ("target_dof_vel", c_void_p),
+                ("action", c_void_p), ("noise_acc", c_void_p), ("sag", c_void_p), ("lever_dir", c_void_p),
+                ("kp", c_float), ("kd", c_float), ("dt", c_float), ("action_scale", c_float), ("lever", c_float), ("substeps", c_int32),
+                ("err", c_void_p), ("err_vel", c_void_p), ("rb", c_void_p), ("dof_pos", c_void_p), ("dof_vel", c_void_p), ("dof_force", c_void_p),
+                ("reset_mask", c_void_p)]
+
+
 class GemmDesc(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p), ("aux", c_void_p),
@@ -172,6 +180,8 @@ SIGNATURES = {
     "pulse_sizeof_rollout_record_args": (c_int, []),
     "pulse_rollout_record": (c_int, [POINTER(RolloutRecordArgs), P]),
     "pulse_kinematic_sim_step": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, P, P, P, P, c_int32, P]),
+    "pulse_sizeof_pd_sim_args": (c_int, []),
+    "pulse_pd_sim_step": (c_int, [POINTER(PdSimArgs), P]),
     "pulse_sizeof_motion_state_args": (c_int, []),
     "pulse_motion_state": (c_int, [POINTER(MotionStateArgs), P]),
     "pulse_gae": (c_int, [P, P, P, P, c_int32, c_int32, c_int64, c_int64, c_float, c_float, P, P, P]),

@@ -127,10 +127,11 @@ def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kin
     if reference == "motion_lib":
         from . import synthetic as syn
         from .env.motion_lib import MotionLib
-        from .env.sim import KinematicSim
+        from .env.sim import KinematicSim, PdSim
         tables = syn.synthetic_motion_library(syn.make_generator(seed + 5, rank), min(num_envs, 1024))
         motion = MotionLib.from_tables(tables, device)
-        sim = KinematicSim(num_envs, horizon + 1, device, seed=seed, rank=rank)
+        sim_cls = PdSim if env_cfg.pop("physics", "tracking") == "pd" else KinematicSim        # "pd": action-dependent stand-in
+        sim = sim_cls(num_envs, horizon + 1, device, seed=seed, rank=rank)
         task = HumanoidIm({"env": env_cfg}, sim, motion, device=device)
         return VecTaskPythonWrapper(task, rl_device=device), None
     from .env.sim import RecordedMotion, RecordedRollout, RecordedSim

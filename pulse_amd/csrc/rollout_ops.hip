@@ -9,6 +9,7 @@
 // HBM traffic is ~40 B per env: launch-latency bound by construction, which is the point.
 // Compiled with -ffp-contract=off.
 #include "common.h"
+#include "rot_math.h"
 
 namespace pulse {
 
@@ -95,9 +96,81 @@ __global__ void __launch_bounds__(256) kinematic_sim_kernel(const float* __restr
     }
 }
 
+// action-dependent physics stand-in (see include/pulse_hip.h: pulse_pd_sim_args); one thread per (env, body)
+__global__ void __launch_bounds__(256) pd_sim_kernel(const pulse_pd_sim_args a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int J = a.num_bodies, nd = 3 * (J - 1);
+    if (i >= a.num_envs * J) return;
+    const long long e = i / J;
+    const int b = (int)(i - e * J);
+    const float* t = a.target_rb + i * 13;
+    float* o = a.rb + i * 13;
+    if (b == 0) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) o[k] = t[k];
+        return;
+    }
+    const long long d0 = e * nd + 3 * (b - 1);
+    const bool rst = a.reset_mask && a.reset_mask[e];
+    float er[3], ev[3], tq[3];
+    const float h = a.dt / (float)a.substeps;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        er[k] = rst ? 0.0f : a.err[d0 + k];
+        ev[k] = rst ? 0.0f : a.err_vel[d0 + k];
+        tq[k] = 0.0f;
+    }
+    if (!rst) {
+        for (int s = 0; s < a.substeps; ++s) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float te = a.sag[3 * (b - 1) + k] + a.action_scale * a.action[d0 + k];
+                const float acc = a.kp * (te - er[k]) - a.kd * ev[k] + a.noise_acc[d0 + k];
+                ev[k] = ev[k] + h * acc;
+                er[k] = er[k] + h * ev[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float te = a.sag[3 * (b - 1) + k] + a.action_scale * a.action[d0 + k];
+            tq[k] = a.kp * (te - er[k]) - a.kd * ev[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.err[d0 + k] = er[k];
+        a.err_vel[d0 + k] = ev[k];
+        a.dof_pos[d0 + k] = a.target_dof_pos[d0 + k] + er[k];
+        a.dof_vel[d0 + k] = a.target_dof_vel[d0 + k] + ev[k];
+        a.dof_force[d0 + k] = tq[k];
+    }
+    const float* u = a.lever_dir + 3 * b;
+    const V3 ce{er[1] * u[2] - er[2] * u[1], er[2] * u[0] - er[0] * u[2], er[0] * u[1] - er[1] * u[0]};
+    const V3 cv{ev[1] * u[2] - ev[2] * u[1], ev[2] * u[0] - ev[0] * u[2], ev[0] * u[1] - ev[1] * u[0]};
+    const Q4 q = qmul(exp_map_to_q(V3{er[0], er[1], er[2]}), Q4{t[3], t[4], t[5], t[6]});
+    o[0] = t[0] + a.lever * ce.x; o[1] = t[1] + a.lever * ce.y; o[2] = t[2] + a.lever * ce.z;
+    o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+    o[7] = t[7] + a.lever * cv.x; o[8] = t[8] + a.lever * cv.y; o[9] = t[9] + a.lever * cv.z;
+    o[10] = t[10] + ev[0]; o[11] = t[11] + ev[1]; o[12] = t[12] + ev[2];
+}
+
 }  // namespace pulse
 
 using namespace pulse;
+
+extern "C" int pulse_sizeof_pd_sim_args(void) { return (int)sizeof(pulse_pd_sim_args); }
+
+extern "C" int pulse_pd_sim_step(const pulse_pd_sim_args* args, pulse_stream_t s) {
+    PULSE_REQUIRE(args != nullptr, "pulse_pd_sim_step: null args");
+    const pulse_pd_sim_args& a = *args;
+    PULSE_REQUIRE(a.num_envs >= 0 && a.num_bodies >= 2 && a.substeps >= 1 && a.dt > 0.f, "pulse_pd_sim_step: bad sizes");
+    if (a.num_envs == 0) return PULSE_OK;
+    PULSE_REQUIRE(a.target_rb && a.target_dof_pos && a.target_dof_vel && a.action && a.noise_acc && a.sag && a.lever_dir && a.err && a.err_vel &&
+                      a.rb && a.dof_pos && a.dof_vel && a.dof_force, "pulse_pd_sim_step: null pointer");
+    const long long n = a.num_envs * a.num_bodies;
+    hipLaunchKernelGGL(pd_sim_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), a);
+    return check_launch("pulse_pd_sim_step");
+}
 
 extern "C" int pulse_sizeof_rollout_record_args(void) { return (int)sizeof(pulse_rollout_record_args); }
 

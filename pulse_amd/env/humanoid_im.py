@@ -456,6 +456,8 @@ class HumanoidIm:
                                           "start_times": self._motion_start_times, "progress": self.progress_buf,
                                           "clear0": self.reset_buf, "clear1": self._terminate_buf, "clear2": self._cycle_counter,
                                           "zero_start_offsets": self._motion_start_times_offset, "zero_global_offset": self._global_offset})
+            if hasattr(sim, "on_reset"):
+                sim.on_reset(mask)
             if self.self_obs_v == 2:
                 self._init_tensor_history(mask)
             self._compute_observations(env_mask=mask)

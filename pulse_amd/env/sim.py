@@ -202,3 +202,48 @@ class KinematicSim:
         torch.where(mask[:, None, None], state["rb_records"], self.rigid_body_state, out=self.rigid_body_state)
         torch.where(mask[:, None], state["dof_pos"], self.dof_pos, out=self.dof_pos)
         torch.where(mask[:, None], state["dof_vel"], self.dof_vel, out=self.dof_vel)
+
+
+class PdSim(KinematicSim):
+    """Physics stand-in whose state DEPENDS ON THE ACTION (pulse_pd_sim_step): per-joint error states under PD control towards
+    ``sag + action_scale * action`` with a recorded disturbance; bodies are the tracked reference displaced by those errors.  Used
+    by the return-parity experiment (tools/return_parity.py) -- the bench keeps KinematicSim.  The CPU twin is
+    oracle/pd_sim_oracle.py; both draw the disturbance bank with the same generator recipe."""
+
+    def __init__(self, num_envs, bank_frames, device, seed=1234, rank=0):
+        super().__init__(num_envs, bank_frames, device, seed=seed, rank=rank)
+        g = syn.make_generator(seed + 23, rank)
+        self.bank["acc"] = (syn.PD_SIM["noise_acc"] * torch.randn(bank_frames, num_envs, syn.NUM_DOF, generator=g)).to(device)
+        sag, u = syn.pd_sim_tables()
+        self._sag, self._lever_dir = sag.to(device), u.to(device).contiguous()
+        self.err = torch.zeros(num_envs, syn.NUM_DOF, device=device)
+        self.err_vel = torch.zeros(num_envs, syn.NUM_DOF, device=device)
+        self.dt = 2.0 / 60.0
+        self._reset_mask = torch.zeros(num_envs, dtype=torch.uint8, device=device)
+
+    def simulate_and_refresh(self):
+        from .. import _lib
+        self.frame = (self.frame + 1) % self.bank_frames
+        t, c = self._target, syn.PD_SIM
+        a = _lib.PdSimArgs()
+        a.num_envs, a.num_bodies = self.num_envs, syn.NUM_BODIES
+        a.target_rb, a.target_dof_pos, a.target_dof_vel = t["rb_records"].data_ptr(), t["dof_pos"].data_ptr(), t["dof_vel"].data_ptr()
+        act = self.pd_targets.contiguous()
+        a.action, a.noise_acc = act.data_ptr(), self.bank["acc"][self.frame].data_ptr()
+        a.sag, a.lever_dir = self._sag.data_ptr(), self._lever_dir.data_ptr()
+        a.kp, a.kd, a.dt, a.action_scale, a.lever, a.substeps = c["kp"], c["kd"], self.dt, c["action_scale"], c["lever"], c["substeps"]
+        a.err, a.err_vel = self.err.data_ptr(), self.err_vel.data_ptr()
+        a.rb, a.dof_pos, a.dof_vel, a.dof_force = (self.rigid_body_state.data_ptr(), self.dof_pos.data_ptr(), self.dof_vel.data_ptr(),
+                                                   self.dof_force.data_ptr())
+        import ctypes
+        _lib.check(_lib.load().pulse_pd_sim_step(ctypes.byref(a), torch.cuda.current_stream().cuda_stream), "pulse_pd_sim_step")
+
+    def on_reset(self, mask):
+        """Reference-state init of the masked envs (HumanoidIm.reset_masked wrote their state): the error states restart at zero."""
+        keep = (~mask).to(self.err.dtype)[:, None]
+        self.err.mul_(keep)
+        self.err_vel.mul_(keep)
+
+    def set_env_states_masked(self, mask, state):
+        super().set_env_states_masked(mask, state)
+        self.on_reset(mask)

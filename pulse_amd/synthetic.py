@@ -213,3 +213,20 @@ def synthetic_motion_library(g, num_motions, min_frames=45, max_frames=180, fps=
         "motion_num_frames": num_frames, "motion_fps": torch.full((m,), fps), "motion_dt": torch.full((m,), dt),
         "motion_lengths": ((1.0 / fps) * (num_frames - 1).double()).float(), "length_starts": starts,   # curr_len, motion_lib_base.py:263
     }
+
+
+# --------------------------------------------------------------------------- #
+# Action-dependent physics stand-in (return-parity experiments): constants shared by the HIP kernel's host class
+# (pulse_amd/env/sim.py:PdSim) and its CPU twin (oracle/pd_sim_oracle.py).  See include/pulse_hip.h: pulse_pd_sim_args.
+# --------------------------------------------------------------------------- #
+PD_SIM = {"kp": 400.0, "kd": 40.0, "substeps": 2, "action_scale": 0.25, "lever": 0.3, "noise_acc": 2.0}
+
+
+def pd_sim_tables():
+    """(sag (69,), lever_dir (24, 3)): a constant per-joint offset of the PD set point the policy has to learn to cancel, and the unit
+    'bone' directions that turn a joint-angle error into a body displacement.  Deterministic (no RNG state involved)."""
+    j = torch.arange(NUM_DOF, dtype=torch.float32)
+    sag = 0.25 * torch.sin(0.7 * (j + 1.0))
+    b = torch.arange(NUM_BODIES, dtype=torch.float32)
+    u = torch.stack([torch.cos(1.3 * b), torch.sin(1.3 * b) * torch.cos(0.9 * b + 0.4), torch.sin(1.3 * b) * torch.sin(0.9 * b + 0.4)], dim=-1)
+    return sag, u / u.norm(dim=-1, keepdim=True)

@@ -1,0 +1,122 @@
+"""Return-parity experiment (BASELINE.json north_star: "episode return within 1% of reference after 1000 PPO iterations").
+
+    python tools/return_parity.py --iters 1000 --out profiles/r02_return_parity.json
+
+Trains the HIP CommonAgent and the PyTorch-CPU oracle agent (oracle/agent_oracle.py) side by side at cfg1 scale (64 envs x horizon
+16, [512, 512] actor / critic) on the action-dependent physics stand-in (pulse_pd_sim_step on the device, oracle/pd_sim_oracle.py on
+the host): same motion library, same disturbance bank, same initial weights, same policy-sampling noise, same minibatch
+permutations, episodes starting at motion time 0.  The two runs agree to fp32 round-off at first and then drift apart like any
+two fp32 runs of a chaotic training loop; what is compared is the mean episode return over a window of epochs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+class EpisodeMeter:
+    """Episode returns from the (T, N) reward / done tensors of consecutive rollouts (what game_rewards averages)."""
+
+    def __init__(self, n):
+        self.acc = torch.zeros(n, dtype=torch.float64)
+        self.length = torch.zeros(n)
+        self.finished = []            # (epoch, return, length)
+
+    def feed(self, epoch, rewards, dones):
+        r, d = rewards.reshape(rewards.shape[0], -1).double().cpu(), dones.reshape(dones.shape[0], -1).cpu().bool()
+        for t in range(r.shape[0]):
+            self.acc += r[t]
+            self.length += 1
+            for e in torch.nonzero(d[t]).flatten().tolist():
+                self.finished.append((epoch, float(self.acc[e]), float(self.length[e])))
+                self.acc[e] = 0
+                self.length[e] = 0
+
+    def mean_return(self, lo, hi):
+        v = [r for e, r, _ in self.finished if lo <= e < hi]
+        return (sum(v) / len(v), len(v)) if v else (float("nan"), 0)
+
+    def mean_step_reward(self, lo, hi):
+        v = [(r, l) for e, r, l in self.finished if lo <= e < hi]
+        return sum(r for r, _ in v) / max(1.0, sum(l for _, l in v))
+
+
+def run(iters, seed=7, device="cuda:0", window=None, log=print):
+    from oracle import agent_oracle as AO
+    from oracle import motion_oracle as MO
+    from pulse_amd import configs
+    window = window or max(1, iters // 5)
+    cfg, num_envs = configs.agent_config("cfg1")
+    T = cfg["horizon_length"]
+    env_over = {"physics": "pd", "stateInit": "Start"}
+    agent, _ = configs.make_agent("cfg1", device=device, seed=seed, reference="motion_lib", env_overrides=env_over, permutation_device="cpu")
+    torch.manual_seed(seed)
+    oenv = MO.make_agent_env(num_envs, T, seed, physics="pd", state_init_start=True)
+
+    def noise(epoch, step=None):
+        g = torch.Generator().manual_seed(seed * 100003 + epoch)
+        z = torch.randn(T, num_envs, 69, generator=g)
+        return z if step is None else z[step]
+    cache = {}
+
+    def noise_cached(epoch, step):
+        if cache.get("e") != epoch:
+            cache["e"], cache["z"] = epoch, noise(epoch)
+            cache["zd"] = cache["z"].to(device)
+        return cache["z"][step]
+    oracle = AO.OracleCommonAgent(cfg, oenv, cfg["network"]["mlp"]["units"], seed=seed, noise=noise_cached)
+    agent.model.load_state_dict(oracle.model.state_dict_ref())
+    agent.noise_provider = lambda e, s: (noise_cached(e, s), cache["zd"][s])[1]
+    m_dev, m_ref = EpisodeMeter(num_envs), EpisodeMeter(num_envs)
+    t_dev = t_ref = 0.0
+    first_diff = None
+    for it in range(iters):
+        t0 = time.time()
+        agent.train_epoch()
+        torch.cuda.synchronize()
+        t1 = time.time()
+        oracle.train_epoch()
+        t2 = time.time()
+        t_dev, t_ref = t_dev + (t1 - t0), t_ref + (t2 - t1)
+        td, rd = agent.experience_buffer.tensor_dict, oracle.tensor_dict
+        m_dev.feed(it, td["rewards"], td["dones"])
+        m_ref.feed(it, rd["rewards"], rd["dones"])
+        if first_diff is None and not torch.equal(td["dones"].cpu(), rd["dones"]):
+            first_diff = it
+        if it % max(1, iters // 20) == 0 or it == iters - 1:
+            a, na = m_dev.mean_return(max(0, it - window), it + 1)
+            b, nb = m_ref.mean_return(max(0, it - window), it + 1)
+            log(f"[return_parity] iter {it}: device {a:.4f} ({na} eps)  oracle {b:.4f} ({nb} eps)  reward diff this epoch "
+                f"{float((td['rewards'].cpu() - rd['rewards']).abs().max()):.2e}")
+    lo = iters - window
+    a, na = m_dev.mean_return(lo, iters)
+    b, nb = m_ref.mean_return(lo, iters)
+    a0, _ = m_dev.mean_return(0, window)
+    b0, _ = m_ref.mean_return(0, window)
+    sa, sb = m_dev.mean_step_reward(lo, iters), m_ref.mean_step_reward(lo, iters)
+    return {"iterations": iters, "config": "cfg1 (64 envs x horizon 16, [512, 512]) on the PD physics stand-in, motion-library reference",
+            "window_epochs": window, "device_mean_episode_return": a, "oracle_mean_episode_return": b, "episodes_in_window": [na, nb],
+            "relative_difference": abs(a - b) / abs(b), "device_mean_step_reward": sa, "oracle_mean_step_reward": sb,
+            "relative_difference_step_reward": abs(sa - sb) / abs(sb),
+            "first_window": {"device": a0, "oracle": b0}, "first_epoch_with_different_dones": first_diff,
+            "seconds": {"device": t_dev, "oracle_cpu": t_ref}, "seed": seed}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    res = run(a.iters, seed=a.seed)
+    print(json.dumps(res, indent=1))
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)

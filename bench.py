@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 
 
 def log(msg):
@@ -50,18 +51,22 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket GEMM launches with events")
     ap.add_argument("--keep-gc", action="store_true", help="leave Python's cyclic garbage collector running during the timed region")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns the config's env count; strong: the config's env count is divided over the ranks")
     return ap.parse_args()
 
 
 def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches, reference="motion_lib"):
-    """Runs in a SUBPROCESS (hard wall-clock bound): the oracle agent on the host cores for a bounded
-    sample -- ``sample_steps`` of the T rollout steps and ``n_minibatches`` PPO minibatch steps at the
-    full N and the full minibatch size -- extrapolated linearly to the whole epoch."""
+    """Runs in a SUBPROCESS (hard wall-clock bound): the oracle agent on the host cores for a bounded sample -- ``sample_steps`` of
+    the T rollout steps and ``n_minibatches`` (>= 3) PPO minibatch steps at the full N and the full minibatch size.  BASELINE.md
+    protocol: the intra-op thread count is swept once on a minibatch step (oversubscribing a 256-thread host costs 3x), the best
+    count is used, the rollout step time is the mean of the sampled steps and the minibatch time the MEDIAN of the repetitions
+    after one warm-up; both are extrapolated linearly to the epoch."""
+    import statistics
     import torch
     from oracle import agent_oracle as AO
     from pulse_amd import configs, synthetic as syn
     from pulse_amd.env.sim import RecordedRollout
-    cores = torch.get_num_threads()                         # PyTorch's own default intra-op pool: what the reference would use
     cfg, num_envs = configs.agent_config(cfg_name)
     T = cfg["horizon_length"]
     total_mb = cfg["mini_epochs"] * (T * num_envs // cfg["minibatch_size"])
@@ -77,18 +82,46 @@ def cpu_baseline_worker(cfg_name, seed, sample_steps, n_minibatches, reference="
         env = AO.OracleEnv(rollout, syn.RESET_BODY_IDS, list(range(24)))
     agent = AO.OracleCommonAgent(scfg, env, cfg["network"]["mlp"]["units"], seed=seed)
     agent.obs = env.reset()
+    t_all = time.time()
+    # ---- thread sweep on one minibatch step of synthetic rows (shape of the real thing)
+    logical = os.cpu_count() or 1
+    mb = cfg["minibatch_size"]
+    probe = {"obs": torch.randn(mb, 934), "actions": torch.randn(mb, 69) * 0.1, "old_logp_actions": torch.randn(mb), "advantages": torch.randn(mb),
+             "old_values": torch.randn(mb, 1), "returns": torch.randn(mb, 1), "mu": torch.randn(mb, 69) * 0.1, "sigma": torch.full((mb, 69), 0.055)}
+    sweep = {}
+    for th in [t for t in (8, 16, 32, 64, 128, 256) if t <= logical] or [logical]:
+        torch.set_num_threads(th)
+        agent.calc_gradients(probe)                               # warm-up (thread pool, allocator); timing only, the weights do not matter
+        t0 = time.time()
+        agent.calc_gradients(probe)
+        sweep[th] = time.time() - t0
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    # ---- rollout sample
     t0 = time.time()
-    r = agent.train_epoch(max_minibatches=n_minibatches)
-    wall = time.time() - t0
-    per_step = r["play_time"] / sample_steps
-    per_mb = r["update_time"] / max(1, r["minibatches"])
+    with torch.no_grad():
+        batch = agent.play_steps()
+    play = time.time() - t0
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    nmb = sample_steps * num_envs // mb
+    agent.calc_gradients(agent._get_item(0))                      # warm-up
+    times = []
+    for i in range(max(3, n_minibatches)):
+        t0 = time.time()
+        agent.calc_gradients(agent._get_item(i % nmb))
+        times.append(time.time() - t0)
+    per_step = play / sample_steps
+    per_mb = statistics.median(times)
     epoch_s = per_step * T + per_mb * total_mb
+    wall = time.time() - t_all
     return {"value": T * num_envs / epoch_s, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cfg_name} ({reference} reference) at full width ({num_envs} envs, minibatch {cfg['minibatch_size']}): {sample_steps} of {T} rollout steps "
-                      f"({r['play_time']:.1f} s) + {r['minibatches']} of {total_mb} PPO minibatch steps ({r['update_time']:.1f} s), each extrapolated "
-                      f"linearly to the epoch; {wall:.1f} s of CPU work; oracle/agent_oracle.py, torch {torch.__version__} eager fp32, "
-                      f"{cores} intra-op threads of {os.cpu_count()} logical CPUs",
-            "rollout_s_per_step": per_step, "update_s_per_minibatch": per_mb, "epoch_s_extrapolated": epoch_s}
+            "sample": f"{cfg_name} ({reference} reference) at full width ({num_envs} envs, minibatch {mb}): {sample_steps} of {T} rollout steps "
+                      f"({play:.1f} s) + median of {len(times)} PPO minibatch steps after one warm-up ({per_mb:.2f} s each; {total_mb} per epoch), "
+                      f"extrapolated linearly to the epoch; intra-op threads swept {sweep} -> {cores} of {logical} logical CPUs; "
+                      f"{wall:.1f} s of CPU work; oracle/agent_oracle.py, torch {torch.__version__} eager fp32",
+            "rollout_s_per_step": per_step, "update_s_per_minibatch": per_mb, "epoch_s_extrapolated": epoch_s,
+            "thread_sweep_s_per_minibatch": {str(k): v for k, v in sweep.items()}}
 
 
 def gemm_traffic(cfg_name):
@@ -96,12 +129,18 @@ def gemm_traffic(cfg_name):
     WRITE_SIZE, separate passes, mean over the GEMM launches of one epoch of this config); None if not collected.  The
     counters serialise kernels, so they cannot be read inside the timed region: the number is a property of the same
     command profiled once per round."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_gemm_traffic_{cfg_name}.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["gemm_f32_kernel"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r*_gemm_traffic_{cfg_name}.json")))
+    for path in reversed(paths):              # newest round first
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for key in ("gemm_bf16_kernel", "gemm_f32_kernel") if cfg_name == "cfg5" else ("gemm_f32_kernel",):
+                if key in d:
+                    return d[key]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(cfg_name, seed, sample_steps, n_minibatches, budget_s, reference="motion_lib"):
@@ -147,10 +186,15 @@ def main():
     seed = 1234
     cfg, num_envs = configs.agent_config(a.config)
     T = cfg["horizon_length"]
+    over = {}
+    if a.scaling == "strong" and world > 1:
+        assert num_envs % world == 0
+        num_envs //= world                                        # the SAME total work split over the ranks
+        over = {"num_envs_override": num_envs, "minibatch_size": max(cfg["minibatch_size"] // world, num_envs)}
     # synthetic inputs, seed 1234 + rank: a motion library resident in HBM (+ tracking physics stand-in) or recorded frames
     rollout_cpu = RecordedRollout(num_envs, T + 1, seed=seed, rank=rank) if a.reference == "recorded" else None
     agent, _ = configs.make_agent(a.config, device=device, seed=seed, rank=rank, rollout=rollout_cpu, reference=a.reference,
-                                  multi_gpu=world > 1, dist=dist)
+                                  multi_gpu=world > 1, dist=dist, **over)
     log(f"rank {rank}: synthetic inputs generated ({a.reference})")
     agent.init_tensors()
     agent.obs = agent.env_reset()
@@ -193,8 +237,8 @@ def main():
     env_steps = a.steps * T * num_envs * world
     out = {
         "metric": "env-steps/sec through PPO update", "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
+        "vs_baseline": None, "dtype": "bf16" if cfg.get("mixed_precision") else "f32", "data": "synthetic",
         "config": {"workload": f"{a.config}: {num_envs} SMPL-humanoid envs/GPU x horizon {T}, imitation obs/reward/reset + PPO "
                                f"(actor+critic MLP {cfg['network']['mlp']['units']}, minibatch {cfg['minibatch_size']} x {cfg['mini_epochs']} mini-epochs)",
                    "num_envs_per_gpu": num_envs, "horizon": T, "global_batch": T * num_envs * world, "parallelism": f"dp{world}",
@@ -202,16 +246,35 @@ def main():
                    else "pre-recorded reference frames"},
         "play_ms_per_step": 1e3 * play / a.steps, "update_ms_per_step": 1e3 * upd / a.steps, "per_step_play_update_ms": per_step,
     }
+    if world > 1:
+        st = dist.stats()
+        out["allreduce"] = {"backend": st["backend"], "ranks": world, "calls_per_step": st["calls"] / max(1, a.steps + a.warmup),
+                            "mbytes_per_call": st["bytes"] / max(1, st["calls"]) / 1e6,
+                            "ms_per_step_host_enqueue": 1e3 * st["seconds"] / max(1, a.steps + a.warmup)}
     if not a.no_roofline:
         s = prof.summary()
-        n = sum(v[0] for v in s.values())
-        t = sum(v[1] for v in s.values())
-        f = sum(v[2] for v in s.values())
-        out["roofline"] = {"bound": "mfma", "achieved": f / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": f / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": gemm_traffic(a.config), "kernel": "gemm_f32_kernel",
-                           "launches": n, "avg_us": 1e6 * t / max(1, n), "kernel_time_frac_of_step": t / (elapsed / a.steps),
-                           "instrumented_steps": 1,
-                           "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in s.items()}}
+
+        def roof(tags, peak, kernel):
+            sel = {k: v for k, v in s.items() if k in tags}
+            n = sum(v[0] for v in sel.values())
+            t = sum(v[1] for v in sel.values())
+            f = sum(v[2] for v in sel.values())
+            if n == 0 or t == 0:
+                return None
+            return {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": f / t / 1e12 / peak,
+                    "traffic": gemm_traffic(a.config), "kernel": kernel, "launches": n, "avg_us": 1e6 * t / max(1, n),
+                    "kernel_time_frac_of_step": t / (elapsed / a.steps), "instrumented_steps": 1,
+                    "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in sel.items()}}
+        r32 = roof(("fwd", "dx", "dw"), MFMA_F32_PEAK_TFLOPS, "gemm_f32_kernel")
+        r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")
+        if r16 is not None:
+            # mixed precision: the training GEMMs run on the bf16 MFMA (judged against its 2.5 PFLOP/s dense peak; with fp32 operand
+            # storage the kernel is bound by operand traffic); the rollout's fp32 inference GEMMs are reported beside it
+            out["roofline"] = r16
+            if r32 is not None:
+                out["roofline_fp32_gemm"] = r32
+        elif r32 is not None:
+            out["roofline"] = r32
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle (subprocess, bounded)")
         out["cpu_baseline"] = cpu_baseline(a.config, seed, a.cpu_steps, a.cpu_minibatches, a.cpu_budget, a.reference)

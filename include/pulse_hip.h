@@ -411,6 +411,9 @@ int pulse_gae(const float* rewards, const float* values, const float* next_value
 #define PULSE_EPI_RELU_GRAD 1 /* C = acc * (aux > 0)           (aux = forward activation)  */
 #define PULSE_EPI_SILU_GRAD 2 /* C = acc * silu'(aux)          (aux = forward pre-activation) */
 
+#define PULSE_GEMM_COMPUTE_F32  0
+#define PULSE_GEMM_COMPUTE_BF16 1
+
 typedef struct pulse_gemm_desc {
     const float* A; const float* B; float* C;
     float* C2;            /* optional second output (pre-activation), EPI_BIAS_ACT + SILU */
@@ -429,6 +432,10 @@ typedef struct pulse_gemm_desc {
        rowsum[z * stride_rowsum + s * split_stride + m] = sum over slab s of A(k, m) -- the BIAS gradient, taken from the
        A fragments the kernel already holds, so no separate column-sum pass over dY is needed. */
     float* rowsum; int64_t stride_rowsum;
+    /* PULSE_GEMM_COMPUTE_BF16: operands (fp32 in memory) are rounded to bf16 on the way into LDS and multiplied on
+       v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the arithmetic of a bf16 autocast Linear over fp32 master weights
+       (phc/learning/amp_agent.py:671); with round_output_bf16 the outputs are rounded to bf16-representable values as well. */
+    int32_t compute_type; int32_t round_output_bf16;
 } pulse_gemm_desc;
 
 int pulse_sizeof_gemm_desc(void);

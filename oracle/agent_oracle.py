@@ -182,6 +182,7 @@ class OracleCommonAgent:
         self.grad_norm, self.truncate_grads = config["grad_norm"], config["truncate_grads"]
         self.mini_epochs_num, self.minibatch_size = config["mini_epochs"], config["minibatch_size"]
         self.normalize_advantage = config["normalize_advantage"]
+        self.mixed_precision = bool(config.get("mixed_precision", False))        # bf16 autocast around model forward + losses (:426)
         self.batch_size = self.horizon_length * self.num_actors
         self.last_lr = float(config["learning_rate"])
         self.actions_num, obs_dim = 69, 934
@@ -282,6 +283,10 @@ class OracleCommonAgent:
     def calc_gradients(self, d):
         self.set_train()
         obs_batch = self.running_mean_std(d["obs"])
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=self.mixed_precision):
+            return self._calc_gradients_inner(d, obs_batch)
+
+    def _calc_gradients_inner(self, d, obs_batch):
         res = self.model({"is_train": True, "prev_actions": d["actions"], "obs": obs_batch})
         action_log_probs, values, mu, sigma = res["prev_neglogp"], res["values"], res["mus"], res["sigmas"]
         ratio = torch.exp(d["old_logp_actions"] - action_log_probs)
@@ -301,7 +306,8 @@ class OracleCommonAgent:
         loss = a_loss + self.critic_coef * c_loss - 0.0 * entropy + (self.bounds_loss_coef or 0.0) * b_loss
         for p in self.model.parameters():
             p.grad = None
-        loss.backward()
+        with torch.autocast("cpu", enabled=False):
+            loss.backward()
         gn = None
         if self.truncate_grads:
             gn = nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
@@ -575,6 +581,13 @@ def oracle_amp_calc_gradients(model, optimizer, rms, rms_temp, amp_rms, d, cfg):
     b = cfg["amp_minibatch_size"]
     amp_obs, amp_replay, amp_demo = amp_rms(d["amp_obs"][0:b]), amp_rms(d["amp_obs_replay"][0:b]), amp_rms(d["amp_obs_demo"][0:b])
     amp_demo.requires_grad_(True)
+    if cfg.get("autocast_bf16", False):           # amp_agent.py:671: autocast(enabled=self.mixed_precision) around forward + losses (bf16 here)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            return _amp_calc_gradients_tail(model, optimizer, d, cfg, obs_proc, amp_obs, amp_replay, amp_demo)
+    return _amp_calc_gradients_tail(model, optimizer, d, cfg, obs_proc, amp_obs, amp_replay, amp_demo)
+
+
+def _amp_calc_gradients_tail(model, optimizer, d, cfg, obs_proc, amp_obs, amp_replay, amp_demo):
     res = model({"is_train": True, "prev_actions": d["actions"], "obs": obs_proc, "amp_obs": amp_obs, "amp_obs_replay": amp_replay,
                  "amp_obs_demo": amp_demo})
     nlp, values, mu, sigma = res["prev_neglogp"], res["values"], res["mus"], res["sigmas"]
@@ -605,9 +618,10 @@ def oracle_amp_calc_gradients(model, optimizer, rms, rms_temp, amp_rms, d, cfg):
     loss = a_loss + cfg["critic_coef"] * c_loss - cfg["entropy_coef"] * entropy + cfg["bounds_loss_coef"] * b_loss + cfg["disc_coef"] * disc_loss
     for p in model.parameters():
         p.grad = None
-    loss.backward()
+    with torch.autocast("cpu", enabled=False):
+        loss.backward()
     with torch.no_grad():
-        kl = policy_kl(mu.detach(), sigma.detach(), d["mu"], d["sigma"], True)
+        kl = policy_kl(mu.detach().float(), sigma.detach().float(), d["mu"], d["sigma"], True)
     gn = nn.utils.clip_grad_norm_(model.parameters(), cfg["grad_norm"])
     optimizer.step()
     return {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(), "kl": kl,

@@ -43,7 +43,8 @@ class OracleAMPAgent:
         self.grad_cfg = {"e_clip": cfg["e_clip"], "critic_coef": cfg["critic_coef"], "entropy_coef": cfg.get("entropy_coef", 0.0),
                          "bounds_loss_coef": cfg["bounds_loss_coef"], "disc_coef": cfg["disc_coef"], "disc_logit_reg": cfg["disc_logit_reg"],
                          "disc_grad_penalty": cfg["disc_grad_penalty"], "disc_weight_decay": cfg["disc_weight_decay"],
-                         "grad_norm": cfg["grad_norm"], "amp_minibatch_size": cfg["amp_minibatch_size"], "clip_value": cfg["clip_value"]}
+                         "grad_norm": cfg["grad_norm"], "amp_minibatch_size": cfg["amp_minibatch_size"], "clip_value": cfg["clip_value"],
+                         "autocast_bf16": bool(cfg.get("mixed_precision", False))}
 
     def _mode(self, train):
         for m in (self.model, self.running_mean_std, self.value_mean_std, self.amp_mean_std):

@@ -128,6 +128,7 @@ class GemmDesc(Structure):
         ("stride_bias", c_int64), ("stride_aux", c_int64),
         ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
         ("rowsum", c_void_p), ("stride_rowsum", c_int64),
+        ("compute_type", c_int32), ("round_output_bf16", c_int32),
     ]
 
 
@@ -144,6 +145,7 @@ class PpoLossArgs(Structure):
 
 
 GEMM_RED_CONTIG, GEMM_OUT_CONTIG = 0, 1
+GEMM_COMPUTE_F32, GEMM_COMPUTE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD = 0, 1, 2
 

@@ -62,9 +62,11 @@ CONFIGS = {
              "extra": {"use_seq_rl": True}},
     # same network trained with the PPO loss (SURVEY.md 8d cfg 3, first variant)
     "cfg3_ppo": {"num_envs": 8192, "horizon_length": 32, "minibatch_size": 16384, "network": "amp_z", "env": "vae_ppo", "agent": "amp"},
-    # BASELINE.json configs[4]: AMP discriminator + PPO, 8192 envs (fp32 here: the reference's "mixed precision" is fp16 autocast)
+    # BASELINE.json configs[4]: AMP discriminator + PPO, 8192 envs, bf16: training GEMMs on the bf16 MFMA over fp32 master weights
     "cfg5": {"num_envs": 8192, "horizon_length": 32, "minibatch_size": 16384, "units": [1024, 512], "env": "amp", "agent": "amp",
-             "extra": {"enable_disc": True}},
+             "extra": {"enable_disc": True, "mixed_precision": True}},
+    "cfg5_f32": {"num_envs": 8192, "horizon_length": 32, "minibatch_size": 16384, "units": [1024, 512], "env": "amp", "agent": "amp",
+                 "extra": {"enable_disc": True}},
     "cfg5_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "units": [512, 512], "env": "amp", "agent": "amp",
                    "extra": {"enable_disc": True, "amp_minibatch_size": 64, "amp_obs_demo_buffer_size": 4096, "amp_replay_buffer_size": 4096,
                              "amp_batch_size": 128}},
@@ -148,7 +150,10 @@ def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kin
 def make_agent(name="cfg2", device="cuda:0", seed=1234, rank=0, rollout=None, reference="recorded", env_overrides=None, **overrides):
     from .learning.amp_agent import AMPAgent
     from .learning.common_agent import CommonAgent
+    num_envs_override = overrides.pop("num_envs_override", None)
     cfg, num_envs = agent_config(name, **overrides)
+    if num_envs_override is not None:
+        num_envs = int(num_envs_override)
     vec_env, rollout = make_env(num_envs, cfg["horizon_length"], device, seed=seed, rank=rank, rollout=rollout, env_kind=cfg["_env_kind"],
                                 reference=reference, env_overrides=env_overrides)
     cfg.update({"vec_env": vec_env, "device": device, "seed": seed})

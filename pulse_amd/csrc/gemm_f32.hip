@@ -63,6 +63,7 @@ struct GemmArgs {
     int vec_epi;                               // all epilogue pointers / pitches are 16-byte aligned
     float* rowsum; long long sRowsum;          // <MC,MC> only: per-slab sums over k of A(k, m)  (bias gradient)
     long long* dbg;                            // optional per-workgroup clock stamps (tools/gemm_bench --clocks)
+    int round_bf16;                            // outputs rounded to bf16-representable values (bf16 autocast semantics)
 };
 
 __device__ __forceinline__ int slot_of(int out) { return out ^ ((out >> 3) & 7); }
@@ -154,6 +155,154 @@ struct Stager {
         }
     }
 };
+
+// ---- epilogue (shared by the fp32 and the bf16 main loops) -----------------------------------------------------------
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// ``round_bf16``: results leave as bf16-representable fp32 values -- what a bf16 autocast Linear hands to the next op.
+__device__ __forceinline__ float rbf(float v) { return (float)(__bf16)v; }
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int tid, int m0, int n0, int bz, int sp, int wm, int wn,
+                                              int half, int l31) {
+    if (g.round_bf16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = rbf(acc[i][j][r]);
+    }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* C = g.C + bz * g.sC + sp * g.sSplit;
+    float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
+    const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+
+    if (g.vec_epi) {
+        const bool fast = m0 + BM <= g.M && n0 + BN <= g.N && (g.epi == 1 || (g.epi == 0 && g.act != 2));
+        const int c4 = (tid & 31) * 4;
+        const int rl0 = tid >> 5;
+        f32x4 ax[16];
+        if (fast && g.epi == 1) {                  // relu-grad: the 16 aux loads fly while the accumulators go through LDS
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
+                                                                                0xffffffffu, RSRC_FLAGS);
+            const int voX = (rl0 * g.ldaux + c4) * 4;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ax[q] = buf_load(rsX, voX, q * 8 * g.ldaux * 4);
+        }
+        // The accumulators are transposed through LDS (the staging buffers are free after the main loop) so every global
+        // access of the epilogue is a 16-byte access covering 512 contiguous bytes of one row per half-wave.
+        float* sC = smem;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        if (g.dbg && tid == 0) g.dbg[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 6] = clock64();
+        if (fast) {
+            // fast path (full tile; none / relu / relu-grad): per 16-byte store one ds_read_b128, the activation, one
+            // buffer store whose row advance is a scalar offset -- no per-access address arithmetic on the VALU
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (long long)m0 * g.ldc + n0, 0, 0xffffffffu, RSRC_FLAGS);
+            const int voC = (rl0 * g.ldc + c4) * 4;
+            const int ldsC = (rl0 * CP + c4) * 4;
+            if (g.epi == 0) {
+                const bool relu = g.act == 1;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4 a = ax[q];
+                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
+                    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                }
+            }
+            return;
+        }
+        const int col = n0 + c4;
+        if (col < g.N) {
+            const bool full = col + 3 < g.N;
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int rl = rl0 + 8 * q;
+                const int row = m0 + rl;
+                if (row >= g.M) continue;
+                float4 v = *reinterpret_cast<const float4*>(sC + rl * CP + c4);
+                float o[4] = {v.x, v.y, v.z, v.w};
+                if (g.epi == 0) {
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+                    } else if (g.act == 2) {
+                        if (C2) {
+                            float* p2 = C2 + (long long)row * g.ldc2 + col;
+                            if (full) *reinterpret_cast<float4*>(p2) = make_float4(o[0], o[1], o[2], o[3]);
+                            else for (int k = 0; k < 4 && col + k < g.N; ++k) p2[k] = o[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
+                    }
+                } else {
+                    const float* pa = aux + (long long)row * g.ldaux + col;
+                    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (full) { const float4 t = *reinterpret_cast<const float4*>(pa); a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w; }
+                    else for (int k = 0; k < 4 && col + k < g.N; ++k) a4[k] = pa[k];
+                    if (g.epi == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = a4[k] > 0.f ? o[k] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sg = 1.f / (1.f + __expf(-a4[k]));
+                            o[k] *= sg * (1.f + a4[k] * (1.f - sg));
+                        }
+                    }
+                }
+                float* pc = C + (long long)row * g.ldc + col;
+                if (full) *reinterpret_cast<float4*>(pc) = make_float4(o[0], o[1], o[2], o[3]);
+                else for (int k = 0; k < 4 && col + k < g.N; ++k) pc[k] = o[k];
+            }
+        }
+        return;
+    }
+
+    // Scalar path (unaligned C / aux pitches): one dword per lane per accumulator register.
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                if (g.epi == 0) {
+                    if (g.act == 1) {
+                        v = fmaxf(v, 0.f);
+                    } else if (g.act == 2) {
+                        if (C2) C2[(long long)row * g.ldc2 + col] = v;   // keep the pre-activation for backward
+                        v = v / (1.f + __expf(-v));
+                    }
+                } else if (g.epi == 1) {
+                    v = aux[(long long)row * g.ldaux + col] > 0.f ? v : 0.f;
+                } else {
+                    const float zz = aux[(long long)row * g.ldaux + col];
+                    const float sg = 1.f / (1.f + __expf(-zz));
+                    v *= sg * (1.f + zz * (1.f - sg));
+                }
+                C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
 
 template <bool AKC, bool BKC>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
@@ -352,139 +501,254 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
         }
     } dbg_stamp{g, dbg_c0, dbg_w0, dbg_c1, dbg_w1};
 
-    // ---- epilogue -----------------------------------------------------------------------------------
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* C = g.C + bz * g.sC + sp * g.sSplit;
-    float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
-    const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+    gemm_epilogue(g, acc, tid, m0, n0, bz, sp, wm, wn, half, l31);
+}
 
-    if (g.vec_epi) {
-        const bool fast = m0 + BM <= g.M && n0 + BN <= g.N && (g.epi == 1 || (g.epi == 0 && g.act != 2));
-        const int c4 = (tid & 31) * 4;
-        const int rl0 = tid >> 5;
-        f32x4 ax[16];
-        if (fast && g.epi == 1) {                  // relu-grad: the 16 aux loads fly while the accumulators go through LDS
-            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
-                                                                                0xffffffffu, RSRC_FLAGS);
-            const int voX = (rl0 * g.ldaux + c4) * 4;
+// =====================================================================================================================
+// bf16 MFMA variant (BASELINE.json configs[4]: "AMP discriminator + PPO ... bf16"; the reference's autocast site is
+// phc/learning/amp_agent.py:671, common_agent.py:426,461).  Storage stays fp32 (fp32 master weights, fp32 activations in HBM);
+// operands are rounded to bf16 ON THE WAY INTO LDS, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA
+// rate), and with round_bf16 the outputs leave as bf16-representable values -- exactly what a bf16 autocast Linear computes.
+// Same 128x128 tile, same LDS image geometry with 8 bf16 per 16-byte slot, so one k-tile is 64 deep and one ds_read_b128 is the
+// whole operand of one MFMA.  At this MFMA rate the kernel is bound by the fp32 operand traffic (L2 / HBM), not by the matrix pipe:
+// a plain double-buffered loop, all fragment reads of a stage issued before the tile's barrier (same race rule as above).
+// =====================================================================================================================
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int BK16 = 64;
+
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    bf16x8 o;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) ax[q] = buf_load(rsX, voX, q * 8 * g.ldaux * 4);
+    for (int k = 0; k < 4; ++k) {
+        const bf16x2 t = __builtin_convertvector((f32x2){v[2 * k], v[2 * k + 1]}, bf16x2);
+        o[2 * k] = t[0]; o[2 * k + 1] = t[1];
+    }
+    return o;
+}
+
+template <bool KC>
+struct Stager16 {
+    f32x4 r[8];
+    int voff[8];         // KC: 4 used (each slot = two adjacent 16-byte loads); MC: 8 k rows
+    int lds[4];
+    int kpos;            // first k position of this thread's slot(s) inside the 64-deep tile
+
+    __device__ __forceinline__ void init(int tid, int ld, int ext_rel, int img_off) {
+        if constexpr (KC) {
+            const int kc = tid & 7, row0 = tid >> 3;
+            kpos = kc * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 32 * i;
+                const int rr = row < ext_rel ? row : ext_rel - 1;
+                voff[i] = (rr * ld + kc * 8) * 4;
+                lds[i] = img_off + (kc * KC_SLOTS + slot_of(row)) * 16;
+            }
+        } else {
+            const int kch = tid >> 5, L = tid & 31;
+            kpos = kch * 8;
+            const int col = 4 * L < ext_rel ? 4 * L : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) voff[i] = ((kch * 8 + i) * ld + col) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds[j] = img_off + (kch * KC_SLOTS + slot_of(4 * L + j)) * 16;
         }
-        // The accumulators are transposed through LDS (the staging buffers are free after the main loop) so every global
-        // access of the epilogue is a 16-byte access covering 512 contiguous bytes of one row per half-wave.
-        float* sC = smem;
+    }
+    __device__ __forceinline__ void clamp_short(int ld, int readable) {
+        if constexpr (KC) {
+            // a 16-byte load covers 4 k positions: the first half is readable if kpos < readable, the second if kpos + 4 < readable
+            if (kpos >= readable) {                                  // nothing of this slot is readable: both halves re-read position 0
+#pragma unroll
+                for (int i = 0; i < 4; ++i) voff[i] -= kpos * 4;
+                kpos_hi_ok = false;
+            } else {
+                kpos_hi_ok = kpos + 4 < readable;                     // second half past the readable range: re-read the first half
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (kpos + i >= readable) voff[i] -= (kpos + i) * ld * 4;
+        }
+    }
+    bool kpos_hi_ok = true;
+    __device__ __forceinline__ void load_all(__amdgpu_buffer_rsrc_t rs, int soff) {
+        if constexpr (KC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[2 * i] = buf_load(rs, voff[i], soff);
+                r[2 * i + 1] = buf_load(rs, voff[i] + (kpos_hi_ok ? 16 : 0), soff);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = buf_load(rs, voff[i], soff);
+        }
+    }
+    template <bool MASKED>
+    __device__ __forceinline__ void store(int st, int u, int lo, int hi) {
+        float v[8];
+        if constexpr (KC) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = r[2 * u][e]; v[4 + e] = r[2 * u + 1][e]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = r[i][u];
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (kpos + e < lo || kpos + e >= hi) v[e] = 0.f;
+        }
+        extern __shared__ __attribute__((aligned(16))) char smem_c[];
+        *reinterpret_cast<bf16x8*>(smem_c + st + lds[u]) = pack8(v);
+    }
+};
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs g) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q8 = ntile >> 3, rr = ntile & 7;
+    const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int bz = z / g.splitk, sp = z - bz * g.splitk;
+    const int kbeg = sp * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int klen = kend - kbeg;
+    const int nkt = (klen + BK16 - 1) / BK16;
+    const int r4 = (klen + 3) & ~3;
+    const int wlast = r4 > BK16 ? r4 - BK16 : 0;
+    const int lo = nkt > 0 ? (nkt - 1) * BK16 - wlast : 0;
+    const int hi = klen - wlast;
+
+    const float* Ab = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
+    const float* Bb = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, 0xffffffffu, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, 0xffffffffu, RSRC_FLAGS);
+    const int kstepA = AKC ? 4 : g.lda * 4, kstepB = BKC ? 4 : g.ldb * 4;
+    auto koff = [&](int t) { return t == nkt - 1 ? wlast : t * BK16; };
+
+    Stager16<AKC> sa;
+    Stager16<BKC> sb;
+    sa.init(tid, g.lda, g.M - m0, 0);
+    sb.init(tid, g.ldb, g.N - n0, IMG_BYTES);
+    if (nkt == 1 && r4 < BK16) { sa.clamp_short(g.lda, AKC ? r4 : klen); sb.clamp_short(g.ldb, BKC ? r4 : klen); }
+
+    const int frA0 = (half * KC_SLOTS + slot_of(wm * 64 + l31)) * 16;
+    const int frA1 = (half * KC_SLOTS + slot_of(wm * 64 + 32 + l31)) * 16;
+    const int frB0 = IMG_BYTES + (half * KC_SLOTS + slot_of(wn * 64 + l31)) * 16;
+    const int frB1 = IMG_BYTES + (half * KC_SLOTS + slot_of(wn * 64 + 32 + l31)) * 16;
+
+    f32x16 acc[2][2];
+    {
+        float b0 = 0.f, b1 = 0.f;
+        if (g.epi == 0 && g.bias) {
+            const float* bias = g.bias + bz * g.sBias;
+            const int c0 = n0 + wn * 64 + l31;
+            if (c0 < g.N) b0 = bias[c0];
+            if (c0 + 32 < g.N) b1 = bias[c0 + 32];
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
-        __syncthreads();
-        if (g.dbg && tid == 0) g.dbg[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 6] = clock64();
-        if (fast) {
-            // fast path (full tile; none / relu / relu-grad): per 16-byte store one ds_read_b128, the activation, one
-            // buffer store whose row advance is a scalar offset -- no per-access address arithmetic on the VALU
-            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (long long)m0 * g.ldc + n0, 0, 0xffffffffu, RSRC_FLAGS);
-            const int voC = (rl0 * g.ldc + c4) * 4;
-            const int ldsC = (rl0 * CP + c4) * 4;
-            if (g.epi == 0) {
-                const bool relu = g.act == 1;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
-                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const f32x4 a = ax[q];
-                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
-                    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
-                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
-                }
-            }
-            return;
-        }
-        const int col = n0 + c4;
-        if (col < g.N) {
-            const bool full = col + 3 < g.N;
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const int rl = rl0 + 8 * q;
-                const int row = m0 + rl;
-                if (row >= g.M) continue;
-                float4 v = *reinterpret_cast<const float4*>(sC + rl * CP + c4);
-                float o[4] = {v.x, v.y, v.z, v.w};
-                if (g.epi == 0) {
-                    if (g.act == 1) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
-                    } else if (g.act == 2) {
-                        if (C2) {
-                            float* p2 = C2 + (long long)row * g.ldc2 + col;
-                            if (full) *reinterpret_cast<float4*>(p2) = make_float4(o[0], o[1], o[2], o[3]);
-                            else for (int k = 0; k < 4 && col + k < g.N; ++k) p2[k] = o[k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
-                    }
-                } else {
-                    const float* pa = aux + (long long)row * g.ldaux + col;
-                    float a4[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (full) { const float4 t = *reinterpret_cast<const float4*>(pa); a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w; }
-                    else for (int k = 0; k < 4 && col + k < g.N; ++k) a4[k] = pa[k];
-                    if (g.epi == 1) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = a4[k] > 0.f ? o[k] : 0.f;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float sg = 1.f / (1.f + __expf(-a4[k]));
-                            o[k] *= sg * (1.f + a4[k] * (1.f - sg));
-                        }
-                    }
-                }
-                float* pc = C + (long long)row * g.ldc + col;
-                if (full) *reinterpret_cast<float4*>(pc) = make_float4(o[0], o[1], o[2], o[3]);
-                else for (int k = 0; k < 4 && col + k < g.N; ++k) pc[k] = o[k];
-            }
-        }
-        return;
+            for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
     }
+    float rsum[2] = {0.f, 0.f};
+    const bool do_rs = !AKC && g.rowsum != nullptr && tn == 0 && wn == 0;
 
-    // Scalar path (unaligned C / aux pitches): one dword per lane per accumulator register.
+    bf16x8 fa[4][2], fb[4][2];                                     // the four 16-k groups of one tile
+    auto frags = [&](int G, int st) {
+        extern __shared__ __attribute__((aligned(16))) char smem_c[];
+        const int o = st + 2 * G * KC_SLOTS * 16;
+        fa[G][0] = *reinterpret_cast<const bf16x8*>(smem_c + frA0 + o);
+        fb[G][0] = *reinterpret_cast<const bf16x8*>(smem_c + frB0 + o);
+        fb[G][1] = *reinterpret_cast<const bf16x8*>(smem_c + frB1 + o);
+        fa[G][1] = *reinterpret_cast<const bf16x8*>(smem_c + frA1 + o);
+    };
+    auto mma = [&](int G) {
+        if constexpr (!AKC) {
+            if (do_rs) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= g.N) continue;
+                for (int e = 0; e < 8; ++e) { rsum[0] += (float)fa[G][0][e]; rsum[1] += (float)fa[G][1][e]; }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[G][i], fb[G][0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[G][i], fb[G][1], acc[i][1], 0, 0, 0);
+        }
+    };
+
+    if (nkt > 0) {
+        sa.load_all(rsA, koff(0) * kstepA);
+        sb.load_all(rsB, koff(0) * kstepB);
+        if (nkt == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r];
-                if (g.epi == 0) {
-                    if (g.act == 1) {
-                        v = fmaxf(v, 0.f);
-                    } else if (g.act == 2) {
-                        if (C2) C2[(long long)row * g.ldc2 + col] = v;   // keep the pre-activation for backward
-                        v = v / (1.f + __expf(-v));
-                    }
-                } else if (g.epi == 1) {
-                    v = aux[(long long)row * g.ldaux + col] > 0.f ? v : 0.f;
-                } else {
-                    const float zz = aux[(long long)row * g.ldaux + col];
-                    const float sg = 1.f / (1.f + __expf(-zz));
-                    v *= sg * (1.f + zz * (1.f - sg));
-                }
-                C[(long long)row * g.ldc + col] = v;
+            for (int u = 0; u < 4; ++u) { sa.template store<true>(0, u, lo, hi); sb.template store<true>(0, u, lo, hi); }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sa.template store<false>(0, u, 0, BK16); sb.template store<false>(0, u, 0, BK16); }
+        }
+    }
+    __syncthreads();
+    if (nkt > 1) { sa.load_all(rsA, koff(1) * kstepA); sb.load_all(rsB, koff(1) * kstepB); }
+    if (nkt > 0) frags(0, 0);
+    for (int t = 0; t < nkt; ++t) {
+        const int cur = (t & 1) * STAGE_BYTES, oth = STAGE_BYTES - cur;
+        const bool has_next = t + 1 < nkt, stage_last = t + 2 == nkt;
+        frags(1, cur);
+        mma(0);
+        if (has_next) {
+            if (stage_last) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sa.template store<true>(oth, u, lo, hi);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sa.template store<false>(oth, u, 0, BK16);
+            }
+        }
+        frags(2, cur);
+        mma(1);
+        if (has_next) {
+            if (stage_last) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sb.template store<true>(oth, u, lo, hi);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sb.template store<false>(oth, u, 0, BK16);
+            }
+        }
+        frags(3, cur);                                           // every read of this stage is issued before the barrier
+        if (has_next) __syncthreads();
+        if (t + 2 < nkt) { sa.load_all(rsA, koff(t + 2) * kstepA); sb.load_all(rsB, koff(t + 2) * kstepB); }
+        mma(2);
+        mma(3);
+        if (has_next) frags(0, oth);
+    }
+    if constexpr (!AKC) {
+        if (do_rs) {
+            const float r0 = rsum[0] + __shfl_xor(rsum[0], 32, 64);
+            const float r1 = rsum[1] + __shfl_xor(rsum[1], 32, 64);
+            if (half == 0) {
+                float* rs = g.rowsum + bz * g.sRowsum + sp * g.sSplit;
+                const int row = m0 + wm * 64 + l31;
+                if (row < g.M) rs[row] = r0;
+                if (row + 32 < g.M) rs[row + 32] = r1;
             }
         }
     }
+    __syncthreads();
+    gemm_epilogue(g, acc, tid, m0, n0, bz, sp, wm, wn, half, l31);
 }
 
 // ---- deterministic reduction of split-K slabs (and of column-sum partials) ---------------------
@@ -601,14 +865,18 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldc2 = d->ldc2; g.ldaux = d->ldaux;
     g.sA = d->stride_a; g.sB = d->stride_b; g.sC = d->stride_c; g.sC2 = d->stride_c2; g.sBias = d->stride_bias; g.sAux = d->stride_aux;
     g.batch = d->batch; g.splitk = d->split_k;
+    const int bk = d->compute_type == PULSE_GEMM_COMPUTE_BF16 ? BK16 : BK;
     int kchunk = (d->K + d->split_k - 1) / d->split_k;
-    kchunk = ((kchunk + BK - 1) / BK) * BK;
-    g.kchunk = kchunk > 0 ? kchunk : BK;
+    kchunk = ((kchunk + bk - 1) / bk) * bk;
+    g.kchunk = kchunk > 0 ? kchunk : bk;
     g.sSplit = d->split_stride;
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     g.dbg = g_dbg;
+    PULSE_REQUIRE(d->compute_type == PULSE_GEMM_COMPUTE_F32 || d->compute_type == PULSE_GEMM_COMPUTE_BF16, "pulse_gemm_f32: bad compute_type");
+    const bool bf = d->compute_type == PULSE_GEMM_COMPUTE_BF16;
+    g.round_bf16 = bf && d->round_output_bf16 ? 1 : 0;
     // per-workgroup buffer offsets are 32-bit: tile-relative (128 rows) for reduction-contiguous operands, split-relative
     // (kchunk rows) for [red][out] operands
     PULSE_REQUIRE((long long)d->lda * (akc ? 129 : g.kchunk + 1) < (1LL << 28) && (long long)d->ldb * (bkc ? 129 : g.kchunk + 1) < (1LL << 28) &&
@@ -621,7 +889,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
     // The 64.5 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling
     // hipFuncSetAttribute on every launch serialises the host against the stream).
-    static size_t attr_done[3] = {0, 0, 0};
+    static size_t attr_done[6] = {0, 0, 0, 0, 0, 0};
     hipError_t e = hipSuccess;
 #define LAUNCH(IDX, AK, BK_)                                                                                       \
     if (attr_done[IDX] != lds) {                                                                                      \
@@ -631,10 +899,23 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
         attr_done[IDX] = lds;                                                                                     \
     }                                                                                                             \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
-    if (akc && bkc) { LAUNCH(0, true, true); }
+#define LAUNCH16(IDX, AK, BK_)                                                                                     \
+    if (attr_done[IDX] != lds) {                                                                                  \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AK, BK_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_f32: LDS attribute: %s", hipGetErrorString(e)); \
+        attr_done[IDX] = lds;                                                                                     \
+    }                                                                                                             \
+    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
+    if (bf) {
+        if (akc && bkc) { LAUNCH16(3, true, true); }
+        else if (akc && !bkc) { LAUNCH16(4, true, false); }
+        else { LAUNCH16(5, false, false); }
+    } else if (akc && bkc) { LAUNCH(0, true, true); }
     else if (akc && !bkc) { LAUNCH(1, true, false); }
     else { LAUNCH(2, false, false); }
 #undef LAUNCH
+#undef LAUNCH16
     return check_launch("pulse_gemm_f32");
 }
 

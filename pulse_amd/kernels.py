@@ -18,6 +18,20 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
+def _chk(t, name, dtype=torch.float32, contiguous=True):
+    """Raw-pointer arguments: wrong dtype / device / layout would be silently re-interpreted by the kernel (e.g. uint8 dones read as
+    int64), so they are rejected here.  None passes through (optional arguments)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise TypeError(f"{name}: expected a CUDA tensor, got {type(t).__name__} on {getattr(t, 'device', None)}")
+    if t.dtype != dtype and not (dtype == torch.uint8 and t.dtype == torch.bool):
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and t.numel() > 0 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost stride must be 1, got strides {tuple(t.stride())}")
+    return t.data_ptr()
+
+
 class GemmProfiler:
     """Brackets every pulse_gemm_f32 launch with a HIP event pair on the launch stream (torch's
     current stream IS the stream the kernels are enqueued on) and tallies algorithmic FLOPs.
@@ -55,7 +69,7 @@ def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG,
                    activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
                    stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
                    a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None, rowsum=None, rowsum_off=0,
-                   stride_rowsum=0):
+                   stride_rowsum=0, compute_bf16=False):
     """Build (descriptor, algorithmic FLOPs, variant tag) once; launch many times with launch_gemm."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -72,7 +86,12 @@ def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG,
     d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
     d.rowsum = (rowsum.data_ptr() + 4 * rowsum_off) if rowsum is not None else None
     d.stride_rowsum = stride_rowsum
+    # bf16 MFMA with fp32 storage (bf16 autocast over fp32 master weights); split-K slabs are partial sums and stay unrounded
+    d.compute_type = _lib.GEMM_COMPUTE_BF16 if compute_bf16 else _lib.GEMM_COMPUTE_F32
+    d.round_output_bf16 = 1 if (compute_bf16 and split_k == 1) else 0
     tag = ("fwd" if b_layout == GEMM_RED_CONTIG else "dx") if a_layout == GEMM_RED_CONTIG else "dw"
+    if compute_bf16:
+        tag = "bf16_" + tag
     flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
     return d, flops, tag
 
@@ -100,18 +119,21 @@ class Plan:
     """A pre-built launch sequence: GEMM descriptors and bound C-ABI calls are created once per
     workspace, so replaying a forward / backward pass costs one ctypes call per kernel."""
 
-    def __init__(self):
+    def __init__(self, bf16=False):
         self.ops = []
+        self.split = 0
+        self.bf16 = bool(bf16)          # every GEMM of this plan runs on the bf16 MFMA (mixed_precision training passes)
 
     def gemm(self, A, B, C, **kw):
+        kw.setdefault("compute_bf16", self.bf16)
         self.ops.append((0,) + make_gemm_desc(A, B, C, **kw))
 
     def call(self, name, *args):
         self.ops.append((1, getattr(_lib.load(), name), args, name))
 
-    def run(self):
+    def run(self, start=0, stop=None):
         st = _stream()
-        for op in self.ops:
+        for op in self.ops[start:stop]:
             if op[0] == 0:
                 launch_gemm(op[1], op[2], op[3], st)
             else:
@@ -159,6 +181,10 @@ def policy_sample(mu, mu_stride, logstd, noise, noise_stride, rows, num_actions,
                   values_off=0, mus_out=None, mus_out_stride=0, mus_out_off=0):
     def po(t, off):
         return (t.data_ptr() + 4 * off) if t is not None else None
+    for t, nm in ((mu, "mu"), (logstd, "logstd"), (noise, "noise"), (value_raw, "value_raw"), (actions, "actions"), (sigmas, "sigmas"),
+                  (neglogp, "neglogp"), (values, "values"), (mus_out, "mus_out")):
+        _chk(t, nm)
+    _chk(value_mean, "value_mean", torch.float64), _chk(value_var, "value_var", torch.float64)
     _lib.check(_lib.load().pulse_policy_sample(po(mu, mu_off), mu_stride, _p(logstd), _p(noise), noise_stride, _p(value_raw),
                                                value_stride, _p(value_mean), _p(value_var), rows, num_actions,
                                                po(actions, actions_off), actions_stride, po(sigmas, sigmas_off), sigmas_stride,
@@ -195,11 +221,19 @@ def advantage_normalize(returns, values, adv_out, partials):
 
 
 def sqnorm_partial(x, count, partials):
+    _chk(x, "x"), _chk(partials, "partials")
+    if x.numel() < count or not x.is_contiguous():
+        raise ValueError(f"sqnorm_partial: x must be a contiguous buffer of at least {count} floats")
     _lib.check(_lib.load().pulse_sqnorm_partial(_p(x), count, _p(partials), partials.numel(), _stream()), "pulse_sqnorm_partial")
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               max_norm=0.0, sqnorm_partials=None, grad_norm_out=None):
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (sqnorm_partials, "sqnorm_partials"),
+                  (grad_norm_out, "grad_norm_out")):
+        _chk(t, nm)
+        if t is not None and nm in ("params", "grads", "exp_avg", "exp_avg_sq") and (t.numel() < count or not t.is_contiguous()):
+            raise ValueError(f"adam_step: {nm} must be a contiguous buffer of at least {count} floats")
     _lib.check(_lib.load().pulse_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), count, float(lr), beta1, beta2,
                                            eps, weight_decay, int(step), float(max_norm), _p(sqnorm_partials),
                                            sqnorm_partials.numel() if sqnorm_partials is not None else 0, _p(grad_norm_out),
@@ -212,8 +246,11 @@ def rollout_record(*, rewards, dones, terminate, value_raw, value_stride, value_
     """play_steps bookkeeping of one rollout step in one launch (include/pulse_hip.h section 2c)."""
     a = _lib.RolloutRecordArgs()
     a.num_envs = rewards.numel()
-    a.rewards, a.reward_scale, a.reward_shift = _p(rewards), float(reward_scale), float(reward_shift)
-    a.dones, a.terminate = _p(dones), _p(terminate)
+    a.rewards, a.reward_scale, a.reward_shift = _chk(rewards, "rewards"), float(reward_scale), float(reward_shift)
+    a.dones, a.terminate = _chk(dones, "dones", torch.int64), _chk(terminate, "terminate", torch.int64)
+    _chk(done_mask, "done_mask", torch.uint8), _chk(current_rewards, "current_rewards"), _chk(current_lengths, "current_lengths")
+    _chk(meter_rewards, "meter_rewards"), _chk(meter_lengths, "meter_lengths"), _chk(value_mean, "value_mean", torch.float64)
+    _chk(value_var, "value_var", torch.float64)
     a.value_raw, a.value_stride = _p(value_raw), int(value_stride)
     a.value_mean, a.value_var, a.value_eps = _p(value_mean), _p(value_var), float(value_eps)
     a.buf_rewards, a.buf_next_values, a.buf_dones, a.env_stride = _p(buf_rewards), _p(buf_next_values), _p(buf_dones), int(env_stride)

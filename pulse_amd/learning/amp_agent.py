@@ -88,7 +88,9 @@ class AMPAgent(CommonAgent):
         self.only_kin_loss = bool(env_cfg.get("only_kin_loss", False))
         self.temp_running_mean = bool(getattr(task, "temp_running_mean", True))
         self.kin_lr = float(getattr(task, "kin_lr", 5e-4))
-        self.enable_disc = bool(config.get("enable_disc", False))
+        # the reference's AMPAgent always trains its discriminator (amp_agent.py:621-629, 704-709); here it follows the env: on whenever
+        # the env exposes AMP observation windows, unless the config says otherwise
+        self.enable_disc = bool(config.get("enable_disc", "amp_observation_space" in self.env_info))
         if self.enable_disc:
             self._load_amp_config(config)
         if self.save_kin_info:
@@ -115,6 +117,7 @@ class AMPAgent(CommonAgent):
         if not self._normalize_amp_input or config.get("norm_disc_reward", False):
             raise NotImplementedError("normalize_amp_input: True / norm_disc_reward: False (the shipped settings)")
         self.disc = DiscNetwork(config["network"], self._amp_dim, device=self.ppo_device, split_k=int(config.get("split_k", 8)))
+        self.disc.mixed_precision = self.mixed_precision
         self._amp_input_mean_std = RunningMeanStd((self._amp_dim,), device=self.ppo_device)
         self.disc_exp_avg = torch.zeros(self.disc.n_flat, device=self.ppo_device)
         self.disc_exp_avg_sq = torch.zeros(self.disc.n_flat, device=self.ppo_device)

@@ -45,13 +45,19 @@ class CommonAgent:
         self.config = self.cfg = config
         self.base_name = base_name
         self.exp_name = str(config.get("train_dir", "output/pulse_amd")).split("/")[-1]
+        self.nn_dir = config.get("network_path", str(config.get("train_dir", "output/pulse_amd")) + "/nn")
         self.multi_gpu = bool(config.get("multi_gpu", False))
+        self.overlap_allreduce = bool(config.get("overlap_allreduce", True))   # gradient buckets all-reduced beside the backward
         self.dist = config.get("dist") or DistContext(enabled=None if self.multi_gpu else False)
         self.rank, self.world_size = self.dist.rank, self.dist.world_size
         self.ppo_device = self.device = torch.device(config.get("device", config.get("ppo_device", "cuda:0")))
         if self.ppo_device.type != "cuda":
             raise ValueError("pulse_amd agents run on the GPU only (there is no CPU path)")
-        self.vec_env = config["vec_env"]
+        if "vec_env" in config:
+            self.vec_env = config["vec_env"]
+        else:                # A2CBase.__init__: vecenv.create_vec_env(env_name, num_actors, **env_config)
+            from ..runner import create_vec_env
+            self.vec_env = create_vec_env(config["env_name"], int(config["num_actors"]), **config.get("env_config", {}))
         self.env_info = config.get("env_info") or self.vec_env.get_env_info()
         self.num_actors = int(config.get("num_actors", self.vec_env.num_envs))
         self.num_agents = 1
@@ -74,9 +80,11 @@ class CommonAgent:
         self.batch_size = self.horizon_length * self.num_actors * self.num_agents
         assert self.batch_size % self.minibatch_size == 0, "batch_size must be divisible by minibatch_size"
         self.num_minibatches = self.batch_size // self.minibatch_size
+        # mixed_precision: the reference wraps model forward + losses of calc_gradients in autocast (amp_agent.py:671,
+        # common_agent.py:426) with a GradScaler.  Here it selects the bf16 MFMA for the TRAINING forward / backward GEMMs over
+        # fp32 master weights (BASELINE.json configs[4] names bf16; bf16 needs no loss scaling); rollout inference stays fp32
+        # like the reference's un-autocast get_action_values (common_agent.py:262-288).
         self.mixed_precision = bool(config.get("mixed_precision", False))
-        if self.mixed_precision:
-            raise NotImplementedError("fp16 autocast + GradScaler path (config 5) is not built; fp32 only")
         self.weight_decay = float(config.get("weight_decay", 0.0))
         self.schedule_type = config.get("schedule_type", "legacy")
         self.is_adaptive_lr = config.get("lr_schedule", "constant") == "adaptive"
@@ -113,6 +121,10 @@ class CommonAgent:
         self.noise_generator = torch.Generator(device=self.ppo_device)
         self.noise_generator.manual_seed(seed)
         self.model = self._build_model(net_config)
+        if self.mixed_precision:
+            if not hasattr(self.model, "mixed_precision"):
+                raise NotImplementedError("mixed_precision is built for the actor / critic MLP and the discriminator (cfg5); the amp_z graph runs fp32")
+            self.model.mixed_precision = True
         self.last_lr = float(self.last_lr)
         # Adam(lr, eps=1e-8) over the flat parameter buffer (common_agent.py:66)
         n = self.model.parameters_count()
@@ -458,9 +470,10 @@ class CommonAgent:
                    e_clip=self.e_clip, critic_coef=self.critic_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
                    dmu=ws["dmu"], dmu_stride=ws["dmu"].stride(0), dvalue=ws["dval"], dvalue_stride=ws["dval"].stride(0),
                    partials=self._loss_slot())
-        net.backward(ws, mb, grad_scale=1.0 / self.world_size)
+        overlap = self.multi_gpu and self.overlap_allreduce and hasattr(net, "w_off")
+        net.backward(ws, mb, grad_scale=1.0 / self.world_size, **({"on_bucket": self._bucket_ready} if overlap else {}))
         extra_info = self._extra_gradients(input_dict, idx)               # AMPAgent: discriminator loss / gradients
-        self._apply_gradients()
+        self._apply_gradients(policy_synced=overlap)
         info, gnorm = self._loss_info(mb)                               # [a_loss, c_loss, b_loss, clip_frac, kl]
         if self._entropy is None:
             ent = float((0.5 + 0.5 * math.log(2 * math.pi)) * self.actions_num) + float(net.sigma.sum().item())
@@ -520,12 +533,19 @@ class CommonAgent:
         net = self.model
         return [(net.flat, net.grad, self.exp_avg, self.exp_avg_sq, net.n_flat)]
 
-    def _apply_gradients(self):
+    def _bucket_ready(self, grad_view):
+        """Data-parallel overlap: a finished gradient bucket goes on the wire while the backward continues."""
+        self.dist.sync_gradients(grad_view, async_op=True)
+
+    def _apply_gradients(self, policy_synced=False):
         """[all-reduce] -> clip_grad_norm_ over ALL parameters -> Adam, one fused launch per flat buffer."""
         groups = self._param_groups()
         if self.multi_gpu:
-            for g in groups:
-                self.dist.sync_gradients(g[1])                               # optimizer.synchronize()
+            for i, g in enumerate(groups):
+                if i == 0 and policy_synced:
+                    continue                                                 # its buckets went out during the backward
+                self.dist.sync_gradients(g[1], async_op=policy_synced)       # optimizer.synchronize()
+            self.dist.wait_gradients()
         self.optimizer_step += 1
         nb = 256
         if self._sq_partials.numel() != nb * len(groups):
@@ -611,6 +631,10 @@ class CommonAgent:
                 mean_rewards = self.game_rewards.get_mean()
                 print(f"epoch: {epoch_num} frames: {self.frame} fps step: {fps_step:.1f} fps total: {fps_total:.1f} "
                       f"reward: {mean_rewards}", flush=True)
+            if self.save_freq > 0 and epoch_num % self.save_freq == 0 and self.rank == 0:      # common_agent.py:160-170
+                import os
+                os.makedirs(self.nn_dir, exist_ok=True)
+                self.save(os.path.join(self.nn_dir, self.config.get("name", "Humanoid")))
             if epoch_num >= max_epochs:
                 return self.game_rewards.get_mean(), epoch_num
 

@@ -41,6 +41,7 @@ class DiscNetwork:
         self.book.finalize()
         self.flat, self.grad, self.n_flat = self.book.flat, self.book.grad, self.book.n_flat
         self._ws = {}
+        self.mixed_precision = False      # True: the training passes (forward on the 3b rows, BCE / penalty backward, weight gradients) on the bf16 MFMA
         self.reset_parameters()
 
     def reset_parameters(self, generator=None):
@@ -85,14 +86,14 @@ class DiscNetwork:
         ws["dL"][3 * b:, 0] = 1.0                      # the penalty path's "ones" column for dw3
         ws["logits"] = ws["L"][:3 * b, :1]
         ws["dlogits"] = ws["dL"][:3 * b, :1]
-        ws["fwd"] = self._plan_forward(ws, 3 * b)
+        ws["fwd"] = self._plan_forward(ws, 3 * b, bf16=self.mixed_precision)
         ws["bwd_bce"], ws["pen_fwd"], ws["pen_bwd"], ws["wgrad"] = self._plans_backward(ws)
         self._ws[b] = ws
         return ws
 
-    def _plan_forward(self, ws, m, x=None, logits=None):
+    def _plan_forward(self, ws, m, x=None, logits=None, bf16=False):
         f = self.flat
-        p = K.Plan()
+        p = K.Plan(bf16=bf16)
         x = ws["X"] if x is None else x
         p.gemm(x, f, ws["H1"], M=m, N=self.u1, K=self.k0, lda=x.stride(0), ldb=self.l1.w.pitch, ldc=self.u1, bias=f, activation=ACT_RELU,
                b_off=self.l1.w.off, bias_off=self.l1.b.off)
@@ -109,26 +110,26 @@ class DiscNetwork:
         w1, w2, w3 = self.l1.w, self.l2.w, self.l3.w
         r3, demo = 3 * b, 2 * b                                     # first penalty row / first demo row
         # (1) BCE path: dz2 = (dL w3) * m2 ; dz1 = (dz2 W2) * m1   over the 3b forward rows
-        bce = K.Plan()
+        bce = K.Plan(bf16=self.mixed_precision)
         bce.gemm(ws["dL"], f, ws["Z2"], M=r3, N=u2, K=1, lda=4, ldb=w3.pitch, ldc=u2, b_layout=GEMM_OUT_CONTIG, b_off=w3.off,
                  epilogue=EPI_RELU_GRAD, aux=ws["H2"], ldaux=u2)
         bce.gemm(ws["Z2"], f, ws["Z1"], M=r3, N=u1, K=u2, lda=u2, ldb=w2.pitch, ldc=u1, b_layout=GEMM_OUT_CONTIG, b_off=w2.off,
                  epilogue=EPI_RELU_GRAD, aux=ws["H1"], ldaux=u1)
         # (2a) penalty forward on the demo rows: u2, u1, g = dD/dx
-        pf = K.Plan()
+        pf = K.Plan(bf16=self.mixed_precision)
         pf.gemm(ws["dL"], f, ws["Z2"], M=b, N=u2, K=1, lda=4, ldb=w3.pitch, ldc=u2, b_layout=GEMM_OUT_CONTIG, a_off=r3 * 4, b_off=w3.off,
                 c_off=r3 * u2, epilogue=EPI_RELU_GRAD, aux=ws["H2"], ldaux=u2, aux_off=demo * u2)
         pf.gemm(ws["Z2"], f, ws["Z1"], M=b, N=u1, K=u2, lda=u2, ldb=w2.pitch, ldc=u1, b_layout=GEMM_OUT_CONTIG, a_off=r3 * u2, b_off=w2.off,
                 c_off=r3 * u1, epilogue=EPI_RELU_GRAD, aux=ws["H1"], ldaux=u1, aux_off=demo * u1)
         pf.gemm(ws["Z1"], f, ws["G"], M=b, N=k0, K=u1, lda=u1, ldb=w1.pitch, ldc=k0p, b_layout=GEMM_OUT_CONTIG, a_off=r3 * u1, b_off=w1.off)
         # (2b) penalty backward: dt1 = (dg W1^T) * m1 -> H1[3b:] ;  m2 * (dt1 W2^T) -> H2[3b:]      (dg lives in X[3b:])
-        pb = K.Plan()
+        pb = K.Plan(bf16=self.mixed_precision)
         pb.gemm(ws["X"], f, ws["H1"], M=b, N=u1, K=k0, lda=k0p, ldb=w1.pitch, ldc=u1, a_off=r3 * k0p, b_off=w1.off, c_off=r3 * u1,
                 epilogue=EPI_RELU_GRAD, aux=ws["H1"], ldaux=u1, aux_off=demo * u1)
         pb.gemm(ws["H1"], f, ws["H2"], M=b, N=u2, K=u1, lda=u1, ldb=w2.pitch, ldc=u2, a_off=r3 * u1, b_off=w2.off, c_off=r3 * u2,
                 epilogue=EPI_RELU_GRAD, aux=ws["H2"], ldaux=u2, aux_off=demo * u2)
         # (3) weight gradients over all 4b stacked rows, bias gradients over the 3b BCE rows
-        wg = K.Plan()
+        wg = K.Plan(bf16=self.mixed_precision)
         m = 4 * b
         wg.gemm(ws["Z1"], ws["X"], slabs, M=u1, N=k0, K=m, lda=u1, ldb=k0p, ldc=w1.pitch, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
                 c_off=w1.off, split_k=S, split_stride=P)

@@ -65,6 +65,7 @@ class A2CNetwork:
         self._slabs = None
         self._ws = {}
         self.training = True
+        self.mixed_precision = False      # True: the TRAINING forward / backward run on the bf16 MFMA (amp_agent.py:671 autocast); inference stays fp32
         self.reset_parameters()
 
     # ------------------------------------------------------------------ config (network_builder.py:461-502)
@@ -212,6 +213,7 @@ class A2CNetwork:
         ws["plan_fwd"] = self._plan_forward(ws, m, 0, 2)
         ws["plan_critic"] = self._plan_forward(ws, m, 1, 1)
         if train:
+            ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, bf16=True) if self.mixed_precision else ws["plan_fwd"]
             ws["dh"] = [e(m, 2 * uu) for uu in u]
             ws["dheads"] = torch.zeros(m, 2 * self.a_pitch, dtype=torch.float32, device=dev)
             ws["dmu"] = ws["dheads"][:, :self.actions_num]
@@ -226,11 +228,11 @@ class A2CNetwork:
         self._ws[key] = ws
         return ws
 
-    def _plan_forward(self, ws, m, n0, cnt):
+    def _plan_forward(self, ws, m, n0, cnt, bf16=False):
         """nets n0 .. n0+cnt-1 (0 = actor, 1 = critic)."""
         u, f = self.units, self.flat
         pre = ws.get("z")
-        p = K.Plan()
+        p = K.Plan(bf16=bf16)
         for l, uu in enumerate(u):
             k = self.in_w[l]
             if l == 0:   # both nets read the same input: one GEMM of N = cnt*u1
@@ -252,7 +254,7 @@ class A2CNetwork:
 
     def forward(self, ws, m):
         """Actor + critic forward on the normalised input in ws['x'] -> ws['heads'] (mu | value)."""
-        ws["plan_fwd"].run()
+        (ws["plan_fwd_train"] if (self.training and "plan_fwd_train" in ws) else ws["plan_fwd"]).run()
 
     def eval_critic(self, ws, m):
         """Critic only (CommonAgent._eval_critic, common_agent.py:551-562) -> ws['val']."""
@@ -265,7 +267,7 @@ class A2CNetwork:
         slabs, P = self._slabs, self.n_flat
         egrad = EPI_RELU_GRAD if self.act == ACT_RELU else EPI_SILU_GRAD
         aux = ws["h"] if self.act == ACT_RELU else ws["z"]
-        p = K.Plan()
+        p = K.Plan(bf16=self.mixed_precision)
 
         dhd = ws["dheads"]
         # heads -> dH_L for both nets in one launch (activation derivative fused)
@@ -284,6 +286,7 @@ class A2CNetwork:
             dz = ws["dh"][l]
             # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
             if l == 0:
+                p.split = len(p.ops)        # everything before this point only touches gradient elements >= w_off[1] (layers 2.., heads)
                 p.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P, algo_n=self.in_dim,
                        rowsum=slabs, rowsum_off=self.b_off[0])
@@ -297,9 +300,26 @@ class A2CNetwork:
                        aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
         return p
 
-    def backward(self, ws, m, grad_scale=1.0):
+    def backward(self, ws, m, grad_scale=1.0, on_bucket=None):
         """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
-        Deterministic: split-K slabs + ordered reduces."""
-        ws["plan_bwd"].run()
-        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat, self.grad, scale=grad_scale)
+        Deterministic: split-K slabs + ordered reduces.
+
+        ``on_bucket(grad_view)``: data-parallel overlap hook.  The backward produces the gradient of the upper layers and the heads
+        (flat elements >= w_off[1], 4.2 of 12 MB for [1024, 512]) before the layer-1 weight-gradient GEMM -- the largest GEMM of
+        the step -- starts; that bucket is reduced and handed over first so its all-reduce runs beside the layer-1 GEMM, the layer-1
+        bucket follows when its GEMM is done."""
+        plan = ws["plan_bwd"]
+        if on_bucket is None or len(self.units) < 2:
+            plan.run()
+            K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat, self.grad, scale=grad_scale)
+            if on_bucket is not None:
+                on_bucket(self.grad)
+            return self.grad
+        cut = self.w_off[1]
+        plan.run(0, plan.split)
+        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat - cut, self.grad, scale=grad_scale, slabs_off=cut, out_off=cut)
+        on_bucket(self.grad[cut:])
+        plan.run(plan.split, None)
+        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, cut, self.grad, scale=grad_scale)
+        on_bucket(self.grad[:cut])
         return self.grad

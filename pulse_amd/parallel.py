@@ -28,6 +28,8 @@ class DistContext:
         self.enabled = (ws_env > 1) if enabled is None else enabled
         self.rank, self.world_size, self.local_rank = 0, 1, 0
         self._own_group = False
+        self._stat = {"calls": 0, "bytes": 0, "seconds": 0.0}
+        self._pending = []
         if not self.enabled:
             return
         self.rank = int(os.environ.get("RANK", "0"))
@@ -83,10 +85,32 @@ class DistContext:
         for t in extra_tensors:
             self.broadcast_(t)
 
-    def sync_gradients(self, flat_grad):
+    def sync_gradients(self, flat_grad, async_op=False):
         """The explicit `optimizer.synchronize()` of the reference: SUM all-reduce of the flat gradient
-        (each rank pre-scaled its gradient by 1/world_size in the slab reduce)."""
-        return self.all_reduce_sum_(flat_grad)
+        (each rank pre-scaled its gradient by 1/world_size in the slab reduce).  ``async_op``: the collective is enqueued behind
+        the work already on the current stream and runs beside what is launched next; ``wait_gradients`` joins it."""
+        import time
+        t0 = time.perf_counter()
+        if async_op and self.enabled:
+            self._pending.append(dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True))
+            out = flat_grad
+        else:
+            out = self.all_reduce_sum_(flat_grad)
+        self._stat["calls"] += 1
+        self._stat["bytes"] += flat_grad.numel() * flat_grad.element_size()
+        self._stat["seconds"] += time.perf_counter() - t0            # host enqueue time (the collective itself is asynchronous)
+        return out
+
+    def wait_gradients(self):
+        """Make the current stream wait for every gradient bucket in flight."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def stats(self):
+        d = dict(self._stat)
+        d["backend"] = dist.get_backend() if (self.enabled and dist.is_initialized()) else "none"
+        return d
 
     def sync_stats(self, stat_modules, curr_frames):
         """Average running mean / var / count across ranks; sum the frame counter."""

@@ -209,14 +209,14 @@ def _free_port():
     return p
 
 
-def _rank_worker(rank, world, port, outdir):
+def _rank_worker(rank, world, port, outdir, overlap=False):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                        "PULSE_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     import torch as th
     from pulse_amd import configs as C
     th.cuda.set_device(0)
     th.manual_seed(1000 + rank)                                            # different initial weights per rank: setup_algo must fix that
-    agent, _ = C.make_agent("cfg1", device="cuda:0", seed=7, rank=rank, multi_gpu=True, permutation_device="cpu")
+    agent, _ = C.make_agent("cfg1", device="cuda:0", seed=7, rank=rank, multi_gpu=True, permutation_device="cpu", overlap_allreduce=overlap)
     assert agent.world_size == world and agent.rank == rank
     agent.init_tensors()
     agent.obs = agent.env_reset()
@@ -226,10 +226,11 @@ def _rank_worker(rank, world, port, outdir):
     pre, post = [], []
     inner = agent.dist.sync_gradients
 
-    def spy(g):
+    def spy(g, async_op=False):
         pre.append(g.detach().clone().cpu())
-        out = inner(g)
-        post.append(g.detach().clone().cpu())
+        out = inner(g, async_op=async_op)
+        if not async_op:
+            post.append(g.detach().clone().cpu())
         return out
     agent.dist.sync_gradients = spy
     batch = agent.play_steps()
@@ -242,7 +243,7 @@ def _rank_worker(rank, world, port, outdir):
     agent._end_loss_ring()
     th.cuda.synchronize()
     th.save({"before": flat_before.cpu(), "after_setup_rank0_view": None, "pre": pre, "post": post, "flat": agent.model.flat.cpu(),
-             "obs_sum": float(agent.experience_buffer.tensor_dict["obses"].double().sum())}, os.path.join(outdir, f"rank{rank}.pt"))
+             "obs_sum": float(agent.experience_buffer.tensor_dict["obses"].double().sum())}, os.path.join(outdir, f"rank{rank}_{int(overlap)}.pt"))
     agent.dist.barrier()
     agent.dist.shutdown()
 
@@ -252,13 +253,19 @@ def test_two_ranks_share_gpu_gradient_mean_and_identical_parameters(dev):
     ctx = mp.get_context("spawn")
     port = _free_port()
     with tempfile.TemporaryDirectory() as outdir:
-        procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, outdir)) for r in range(2)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(timeout=600)
-        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-        r0, r1 = (torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2))
+        for overlap in (False, True):
+            procs = [ctx.Process(target=_rank_worker, args=(r, 2, port + int(overlap), outdir, overlap)) for r in range(2)]
+            for p in procs:
+                p.start()
+            for p in procs:
+                p.join(timeout=600)
+            assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        r0, r1 = (torch.load(os.path.join(outdir, f"rank{r}_0.pt")) for r in range(2))
+        o0, o1 = (torch.load(os.path.join(outdir, f"rank{r}_1.pt")) for r in range(2))
+    # overlapped path (two gradient buckets all-reduced asynchronously beside the layer-1 weight-gradient GEMM): six bucket calls,
+    # the same parameters, bit for bit, as the single blocking all-reduce
+    assert len(o0["pre"]) == 6 and o0["pre"][0].numel() + o0["pre"][1].numel() == r0["pre"][0].numel()
+    assert torch.equal(o0["flat"], o1["flat"]) and torch.equal(o0["flat"], r0["flat"])
     assert not torch.equal(r0["before"], r1["before"])                      # ranks started from different weights ...
     assert abs(r0["obs_sum"] - r1["obs_sum"]) > 1e-3                        # ... and own different env shards
     assert len(r0["pre"]) == len(r1["pre"]) == 3

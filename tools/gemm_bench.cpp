@@ -33,6 +33,7 @@ struct CaseP {
     int splitk; long long split_stride;
     int act, epi; bool bias; int ldaux; long long saux;
     double algo_flops;
+    int bf16;
 };
 struct Case : CaseP { std::string name; };
 
@@ -51,6 +52,7 @@ __global__ void check_kernel(const float* A, const float* B, const float* C, con
     for (int k = 0; k < c.K; ++k) {
         float av = c.a_layout == PULSE_GEMM_RED_CONTIG ? a[(long long)m * c.lda + k] : a[(long long)k * c.lda + m];
         float bv = c.b_layout == PULSE_GEMM_RED_CONTIG ? b[(long long)n * c.ldb + k] : b[(long long)k * c.ldb + n];
+        if (c.bf16) { av = (float)(__bf16)av; bv = (float)(__bf16)bv; }
         acc = fmaf(av, bv, acc);
     }
     float ref = acc;
@@ -68,7 +70,7 @@ int main(int argc, char** argv) {
     int iters = 20, warm = 3;
     std::string only;
     std::vector<std::pair<int, int>> opts;
-    bool sweep = false, clocks = false;
+    bool sweep = false, clocks = false, bf16_cases = false;
     std::vector<std::vector<int>> custom;      // --fwd M N K lda ldb ldc
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
@@ -77,6 +79,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--opt")) { int k = atoi(argv[++i]); int v = atoi(argv[++i]); opts.push_back({k, v}); }
         else if (!strcmp(argv[i], "--sweep")) sweep = true;
         else if (!strcmp(argv[i], "--clocks")) clocks = true;
+        else if (!strcmp(argv[i], "--bf16")) bf16_cases = true;
         else if (!strcmp(argv[i], "--fwd")) { std::vector<int> v; for (int j = 0; j < 6; ++j) v.push_back(atoi(argv[++i])); custom.push_back(v); }
     }
     for (auto& o : opts) pulse_gemm_set_option(o.first, o.second);
@@ -98,7 +101,7 @@ int main(int argc, char** argv) {
                    long long sc, int splitk, long long ss, int act, int epi, bool bias, int ldaux, long long saux, double algoK, double algoN) {
         Case c;
         static_cast<CaseP&>(c) = CaseP{M, N, K, lda, ldb, ldc, al, bl, batch, sa, sb, sc, splitk, ss, act, epi, bias, ldaux, saux,
-                                       2.0 * M * (algoN > 0 ? algoN : N) * (algoK > 0 ? algoK : K) * batch};
+                                       2.0 * M * (algoN > 0 ? algoN : N) * (algoK > 0 ? algoK : K) * batch, 0};
         c.name = nm;
         cases.push_back(c);
     };
@@ -139,6 +142,10 @@ int main(int argc, char** argv) {
             add(nm, 16384, 2048, K, 4096, 4096, 2048, R, R, 1, 0, 0, 0, 1, 0, 1, 0, true, 0, 0, 0, 0);
         }
 
+    if (bf16_cases) {
+        const size_t n0 = cases.size();
+        for (size_t i = 0; i < n0; ++i) { Case c = cases[i]; c.bf16 = 1; c.name = "bf16 " + c.name; cases.push_back(c); }
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     {   // DVFS ramp: the chip needs sustained load before its clock settles; measured cases right after idle run ~10 % slow
         pulse_gemm_desc d; memset(&d, 0, sizeof d);
@@ -156,6 +163,7 @@ int main(int argc, char** argv) {
         d.a_layout = c.a_layout; d.b_layout = c.b_layout; d.batch = c.batch;
         d.stride_a = c.sa; d.stride_b = c.sb; d.stride_c = c.sc; d.stride_aux = c.saux; d.stride_bias = c.N;
         d.split_k = c.splitk; d.split_stride = c.split_stride; d.activation = c.act; d.epilogue = c.epi;
+        d.compute_type = c.bf16 ? PULSE_GEMM_COMPUTE_BF16 : PULSE_GEMM_COMPUTE_F32;
         for (int i = 0; i < warm; ++i)
             if (pulse_gemm_f32(&d, nullptr) != PULSE_OK) { fprintf(stderr, "%s: %s\n", c.name.c_str(), pulse_last_error()); exit(1); }
         CK(hipDeviceSynchronize());
@@ -200,7 +208,7 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 16; ++k) if (hist[k]) printf(" %dx%d", k, hist[k]);
                 printf("\n");
             }
-            const int ktiles = ((c.K + c.splitk - 1) / c.splitk + 31) / 32;
+            const int ktiles = c.bf16 ? ((c.K + c.splitk - 1) / c.splitk + 63) / 64 / 8 + 1 : ((c.K + c.splitk - 1) / c.splitk + 31) / 32;
             const double ghz = sum_all_c / (sum_all_w * 10.0);          // shader cycles per ns, sustained (last of the timed launches)
             const double ideal_cyc = (double)nwg * ktiles * 4096.0 / 256.0;   // MFMA-pipe cycles per SIMD if all 1024 SIMDs stay busy
             printf("    clocks: %d WGs, main %.0f cyc/WG (solo ideal %d), epilogue %.0f cyc (to LDS+barrier %.0f), sustained %.3f GHz, span %.1f us, pipe-cycle efficiency %.3f\n",

@@ -13,7 +13,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        key = "gemm_f32_kernel" if "gemm_f32_kernel" in k else ("other_pulse" if "pulse" in k else "torch")
+        key = ("gemm_f32_kernel" if "gemm_f32_kernel" in k else "gemm_bf16_kernel" if "gemm_bf16_kernel" in k
+               else ("other_pulse" if "pulse" in k else "torch"))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for key, cs in agg.items():
@@ -24,5 +25,9 @@ for key, cs in agg.items():
     write = 1024.0 * sum(w) / len(w)
     res[key] = {"launches_fetch_pass": len(f), "launches_write_pass": len(w), "fetch_bytes_per_launch": fetch,
                 "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
+    hit, miss = cs.get("TCC_HIT_sum", []), cs.get("TCC_MISS_sum", [])
+    if hit and miss:          # L2 hit rate (MI355X_MICROARCH.md, L2 section): the fabric-side FETCH_SIZE above counts L2 MISSES, Infinity-Cache hits included
+        res[key]["l2_hit_rate"] = sum(hit) / max(1.0, sum(hit) + sum(miss))
+        res[key]["l2_requests_per_launch"] = (sum(hit) + sum(miss)) / len(hit)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -47,7 +47,10 @@ class EpisodeMeter:
         return sum(r for r, _ in v) / max(1.0, sum(l for _, l in v))
 
 
-def run(iters, seed=7, device="cuda:0", window=None, log=print):
+def run(iters, seed=7, device="cuda:0", window=None, log=print, side="both"):
+    """side: 'both' trains the two agents in lockstep (short runs / tests); 'device' or 'oracle' trains one of them and returns its
+    episode stream -- the CPU oracle needs no GPU, so the long experiment runs its two halves on different machines and
+    ``merge`` compares them (seeds, noise and permutations are functions of (seed, epoch) only)."""
     from oracle import agent_oracle as AO
     from oracle import motion_oracle as MO
     from pulse_amd import configs
@@ -55,7 +58,10 @@ def run(iters, seed=7, device="cuda:0", window=None, log=print):
     cfg, num_envs = configs.agent_config("cfg1")
     T = cfg["horizon_length"]
     env_over = {"physics": "pd", "stateInit": "Start"}
-    agent, _ = configs.make_agent("cfg1", device=device, seed=seed, reference="motion_lib", env_overrides=env_over, permutation_device="cpu")
+    torch.set_num_threads(min(8, torch.get_num_threads()))       # the oracle's ops are tiny: a 128-thread pool only adds overhead
+    agent = None
+    if side in ("both", "device"):
+        agent, _ = configs.make_agent("cfg1", device=device, seed=seed, reference="motion_lib", env_overrides=env_over, permutation_device="cpu")
     torch.manual_seed(seed)
     oenv = MO.make_agent_env(num_envs, T, seed, physics="pd", state_init_start=True)
 
@@ -67,33 +73,45 @@ def run(iters, seed=7, device="cuda:0", window=None, log=print):
 
     def noise_cached(epoch, step):
         if cache.get("e") != epoch:
-            cache["e"], cache["z"] = epoch, noise(epoch)
-            cache["zd"] = cache["z"].to(device)
+            cache["e"], cache["z"], cache["zd"] = epoch, noise(epoch), None
         return cache["z"][step]
     oracle = AO.OracleCommonAgent(cfg, oenv, cfg["network"]["mlp"]["units"], seed=seed, noise=noise_cached)
-    agent.model.load_state_dict(oracle.model.state_dict_ref())
-    agent.noise_provider = lambda e, s: (noise_cached(e, s), cache["zd"][s])[1]
+    if agent is not None:
+        agent.model.load_state_dict(oracle.model.state_dict_ref())        # same initial weights (CPU draw, seed-determined)
+
+        def dev_noise(e, s):
+            if cache.get("e") != e or cache.get("zd") is None:
+                cache["e"], cache["z"] = e, noise(e)
+                cache["zd"] = cache["z"].to(device)
+            return cache["zd"][s]
+        agent.noise_provider = dev_noise
     m_dev, m_ref = EpisodeMeter(num_envs), EpisodeMeter(num_envs)
     t_dev = t_ref = 0.0
     first_diff = None
     for it in range(iters):
         t0 = time.time()
-        agent.train_epoch()
-        torch.cuda.synchronize()
+        if agent is not None:
+            agent.train_epoch()
+            torch.cuda.synchronize()
+            td = agent.experience_buffer.tensor_dict
+            m_dev.feed(it, td["rewards"], td["dones"])
         t1 = time.time()
-        oracle.train_epoch()
+        if side in ("both", "oracle"):
+            oracle.train_epoch()
+            rd = oracle.tensor_dict
+            m_ref.feed(it, rd["rewards"], rd["dones"])
         t2 = time.time()
         t_dev, t_ref = t_dev + (t1 - t0), t_ref + (t2 - t1)
-        td, rd = agent.experience_buffer.tensor_dict, oracle.tensor_dict
-        m_dev.feed(it, td["rewards"], td["dones"])
-        m_ref.feed(it, rd["rewards"], rd["dones"])
-        if first_diff is None and not torch.equal(td["dones"].cpu(), rd["dones"]):
+        if side == "both" and first_diff is None and not torch.equal(td["dones"].cpu(), rd["dones"]):
             first_diff = it
         if it % max(1, iters // 20) == 0 or it == iters - 1:
             a, na = m_dev.mean_return(max(0, it - window), it + 1)
             b, nb = m_ref.mean_return(max(0, it - window), it + 1)
-            log(f"[return_parity] iter {it}: device {a:.4f} ({na} eps)  oracle {b:.4f} ({nb} eps)  reward diff this epoch "
-                f"{float((td['rewards'].cpu() - rd['rewards']).abs().max()):.2e}")
+            log(f"[return_parity] iter {it}: device {a:.4f} ({na} eps)  oracle {b:.4f} ({nb} eps)  ({t_dev:.0f} s device, {t_ref:.0f} s oracle)")
+    if side != "both":
+        m = m_dev if side == "device" else m_ref
+        return {"side": side, "iterations": iters, "seed": seed, "finished": m.finished, "seconds": t_dev if side == "device" else t_ref,
+                "torch": torch.__version__}
     lo = iters - window
     a, na = m_dev.mean_return(lo, iters)
     b, nb = m_ref.mean_return(lo, iters)
@@ -108,14 +126,44 @@ def run(iters, seed=7, device="cuda:0", window=None, log=print):
             "seconds": {"device": t_dev, "oracle_cpu": t_ref}, "seed": seed}
 
 
+def merge(dev_path, ref_path, window=None):
+    """Compare the episode streams of a 'device' run and an 'oracle' run of the same (seed, iterations)."""
+    d, r = json.load(open(dev_path)), json.load(open(ref_path))
+    assert d["iterations"] == r["iterations"] and d["seed"] == r["seed"]
+    iters = d["iterations"]
+    window = window or max(1, iters // 5)
+    md, mr = EpisodeMeter(1), EpisodeMeter(1)
+    md.finished, mr.finished = [tuple(x) for x in d["finished"]], [tuple(x) for x in r["finished"]]
+    lo = iters - window
+    a, na = md.mean_return(lo, iters)
+    b, nb = mr.mean_return(lo, iters)
+    sa, sb = md.mean_step_reward(lo, iters), mr.mean_step_reward(lo, iters)
+    curve = []
+    for k in range(0, iters, max(1, iters // 10)):
+        curve.append({"epochs": [k, min(iters, k + max(1, iters // 10))], "device": md.mean_return(k, k + max(1, iters // 10))[0],
+                      "oracle": mr.mean_return(k, k + max(1, iters // 10))[0]})
+    return {"iterations": iters, "config": "cfg1 (64 envs x horizon 16, [512, 512]) on the PD physics stand-in, motion-library reference",
+            "window_epochs": window, "device_mean_episode_return": a, "oracle_mean_episode_return": b, "episodes_in_window": [na, nb],
+            "relative_difference": abs(a - b) / abs(b), "device_mean_step_reward": sa, "oracle_mean_step_reward": sb,
+            "relative_difference_step_reward": abs(sa - sb) / abs(sb), "learning_curve_mean_episode_return": curve,
+            "first_window": {"device": md.mean_return(0, window)[0], "oracle": mr.mean_return(0, window)[0]},
+            "seconds": {"device": d["seconds"], "oracle_cpu": r["seconds"]}, "seed": d["seed"],
+            "where": {"device": "MI355X (gpurun)", "oracle": f"build container CPU, torch {r['torch']}"}}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--side", default="both", choices=["both", "device", "oracle"])
+    ap.add_argument("--merge", nargs=2, default=None, metavar=("DEVICE_JSON", "ORACLE_JSON"))
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    res = run(a.iters, seed=a.seed)
-    print(json.dumps(res, indent=1))
+    if a.merge:
+        res = merge(*a.merge)
+    else:
+        res = run(a.iters, seed=a.seed, side=a.side, log=lambda m: print(m, flush=True))
+    print(json.dumps({k: v for k, v in res.items() if k != "finished"}, indent=1), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:

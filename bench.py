@@ -13,7 +13,8 @@ environments (weak scaling, envs shard with no data-path collective; the one exc
 step is the flat-gradient all-reduce).
 
 Prints ONE JSON line on rank 0.  ``roofline`` is measured live: every launch of the dominant
-kernel (gemm_f32_kernel, the fp32 MFMA GEMM) inside the LAST step of the timed region is bracketed by
+kernel (gemm_x3_kernel: the fp32 GEMM computed as six bf16 MFMAs per k step over an exact three-way operand split; or
+gemm_f32_kernel, the fp32 MFMA GEMM, with PULSE_GEMM_F32=mfma32) inside the LAST step of the timed region is bracketed by
 a HIP event pair on the launch stream; achieved = algorithmic FLOPs / summed kernel time.  ``cpu_baseline`` is
 the PyTorch-CPU oracle agent (oracle/agent_oracle.py, kind "port") timed on the host cores on a
 bounded sample of the same workload (rank 0, N=1 only).
@@ -30,6 +31,7 @@ if ROOT not in sys.path:
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+MFMA_X3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0   # fp32 GEMM as 6 bf16 MFMAs per algorithmic product group: its matrix-pipe ceiling
 
 
 def log(msg):
@@ -135,7 +137,7 @@ def gemm_traffic(cfg_name):
         try:
             with open(path) as f:
                 d = json.load(f)
-            for key in ("gemm_bf16_kernel", "gemm_f32_kernel") if cfg_name == "cfg5" else ("gemm_f32_kernel",):
+            for key in ("gemm_bf16_kernel", "gemm_x3_kernel", "gemm_f32_kernel") if cfg_name == "cfg5" else ("gemm_x3_kernel", "gemm_f32_kernel"):
                 if key in d:
                     return d[key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
@@ -266,6 +268,11 @@ def main():
                     "kernel_time_frac_of_step": t / (elapsed / a.steps), "instrumented_steps": 1,
                     "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in sel.items()}}
         r32 = roof(("fwd", "dx", "dw"), MFMA_F32_PEAK_TFLOPS, "gemm_f32_kernel")
+        if r32 is None:
+            r32 = roof(("x3_fwd", "x3_dx", "x3_dw"), MFMA_X3_PEAK_TFLOPS, "gemm_x3_kernel")
+            if r32 is not None:
+                r32["arithmetic"] = ("fp32 in / fp32 out; operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 per 16-deep k step, "
+                                     "fp32 accumulation; peak = dense bf16 MFMA peak / 6; the fp32 MFMA's own ceiling is %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS)
         r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")
         if r16 is not None:
             # mixed precision: the training GEMMs run on the bf16 MFMA (judged against its 2.5 PFLOP/s dense peak; with fp32 operand

@@ -413,6 +413,7 @@ int pulse_gae(const float* rewards, const float* values, const float* next_value
 
 #define PULSE_GEMM_COMPUTE_F32  0
 #define PULSE_GEMM_COMPUTE_BF16 1
+#define PULSE_GEMM_COMPUTE_F32X3 2
 
 typedef struct pulse_gemm_desc {
     const float* A; const float* B; float* C;
@@ -435,6 +436,10 @@ typedef struct pulse_gemm_desc {
     /* PULSE_GEMM_COMPUTE_BF16: operands (fp32 in memory) are rounded to bf16 on the way into LDS and multiplied on
        v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the arithmetic of a bf16 autocast Linear over fp32 master weights
        (phc/learning/amp_agent.py:671); with round_output_bf16 the outputs are rounded to bf16-representable values as well. */
+    /* PULSE_GEMM_COMPUTE_F32X3: an fp32 GEMM computed on the bf16 matrix pipe -- every fp32 operand is split EXACTLY into three
+       bf16 numbers (8 + 8 + 8 significand bits) on the way into LDS and the six products that matter at fp32 precision are
+       accumulated in fp32.  fp32-grade results (same tolerances as PULSE_GEMM_COMPUTE_F32, same exactness / linearity
+       properties) at up to 2.67x the fp32 MFMA rate of gfx950.  Inputs must be finite. */
     int32_t compute_type; int32_t round_output_bf16;
 } pulse_gemm_desc;
 

@@ -145,7 +145,7 @@ class PpoLossArgs(Structure):
 
 
 GEMM_RED_CONTIG, GEMM_OUT_CONTIG = 0, 1
-GEMM_COMPUTE_F32, GEMM_COMPUTE_BF16 = 0, 1
+GEMM_COMPUTE_F32, GEMM_COMPUTE_BF16, GEMM_COMPUTE_F32X3 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD = 0, 1, 2
 

@@ -751,6 +751,312 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs g) {
     gemm_epilogue(g, acc, tid, m0, n0, bz, sp, wm, wn, half, l31);
 }
 
+// =====================================================================================================================
+// fp32 GEMM on the bf16 matrix pipe ("x3": three-way operand split, six products).
+//
+// gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the VALU's rate, 1/16 of the bf16 MFMA.  An fp32 number is EXACTLY the sum
+// of three bf16 numbers (8 + 8 + 8 significand bits, truncation split: a1 = a & 0xffff0000, a2 = (a - a1) & 0xffff0000,
+// a3 = a - a1 - a2), every bf16 x bf16 product is exact in fp32, and the products that matter at fp32 precision are the six with
+// plane indices i + j <= 2 (the dropped ones are below 2^-25 of the leading product).  So C = sum_k a b is computed as six
+// v_mfma_f32_32x32x16_bf16 per 16-deep k step, all into the same fp32 accumulator: fp32-grade results (fewer accumulator roundings
+// per k than the fp32 MFMA's one per 2 k) at up to 16 / 6 = 2.67x the fp32 MFMA peak.  Inputs, outputs and storage are fp32; this is
+// an fp32 GEMM, not a reduced-precision one (tests: same fp64-referenced tolerances as the fp32 MFMA kernel; exactness,
+// linearity and tile-position-independence properties hold bit for bit).  Non-finite inputs give NaN (inf - inf in the split).
+//
+// Tile 128 x 128 x 16, 4 waves, each 2 x 2 MFMA tiles.  LDS image per operand and stage: 3 planes x [2 k-chunks of 8][136 slots][16 B]
+// (slot = out ^ ((out >> 3) & 7); 136 keeps the 2-lanes-per-row store pattern conflict-free), two stages.  Per thread and k-tile:
+// 8 elements of A and 8 of B are split (about 44 VALU each, spread over the first MFMAs of the tile), 6 ds_write_b128, 12
+// ds_read_b128 (next tile's fragments, second register set), 24 MFMAs.  Global loads: reduction-contiguous operands 2 x 16 B per
+// thread (two lanes per row), [red][out] operands 8 dwords per thread (lane = out: no register transpose).  The buffer resources
+// carry the true extent, so rows / k positions outside the operand read as zero in hardware: no address clamps, and the k tail needs
+// only a compare-and-zero in the tile that stages the last k-tile.
+// =====================================================================================================================
+constexpr int XK = 16;
+constexpr int X_CSTRIDE = 136;                       // 16-byte slots per 8-k chunk block
+constexpr int X_PLANE = 2 * X_CSTRIDE * 16;          // 4,352 B
+constexpr int X_IMG = 3 * X_PLANE;                   // 13,056 B per operand
+constexpr int X_STAGE = 2 * X_IMG;                   // 26,112 B
+constexpr int X_LDS = BM * CP * 4;                   // 65,536 B: the epilogue transpose (>= 2 stages = 52,224 B) -> two workgroups per CU
+
+__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float bitsf(unsigned v) { return __builtin_bit_cast(float, v); }
+// high halves of (lo_elem, hi_elem) packed as two bf16 (truncation): {hi_elem[31:16], lo_elem[31:16]}
+__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
+    return __builtin_amdgcn_perm(fbits(hi_elem), fbits(lo_elem), 0x07060302u);
+}
+
+template <bool KC>
+struct StagerX {
+    float v[2][8];       // two register sets (tile parity): loads run two tiles ahead of their split.  KC: two 16-byte loads; MC: 8 dwords
+    int voff;            // per-lane byte offset (constant); the k advance and MC's row advance are scalar offsets
+    int lds;
+    int kpos;
+    int ld4;             // MC: bytes per k row (wave-uniform)
+
+    __device__ __forceinline__ void init(int tid, int ld, int img_off) {
+        ld4 = ld * 4;
+        if constexpr (KC) {
+            const int row = tid >> 1, kc = tid & 1;
+            kpos = kc * 8;
+            voff = (row * ld + kc * 8) * 4;
+            lds = img_off + (kc * X_CSTRIDE + slot_of(row)) * 16;
+        } else {
+            const int out = tid & 127, kch = tid >> 7;
+            kpos = kch * 8;
+            voff = (kch * 8 * ld + out) * 4;
+            lds = img_off + (kch * X_CSTRIDE + slot_of(out)) * 16;
+        }
+    }
+    template <int S>
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff) {
+        if constexpr (KC) {
+            const f32x4 a = buf_load(rs, voff, soff), b = buf_load(rs, voff, soff + 16);
+            v[S][0] = a.x; v[S][1] = a.y; v[S][2] = a.z; v[S][3] = a.w; v[S][4] = b.x; v[S][5] = b.y; v[S][6] = b.z; v[S][7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[S][i] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + i * ld4, 0));
+        }
+    }
+    template <int S, bool MASKED>
+    __device__ __forceinline__ void mask(int hi) {
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (kpos + e >= hi) v[S][e] = 0.f;
+        }
+    }
+    template <int S>
+    __device__ __forceinline__ float sum8() const {
+        return ((v[S][0] + v[S][1]) + (v[S][2] + v[S][3])) + ((v[S][4] + v[S][5]) + (v[S][6] + v[S][7]));
+    }
+    // split element pair k (elements 2k, 2k+1) into the three planes' packed dwords
+    u32x4 p0, p1, p2;
+    template <int S>
+    __device__ __forceinline__ void split_pair(int k) {
+        const float a = v[S][2 * k], b = v[S][2 * k + 1];
+        p0[k] = pack_hi16(a, b);
+#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 1)
+        p1[k] = fbits(a); p2[k] = fbits(b); return;
+#endif
+        const float ra = a - bitsf(fbits(a) & 0xffff0000u), rb = b - bitsf(fbits(b) & 0xffff0000u);
+        p1[k] = pack_hi16(ra, rb);
+        const float sa = ra - bitsf(fbits(ra) & 0xffff0000u), sb = rb - bitsf(fbits(rb) & 0xffff0000u);
+        p2[k] = pack_hi16(sa, sb);
+    }
+    __device__ __forceinline__ void write(int st) {
+        extern __shared__ __attribute__((aligned(16))) char smem_c[];
+        *reinterpret_cast<u32x4*>(smem_c + st + lds) = p0;
+#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 2)
+        if (p1[0] == 0x12345678u && p2[1] == 0x9abcdef0u)
+#endif
+        {
+        *reinterpret_cast<u32x4*>(smem_c + st + lds + X_PLANE) = p1;
+        *reinterpret_cast<u32x4*>(smem_c + st + lds + 2 * X_PLANE) = p2;
+        }
+    }
+};
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_x3_kernel(const GemmArgs g) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q8 = ntile >> 3, rr = ntile & 7;
+    const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int bz = z / g.splitk, sp = z - bz * g.splitk;
+    const int kbeg = sp * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int klen = kend - kbeg;
+    const int nkt = (klen + XK - 1) / XK;
+    const int hi = klen - (nkt - 1) * XK;                       // valid k positions of the last tile (1 .. 16)
+
+    long long dbg_c0 = 0, dbg_w0 = 0, dbg_c1 = 0, dbg_w1 = 0;
+    if (g.dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
+
+    // buffer resources with the TRUE extent from this workgroup's origin: anything outside reads as zero (no memory access)
+    const int extA = min(BM, g.M - m0), extB = min(BN, g.N - n0);
+    const int k4rem = ((g.K + 3) & ~3) - kbeg;                   // readable k positions of a reduction-contiguous row from kbeg
+    const float* Ab = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
+    const float* Bb = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
+    const unsigned recA = (unsigned)(AKC ? ((extA - 1) * g.lda + k4rem) : ((klen - 1) * g.lda + extA)) * 4u;
+    const unsigned recB = (unsigned)(BKC ? ((extB - 1) * g.ldb + k4rem) : ((klen - 1) * g.ldb + extB)) * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, klen > 0 ? recA : 0u, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, klen > 0 ? recB : 0u, RSRC_FLAGS);
+    const int kstepA = (AKC ? 4 : g.lda * 4) * XK, kstepB = (BKC ? 4 : g.ldb * 4) * XK;      // bytes per k-tile
+
+    StagerX<AKC> sa;
+    StagerX<BKC> sb;
+    sa.init(tid, g.lda, 0);
+    sb.init(tid, g.ldb, X_IMG);
+
+    // fragment read addresses: lane (l31, half) reads out (wm|wn) * 64 + {0, 32} + l31, k-chunk = half, plane p at + p * X_PLANE
+    const int frA0 = (half * X_CSTRIDE + slot_of(wm * 64 + l31)) * 16;
+    const int frA1 = (half * X_CSTRIDE + slot_of(wm * 64 + 32 + l31)) * 16;
+    const int frB0 = X_IMG + (half * X_CSTRIDE + slot_of(wn * 64 + l31)) * 16;
+    const int frB1 = X_IMG + (half * X_CSTRIDE + slot_of(wn * 64 + 32 + l31)) * 16;
+
+    f32x16 acc[2][2];
+    {
+        float b0 = 0.f, b1 = 0.f;
+        if (g.epi == 0 && g.bias) {
+            const float* bias = g.bias + bz * g.sBias;
+            const int c0 = n0 + wn * 64 + l31;
+            if (c0 < g.N) b0 = bias[c0];
+            if (c0 + 32 < g.N) b1 = bias[c0 + 32];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
+    }
+    float rs_acc = 0.f;
+    const bool do_rs = !AKC && g.rowsum != nullptr && tn == 0;      // workgroup-uniform: the stager of A sums its k rows (bias gradient)
+
+    // Fragment registers: plane 0 in two sets (tile parity), planes 1 and 2 in ONE set that is refilled as soon as the tile's last
+    // MFMA reading it has issued.  Term order (A plane, B plane): (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)  =>  A2 is dead after MFMA 3,
+    // B2 after 7, A1 after 15, B1 after 19.
+    bf16x8 fa0[2][2], fb0[2][2], fa1[2], fb1[2], fa2[2], fb2[2];
+    // fragment read unit u (0..11) of the stage at byte offset st (plane 0 into set S), in the order the slots allow
+    auto frag_unit = [&](auto set_tag, int u, int st) {
+        constexpr int S = decltype(set_tag)::value;
+        extern __shared__ __attribute__((aligned(16))) char smem_c[];
+        auto rd = [&](int addr) { return *reinterpret_cast<const bf16x8*>(smem_c + st + addr); };
+        switch (u) {
+            case 0: fa2[0] = rd(frA0 + 2 * X_PLANE); break;
+            case 1: fa2[1] = rd(frA1 + 2 * X_PLANE); break;
+            case 2: fb0[S][0] = rd(frB0); break;
+            case 3: fb0[S][1] = rd(frB1); break;
+            case 4: fb2[0] = rd(frB0 + 2 * X_PLANE); break;
+            case 5: fb2[1] = rd(frB1 + 2 * X_PLANE); break;
+            case 6: fa0[S][0] = rd(frA0); break;
+            case 7: fa0[S][1] = rd(frA1); break;
+            case 8: fa1[0] = rd(frA0 + X_PLANE); break;
+            case 9: fa1[1] = rd(frA1 + X_PLANE); break;
+            case 10: fb1[0] = rd(frB0 + X_PLANE); break;
+            default: fb1[1] = rd(frB1 + X_PLANE); break;
+        }
+    };
+
+    // One k-tile = 24 MFMAs (6 plane pairs x 4 accumulator tiles; an accumulator is reused every 4th MFMA), one unit of side work
+    // after each:
+    //   slots 0-7    split of tile t+1: A pairs 0-3 (+ A's three ds_write_b128 in slot 4), B pairs 0-3 (its loads were issued TWO
+    //                tiles ago: a tile is only ~770 MFMA cycles per wave, far less than the memory latency)
+    //   slot  8      B's three ds_write_b128, then the ONE barrier of the tile
+    //   slot  9      global loads of tile t+3 into the register set tile t+1 just left
+    //   slots 10-21  next tile's 12 fragment reads: A2 B0' B2 A0' (slots 10-17), A1 (18, 19), B1 (20, 21)
+    // MODE 0 steady, 1 = stages the LAST tile (k tail zeroed, no further loads), 2 = last tile (compute only).
+    auto tile = [&](auto mode_tag, auto stage_tag, int t) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int S = decltype(stage_tag)::value;
+        constexpr int OTH = (1 - S) * X_STAGE;
+        using SetO = std::integral_constant<int, 1 - S>;
+        constexpr int O = 1 - S;                                  // register set / stage of tile t+1 (and t+3)
+        if constexpr (MODE != 2) {
+            sa.template mask<O, MODE == 1>(hi);
+            sb.template mask<O, MODE == 1>(hi);
+            if constexpr (!AKC) {
+                if (do_rs) rs_acc += sa.template sum8<O>();
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 24; ++p) {
+            const int term = p >> 2, i = (p >> 1) & 1, j = p & 1;
+            const bf16x8 a = term == 0 ? fa2[i] : (term == 2 || term == 3) ? fa1[i] : fa0[S][i];
+            const bf16x8 b = term == 1 ? fb2[j] : (term == 2 || term == 4) ? fb1[j] : fb0[S][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+            if constexpr (MODE != 2) {
+                if (p < 4) sa.template split_pair<O>(p);
+                else if (p < 8) sb.template split_pair<O>(p - 4);
+                if (p == 4) sa.write(OTH);
+                if (p == 8) {
+                    sb.write(OTH);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                }
+                if constexpr (MODE == 0) {
+#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 8)
+                    if (p == 9 && t + 3 < nkt && g.K == 12345) {
+#else
+                    if (p == 9 && t + 3 < nkt) {
+#endif
+                        sa.template load<O>(rsA, (t + 3) * kstepA); sb.template load<O>(rsB, (t + 3) * kstepB);
+                    }
+                }
+#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 4)
+                if (p >= 10 && p < 22 && g.K == 12345) frag_unit(SetO{}, p - 10, OTH);
+#else
+                if (p >= 10 && p < 22) frag_unit(SetO{}, p - 10, OTH);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+
+    if (nkt > 0) {
+        sa.template load<0>(rsA, 0); sb.template load<0>(rsB, 0);
+        if (nkt > 1) { sa.template load<1>(rsA, kstepA); sb.template load<1>(rsB, kstepB); }
+        if (nkt == 1) { sa.template mask<0, true>(hi); sb.template mask<0, true>(hi); }
+        if constexpr (!AKC) {
+            if (do_rs) rs_acc += sa.template sum8<0>();
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sa.template split_pair<0>(k); sb.template split_pair<0>(k); }
+        sa.write(0); sb.write(0);
+    }
+    __syncthreads();
+    if (nkt > 2) { sa.template load<0>(rsA, 2 * kstepA); sb.template load<0>(rsB, 2 * kstepB); }
+    if (nkt > 0) {
+#pragma unroll
+        for (int u = 0; u < 12; ++u) frag_unit(I0{}, u, 0);
+    }
+    {
+        int t = 0;
+        for (; t + 3 < nkt; t += 2) { tile(I0{}, I0{}, t); tile(I0{}, I1{}, t + 1); }
+        if (t + 2 < nkt) {
+            tile(I0{}, I0{}, t);
+            tile(I1{}, I1{}, t + 1);
+            tile(I2{}, I0{}, t + 2);
+        } else if (t + 2 == nkt) {
+            tile(I1{}, I0{}, t);
+            tile(I2{}, I1{}, t + 1);
+        } else if (t + 1 == nkt) {
+            tile(I2{}, I0{}, t);
+        }
+    }
+    __syncthreads();                                              // the epilogue (and the row-sum exchange) reuse the staging buffers
+    if constexpr (!AKC) {
+        if (do_rs) {
+            extern __shared__ __attribute__((aligned(16))) float smem[];
+            smem[tid] = rs_acc;                                   // thread (kch = tid >> 7, out = tid & 127) summed its 8 k rows of every tile
+            __syncthreads();
+            if (tid < 128 && m0 + tid < g.M) g.rowsum[bz * g.sRowsum + sp * g.sSplit + m0 + tid] = smem[tid] + smem[tid + 128];
+            __syncthreads();
+        }
+    }
+    if (g.dbg) { dbg_c1 = clock64(); dbg_w1 = wall_clock64(); }
+    struct DbgStamp {
+        const GemmArgs& g; long long c0, w0, c1, w1;
+        __device__ ~DbgStamp() {
+            if (g.dbg && threadIdx.x == 0) {
+                long long* o = g.dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+                o[0] = c0; o[1] = w0; o[2] = c1; o[3] = w1; o[4] = clock64(); o[5] = wall_clock64();
+                o[7] = ((long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            }
+        }
+    } dbg_stamp{g, dbg_c0, dbg_w0, dbg_c1, dbg_w1};
+    gemm_epilogue(g, acc, tid, m0, n0, bz, sp, wm, wn, half, l31);
+}
+
 // ---- deterministic reduction of split-K slabs (and of column-sum partials) ---------------------
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
                                                           long long count, float* __restrict__ out, float scale) {
@@ -865,7 +1171,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldc2 = d->ldc2; g.ldaux = d->ldaux;
     g.sA = d->stride_a; g.sB = d->stride_b; g.sC = d->stride_c; g.sC2 = d->stride_c2; g.sBias = d->stride_bias; g.sAux = d->stride_aux;
     g.batch = d->batch; g.splitk = d->split_k;
-    const int bk = d->compute_type == PULSE_GEMM_COMPUTE_BF16 ? BK16 : BK;
+    const int bk = d->compute_type == PULSE_GEMM_COMPUTE_BF16 ? BK16 : d->compute_type == PULSE_GEMM_COMPUTE_F32X3 ? XK : BK;
     int kchunk = (d->K + d->split_k - 1) / d->split_k;
     kchunk = ((kchunk + bk - 1) / bk) * bk;
     g.kchunk = kchunk > 0 ? kchunk : bk;
@@ -874,8 +1180,9 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     g.dbg = g_dbg;
-    PULSE_REQUIRE(d->compute_type == PULSE_GEMM_COMPUTE_F32 || d->compute_type == PULSE_GEMM_COMPUTE_BF16, "pulse_gemm_f32: bad compute_type");
-    const bool bf = d->compute_type == PULSE_GEMM_COMPUTE_BF16;
+    PULSE_REQUIRE(d->compute_type == PULSE_GEMM_COMPUTE_F32 || d->compute_type == PULSE_GEMM_COMPUTE_BF16 ||
+                  d->compute_type == PULSE_GEMM_COMPUTE_F32X3, "pulse_gemm_f32: bad compute_type");
+    const bool bf = d->compute_type == PULSE_GEMM_COMPUTE_BF16, x3 = d->compute_type == PULSE_GEMM_COMPUTE_F32X3;
     g.round_bf16 = bf && d->round_output_bf16 ? 1 : 0;
     // per-workgroup buffer offsets are 32-bit: tile-relative (128 rows) for reduction-contiguous operands, split-relative
     // (kchunk rows) for [red][out] operands
@@ -885,11 +1192,11 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     auto al16 = [](const void* p, long long ld, long long st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0 && (st % 4) == 0; };
     g.vec_epi = al16(d->C, d->ldc, d->stride_c) && (d->split_stride % 4) == 0 && (!d->aux || al16(d->aux, d->ldaux, d->stride_aux)) &&
                 (!d->C2 || al16(d->C2, d->ldc2, d->stride_c2)) && (!d->bias || al16(d->bias, 4, d->stride_bias));
-    const size_t lds = (size_t)LDS_BYTES + (size_t)g_opt[1];                  // 66,048 B -> two workgroups per CU
+    const size_t lds = (size_t)(x3 ? X_LDS : LDS_BYTES) + (size_t)g_opt[1];   // 65,536 / 66,048 B -> two workgroups per CU
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
     // The 64.5 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling
     // hipFuncSetAttribute on every launch serialises the host against the stream).
-    static size_t attr_done[6] = {0, 0, 0, 0, 0, 0};
+    static size_t attr_done[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipError_t e = hipSuccess;
 #define LAUNCH(IDX, AK, BK_)                                                                                       \
     if (attr_done[IDX] != lds) {                                                                                      \
@@ -907,7 +1214,19 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
         attr_done[IDX] = lds;                                                                                     \
     }                                                                                                             \
     hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
-    if (bf) {
+#define LAUNCHX(IDX, AK, BK_)                                                                                      \
+    if (attr_done[IDX] != lds) {                                                                                  \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<AK, BK_>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_f32: LDS attribute: %s", hipGetErrorString(e)); \
+        attr_done[IDX] = lds;                                                                                     \
+    }                                                                                                             \
+    hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
+    if (x3) {
+        if (akc && bkc) { LAUNCHX(6, true, true); }
+        else if (akc && !bkc) { LAUNCHX(7, true, false); }
+        else { LAUNCHX(8, false, false); }
+    } else if (bf) {
         if (akc && bkc) { LAUNCH16(3, true, true); }
         else if (akc && !bkc) { LAUNCH16(4, true, false); }
         else { LAUNCH16(5, false, false); }
@@ -916,6 +1235,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     else { LAUNCH(2, false, false); }
 #undef LAUNCH
 #undef LAUNCH16
+#undef LAUNCHX
     return check_launch("pulse_gemm_f32");
 }
 

@@ -3,6 +3,7 @@
 Same rules as ``ops.py``: GPU tensors only, enqueue on torch's current stream, no fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -64,12 +65,20 @@ class GemmProfiler:
 
 PROFILER = GemmProfiler()
 
+# How an fp32 GEMM is computed (inputs / outputs / storage are fp32 either way):
+#   "x3"      three-way bf16 operand split, six bf16 MFMAs per k step, fp32 accumulation (PULSE_GEMM_COMPUTE_F32X3): fp32-grade
+#             results on the bf16 matrix pipe, the fast path on gfx950
+#   "mfma32"  v_mfma_f32_32x32x2_f32 (PULSE_GEMM_COMPUTE_F32)
+F32_MODE = os.environ.get("PULSE_GEMM_F32", "x3")
+if F32_MODE not in ("x3", "mfma32"):
+    raise ValueError(f"PULSE_GEMM_F32 must be 'x3' or 'mfma32', not {F32_MODE!r}")
+
 
 def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, bias=None,
                    activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
                    stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
                    a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None, rowsum=None, rowsum_off=0,
-                   stride_rowsum=0, compute_bf16=False):
+                   stride_rowsum=0, compute_bf16=False, f32_mode=None):
     """Build (descriptor, algorithmic FLOPs, variant tag) once; launch many times with launch_gemm."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -87,11 +96,14 @@ def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG,
     d.rowsum = (rowsum.data_ptr() + 4 * rowsum_off) if rowsum is not None else None
     d.stride_rowsum = stride_rowsum
     # bf16 MFMA with fp32 storage (bf16 autocast over fp32 master weights); split-K slabs are partial sums and stay unrounded
-    d.compute_type = _lib.GEMM_COMPUTE_BF16 if compute_bf16 else _lib.GEMM_COMPUTE_F32
+    x3 = (not compute_bf16) and (f32_mode or F32_MODE) == "x3"
+    d.compute_type = _lib.GEMM_COMPUTE_BF16 if compute_bf16 else (_lib.GEMM_COMPUTE_F32X3 if x3 else _lib.GEMM_COMPUTE_F32)
     d.round_output_bf16 = 1 if (compute_bf16 and split_k == 1) else 0
     tag = ("fwd" if b_layout == GEMM_RED_CONTIG else "dx") if a_layout == GEMM_RED_CONTIG else "dw"
     if compute_bf16:
         tag = "bf16_" + tag
+    elif x3:
+        tag = "x3_" + tag
     flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
     return d, flops, tag
 

@@ -16,6 +16,13 @@ from pulse_amd._lib import (ACT_NONE, ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SIL
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["x3", "mfma32"])
+def f32_mode(request, monkeypatch):
+    """Every GEMM test runs on both fp32 paths: the three-way bf16 split on the bf16 MFMA (default) and the fp32 MFMA."""
+    monkeypatch.setattr(K, "F32_MODE", request.param)
+    return request.param
+
+
 def rnd(g, *shape):
     return torch.randn(*shape, generator=g, dtype=torch.float32)
 
@@ -37,7 +44,7 @@ def assert_close64(out, ref64, k):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("m,n,k", [(1, 1, 1), (5, 3, 4), (130, 70, 33), (300, 200, 100), (257, 69, 512), (4096, 1, 512), (1024, 512, 934)])
 @pytest.mark.parametrize("act", [ACT_NONE, ACT_RELU, ACT_SILU])
-def test_gemm_forward(dev, m, n, k, act):
+def test_gemm_forward(f32_mode, dev, m, n, k, act):
     g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
     x, w, b = rnd(g, m, k), rnd(g, n, k) / math.sqrt(k), rnd(g, n)
     kp = (k + 3) // 4 * 4 + 4
@@ -53,7 +60,7 @@ def test_gemm_forward(dev, m, n, k, act):
         assert_close64(pre[:, :n], z, k)
 
 
-def test_gemm_transpose_detecting(dev):
+def test_gemm_transpose_detecting(f32_mode, dev):
     """A = I with an asymmetric B: catches row/col swaps in the MFMA C/D mapping."""
     n = 192
     b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 100.0
@@ -63,7 +70,7 @@ def test_gemm_transpose_detecting(dev):
     assert torch.equal(out.cpu(), b.T.contiguous())                         # exact: one non-zero product per sum
 
 
-def test_gemm_batched_shared_input(dev):
+def test_gemm_batched_shared_input(f32_mode, dev):
     """Two problems in one launch via pointer strides (actor / critic layer pairs)."""
     g = torch.Generator().manual_seed(3)
     m, k, n = 333, 96, 80
@@ -80,7 +87,7 @@ def test_gemm_batched_shared_input(dev):
 
 @pytest.mark.parametrize("m,n,k", [(200, 100, 70), (513, 512, 69), (1000, 512, 1), (2048, 1024, 512)])
 @pytest.mark.parametrize("epi", [EPI_RELU_GRAD, EPI_SILU_GRAD])
-def test_gemm_dx(dev, m, n, k, epi):
+def test_gemm_dx(f32_mode, dev, m, n, k, epi):
     """dX = (dY W) * act'(aux): A reduction-contiguous, B stored [red][out]."""
     g = torch.Generator().manual_seed(n + k)
     dy, w, aux = rnd(g, m, k), rnd(g, k, n) / math.sqrt(k), rnd(g, m, n)
@@ -98,7 +105,7 @@ def test_gemm_dx(dev, m, n, k, epi):
 
 
 @pytest.mark.parametrize("m,n,k,split", [(69, 512, 1000, 4), (512, 1024, 4096, 8), (1, 512, 777, 3), (1024, 960, 16384, 16)])
-def test_gemm_dw_split_k(dev, m, n, k, split):
+def test_gemm_dw_split_k(f32_mode, dev, m, n, k, split):
     """dW = dY^T X with the batch (reduction) dimension split into slabs + deterministic reduce."""
     g = torch.Generator().manual_seed(k)
     dy, x = rnd(g, k, m), rnd(g, k, n)
@@ -120,7 +127,7 @@ def test_gemm_dw_split_k(dev, m, n, k, split):
     assert torch.equal(out, out2)
 
 
-def test_gemm_linearity_full_size(dev):
+def test_gemm_linearity_full_size(f32_mode, dev):
     """Config-2 layer-1 shape (16384 x 2048 x 960): f(a x) == a f(x), and rows are independent."""
     g = torch.Generator().manual_seed(0)
     m, n, k = 16384, 2048, 960
@@ -392,7 +399,7 @@ def test_rollout_record_matches_reference_sequence(dev):
 
 
 @pytest.mark.parametrize("m_out,n_out,k_red,split,batch", [(200, 130, 1000, 1, 1), (70, 512, 4096, 8, 2), (1024, 70, 5000, 4, 1)])
-def test_gemm_rowsum_is_the_bias_gradient(dev, m_out, n_out, k_red, split, batch):
+def test_gemm_rowsum_is_the_bias_gradient(f32_mode, dev, m_out, n_out, k_red, split, batch):
     """dW pass with pulse_gemm_desc.rowsum: slab sums of the A operand's columns == dY.sum(0) (bias gradient)."""
     torch.manual_seed(m_out + k_red)
     lda, ldb = batch * ((m_out + 3) // 4 * 4), batch * ((n_out + 3) // 4 * 4)

@@ -48,14 +48,14 @@ __global__ void check_kernel(const float* A, const float* B, const float* C, con
     int m = (h >> 4) % c.M; h = h * 1664525u + 1013904223u;
     int n = (h >> 4) % c.N;
     const float* a = A + z * c.sa; const float* b = B + z * c.sb;
-    float acc = 0.f;
+    double acc = 0.0;
     for (int k = 0; k < c.K; ++k) {
         float av = c.a_layout == PULSE_GEMM_RED_CONTIG ? a[(long long)m * c.lda + k] : a[(long long)k * c.lda + m];
         float bv = c.b_layout == PULSE_GEMM_RED_CONTIG ? b[(long long)n * c.ldb + k] : b[(long long)k * c.ldb + n];
-        if (c.bf16) { av = (float)(__bf16)av; bv = (float)(__bf16)bv; }
-        acc = fmaf(av, bv, acc);
+        if (c.bf16 == 1) { av = (float)(__bf16)av; bv = (float)(__bf16)bv; }
+        acc += (double)av * (double)bv;
     }
-    float ref = acc;
+    float ref = (float)acc;
     if (c.splitk == 1) {
         if (c.epi == 0) { if (c.bias) ref += bias[z * c.N + n]; if (c.act == 1) ref = fmaxf(ref, 0.f); }
         else if (c.epi == 1) ref = aux[z * c.saux + (long long)m * c.ldaux + n] > 0.f ? ref : 0.f;
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     int iters = 20, warm = 3;
     std::string only;
     std::vector<std::pair<int, int>> opts;
-    bool sweep = false, clocks = false, bf16_cases = false;
+    bool sweep = false, clocks = false, bf16_cases = false, x3_cases = false;
     std::vector<std::vector<int>> custom;      // --fwd M N K lda ldb ldc
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--sweep")) sweep = true;
         else if (!strcmp(argv[i], "--clocks")) clocks = true;
         else if (!strcmp(argv[i], "--bf16")) bf16_cases = true;
+        else if (!strcmp(argv[i], "--x3")) x3_cases = true;
         else if (!strcmp(argv[i], "--fwd")) { std::vector<int> v; for (int j = 0; j < 6; ++j) v.push_back(atoi(argv[++i])); custom.push_back(v); }
     }
     for (auto& o : opts) pulse_gemm_set_option(o.first, o.second);
@@ -142,9 +143,13 @@ int main(int argc, char** argv) {
             add(nm, 16384, 2048, K, 4096, 4096, 2048, R, R, 1, 0, 0, 0, 1, 0, 1, 0, true, 0, 0, 0, 0);
         }
 
+    if (x3_cases) {
+        const size_t n0 = cases.size();
+        for (size_t i = 0; i < n0; ++i) { Case c = cases[i]; c.bf16 = 2; c.name = "x3   " + c.name; cases.push_back(c); }
+    }
     if (bf16_cases) {
         const size_t n0 = cases.size();
-        for (size_t i = 0; i < n0; ++i) { Case c = cases[i]; c.bf16 = 1; c.name = "bf16 " + c.name; cases.push_back(c); }
+        for (size_t i = 0; i < n0; ++i) { Case c = cases[i]; if (c.bf16) continue; c.bf16 = 1; c.name = "bf16 " + c.name; cases.push_back(c); }
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     {   // DVFS ramp: the chip needs sustained load before its clock settles; measured cases right after idle run ~10 % slow
@@ -163,7 +168,7 @@ int main(int argc, char** argv) {
         d.a_layout = c.a_layout; d.b_layout = c.b_layout; d.batch = c.batch;
         d.stride_a = c.sa; d.stride_b = c.sb; d.stride_c = c.sc; d.stride_aux = c.saux; d.stride_bias = c.N;
         d.split_k = c.splitk; d.split_stride = c.split_stride; d.activation = c.act; d.epilogue = c.epi;
-        d.compute_type = c.bf16 ? PULSE_GEMM_COMPUTE_BF16 : PULSE_GEMM_COMPUTE_F32;
+        d.compute_type = c.bf16 == 2 ? PULSE_GEMM_COMPUTE_F32X3 : c.bf16 ? PULSE_GEMM_COMPUTE_BF16 : PULSE_GEMM_COMPUTE_F32;
         for (int i = 0; i < warm; ++i)
             if (pulse_gemm_f32(&d, nullptr) != PULSE_OK) { fprintf(stderr, "%s: %s\n", c.name.c_str(), pulse_last_error()); exit(1); }
         CK(hipDeviceSynchronize());
@@ -208,14 +213,16 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 16; ++k) if (hist[k]) printf(" %dx%d", k, hist[k]);
                 printf("\n");
             }
-            const int ktiles = c.bf16 ? ((c.K + c.splitk - 1) / c.splitk + 63) / 64 / 8 + 1 : ((c.K + c.splitk - 1) / c.splitk + 31) / 32;
+            const int kc = (c.K + c.splitk - 1) / c.splitk;
+            const int cyc_tile = c.bf16 == 2 ? 768 : c.bf16 ? 512 : 4096;      // MFMA-pipe cycles per wave and k-tile
+            const int ktiles = c.bf16 == 2 ? (kc + 15) / 16 : c.bf16 ? (kc + 63) / 64 : (kc + 31) / 32;
             const double ghz = sum_all_c / (sum_all_w * 10.0);          // shader cycles per ns, sustained (last of the timed launches)
-            const double ideal_cyc = (double)nwg * ktiles * 4096.0 / 256.0;   // MFMA-pipe cycles per SIMD if all 1024 SIMDs stay busy
+            const double ideal_cyc = (double)nwg * ktiles * (double)cyc_tile / 256.0;   // MFMA-pipe cycles per SIMD if all 1024 SIMDs stay busy
             printf("    clocks: %d WGs, main %.0f cyc/WG (solo ideal %d), epilogue %.0f cyc (to LDS+barrier %.0f), sustained %.3f GHz, span %.1f us, pipe-cycle efficiency %.3f\n",
-                   nwg, sum_main_c / nwg, ktiles * 4096, sum_epi_c / nwg, sum_epi1 / nwg, ghz, (wmax - wmin) * 0.01, ideal_cyc / (t * 1e9 * ghz));
+                   nwg, sum_main_c / nwg, ktiles * cyc_tile, sum_epi_c / nwg, sum_epi1 / nwg, ghz, (wmax - wmin) * 0.01, ideal_cyc / (t * 1e9 * ghz));
         }
         printf("%-36s %9.1f us %7.1f TF/s  (exec %7.1f)  maxrelerr %.2e%s\n", c.name.c_str(), t * 1e6, c.algo_flops / t / 1e12,
-               2.0 * c.M * c.N * c.K * c.batch / t / 1e12, err, err > 2e-3 ? "  <-- MISMATCH" : "");
+               2.0 * c.M * c.N * c.K * c.batch / t / 1e12, err, err > (c.bf16 == 1 ? 2e-2 : 2e-4) ? "  <-- MISMATCH" : "");
         fflush(stdout);
         if (c.name.rfind("upd", 0) == 0) { tot_flops += c.algo_flops; tot_time += t; }
     }

@@ -628,10 +628,11 @@ def _amp_calc_gradients_tail(model, optimizer, d, cfg, obs_proc, amp_obs, amp_re
             "disc_loss": disc_loss.detach(), "disc_grad_penalty": penalty.detach(), "grad_norm": gn}
 
 
-def oracle_pnn_teacher_action(pnn_model, composer_model, num_prim, activation, obs, running_mean, running_var):
+def oracle_pnn_teacher_action(pnn_model, composer_model, num_prim, activation, obs, running_mean, running_var, has_lateral=False):
     """HumanoidImDistill.step's gt_action (phc/env/tasks/humanoid_im_distill.py:165-198, has_pnn branch, same obs settings for teacher
-    and student) over load_pnn / load_mcp_mlp-shaped state dicts (phc/learning/network_loader.py:11-73; PNN without lateral links,
-    phc/learning/pnn.py:125-131)."""
+    and student) over load_pnn / load_mcp_mlp-shaped state dicts (phc/learning/network_loader.py:11-73; PNN forward
+    phc/learning/pnn.py:84-131: without lateral links :125-131, with them :90-123 -- column c's second layer adds the bias-free
+    ``u[c-1][j][0]`` images of every earlier column's first activation before its own activation; ``u[..][1]`` is unused, :104)."""
     act = {"relu": nn.ReLU, "silu": nn.SiLU}[activation]
 
     def seq(model, prefix, trailing_act):
@@ -649,6 +650,18 @@ def oracle_pnn_teacher_action(pnn_model, composer_model, num_prim, activation, o
 
     with torch.no_grad():
         full_obs = torch.clamp((obs - running_mean.float()) / torch.sqrt(running_var.float() + 1e-05), min=-5.0, max=5.0)
-        x_all = torch.stack([seq(pnn_model, f"a2c_network.pnn.actors.{k}", False)(full_obs) for k in range(num_prim)], dim=1)
+        if has_lateral:
+            cols, h1s = [], []
+            for c in range(num_prim):
+                net = seq(pnn_model, f"a2c_network.pnn.actors.{c}", False)
+                assert len(net) == 5
+                h1 = net[:2](full_obs)
+                lat = [torch.nn.functional.linear(h1s[j], pnn_model[f"a2c_network.pnn.u.{c - 1}.{j}.0.weight"]) for j in range(len(h1s))]
+                h2 = net[3](net[2](h1) + sum(lat))
+                cols.append(net[4](h2))
+                h1s.append(h1)
+            x_all = torch.stack(cols, dim=1)
+        else:
+            x_all = torch.stack([seq(pnn_model, f"a2c_network.pnn.actors.{k}", False)(full_obs) for k in range(num_prim)], dim=1)
         weights = seq(composer_model, "a2c_network.composer", True)(full_obs)
         return torch.sum(weights[:, :, None] * x_all, dim=1)

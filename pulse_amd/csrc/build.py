@@ -33,7 +33,7 @@ SOURCES = [
     ("gae.hip", NO_CONTRACT),
     # MFMA accumulators in VGPR form: no v_accvgpr moves (VALU slots are what the fp32 MFMA loop is short of) and the
     # whole kernel fits the 256-register budget of two waves per SIMD
-    ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
+    ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]),   # packed-f32 VALU (v_pk_add_f32) beside MFMAs costs more than two plain adds
     ("learner_ops.hip", NO_CONTRACT),
 ]
 

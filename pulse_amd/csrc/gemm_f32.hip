@@ -754,14 +754,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs g) {
 // =====================================================================================================================
 // fp32 GEMM on the bf16 matrix pipe ("x3": three-way operand split, six products).
 //
-// gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the VALU's rate, 1/16 of the bf16 MFMA.  An fp32 number is EXACTLY the sum
-// of three bf16 numbers (8 + 8 + 8 significand bits, truncation split: a1 = a & 0xffff0000, a2 = (a - a1) & 0xffff0000,
-// a3 = a - a1 - a2), every bf16 x bf16 product is exact in fp32, and the products that matter at fp32 precision are the six with
-// plane indices i + j <= 2 (the dropped ones are below 2^-25 of the leading product).  So C = sum_k a b is computed as six
-// v_mfma_f32_32x32x16_bf16 per 16-deep k step, all into the same fp32 accumulator: fp32-grade results (fewer accumulator roundings
-// per k than the fp32 MFMA's one per 2 k) at up to 16 / 6 = 2.67x the fp32 MFMA peak.  Inputs, outputs and storage are fp32; this is
-// an fp32 GEMM, not a reduced-precision one (tests: same fp64-referenced tolerances as the fp32 MFMA kernel; exactness,
-// linearity and tile-position-independence properties hold bit for bit).  Non-finite inputs give NaN (inf - inf in the split).
+// gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the VALU's rate, 1/16 of the bf16 MFMA.  An fp32 number is the sum of three
+// bf16 numbers to within 2^-27 of itself (8 + 8 + 8 significand bits: a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2), round
+// to nearest even, the remainders exact; |a2| <= 2^-9 |a|, |a3| <= 2^-18 |a|), every bf16 x bf16 product is exact in fp32, and the
+// products that matter at fp32 precision are the six with plane indices i + j <= 2: the dropped ones are below 2^-26 of the product,
+// a quarter of an fp32 ulp.  So C = sum_k a b is computed as six v_mfma_f32_32x32x16_bf16 per 16-deep k step, all into the same fp32
+// accumulator: fp32-grade results (fewer accumulator roundings per k than the fp32 MFMA's one per 2 k) at up to 16 / 6 = 2.67x the
+// fp32 MFMA's matrix-pipe ceiling.  Inputs, outputs and storage are fp32; this is an fp32 GEMM, not a reduced-precision one (tests:
+// same fp64-referenced tolerances as the fp32 MFMA kernel; the exactness, linearity and tile-position-independence properties hold bit
+// for bit).  Non-finite inputs give NaN (inf - inf in the split).
 //
 // Tile 128 x 128 x 16, 4 waves, each 2 x 2 MFMA tiles.  LDS image per operand and stage: 3 planes x [2 k-chunks of 8][136 slots][16 B]
 // (slot = out ^ ((out >> 3) & 7); 136 keeps the 2-lanes-per-row store pattern conflict-free), two stages.  Per thread and k-tile:
@@ -776,13 +777,16 @@ constexpr int X_CSTRIDE = 136;                       // 16-byte slots per 8-k ch
 constexpr int X_PLANE = 2 * X_CSTRIDE * 16;          // 4,352 B
 constexpr int X_IMG = 3 * X_PLANE;                   // 13,056 B per operand
 constexpr int X_STAGE = 2 * X_IMG;                   // 26,112 B
+#ifndef X3_BARRIER_GAP
+#define X3_BARRIER_GAP 13
+#endif
 constexpr int X_LDS = BM * CP * 4;                   // 65,536 B: the epilogue transpose (>= 2 stages = 52,224 B) -> two workgroups per CU
 
 __device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ float bitsf(unsigned v) { return __builtin_bit_cast(float, v); }
-// high halves of (lo_elem, hi_elem) packed as two bf16 (truncation): {hi_elem[31:16], lo_elem[31:16]}
-__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
-    return __builtin_amdgcn_perm(fbits(hi_elem), fbits(lo_elem), 0x07060302u);
+// (lo_elem, hi_elem) rounded to nearest-even bf16 and packed {hi, lo}: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_rn(float lo_elem, float hi_elem) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo_elem, hi_elem}, bf16x2));
 }
 
 template <bool KC>
@@ -829,31 +833,31 @@ struct StagerX {
     __device__ __forceinline__ float sum8() const {
         return ((v[S][0] + v[S][1]) + (v[S][2] + v[S][3])) + ((v[S][4] + v[S][5]) + (v[S][6] + v[S][7]));
     }
-    // split element pair k (elements 2k, 2k+1) into the three planes' packed dwords
+    // split element pair k (elements 2k, 2k+1) into the three planes' packed dwords: round-to-nearest-even at every level
+    // (v_cvt_pk_bf16_f32), remainders exact (the difference of a float and its 8-bit rounding is representable)
     u32x4 p0, p1, p2;
     template <int S>
     __device__ __forceinline__ void split_pair(int k) {
         const float a = v[S][2 * k], b = v[S][2 * k + 1];
-        p0[k] = pack_hi16(a, b);
+        const unsigned q0 = pack_rn(a, b);
+        p0[k] = q0;
 #if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 1)
         p1[k] = fbits(a); p2[k] = fbits(b); return;
 #endif
-        const float ra = a - bitsf(fbits(a) & 0xffff0000u), rb = b - bitsf(fbits(b) & 0xffff0000u);
-        p1[k] = pack_hi16(ra, rb);
-        const float sa = ra - bitsf(fbits(ra) & 0xffff0000u), sb = rb - bitsf(fbits(rb) & 0xffff0000u);
-        p2[k] = pack_hi16(sa, sb);
+        const float ra = a - bitsf(q0 << 16), rb = b - bitsf(q0 & 0xffff0000u);
+        const unsigned q1 = pack_rn(ra, rb);
+        p1[k] = q1;
+        const float sa = ra - bitsf(q1 << 16), sb = rb - bitsf(q1 & 0xffff0000u);
+        p2[k] = pack_rn(sa, sb);
     }
-    __device__ __forceinline__ void write(int st) {
+    __device__ __forceinline__ void write_plane(int st, int pl) {
         extern __shared__ __attribute__((aligned(16))) char smem_c[];
-        *reinterpret_cast<u32x4*>(smem_c + st + lds) = p0;
 #if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 2)
-        if (p1[0] == 0x12345678u && p2[1] == 0x9abcdef0u)
+        if (pl > 0 && !(p1[0] == 0x12345678u && p2[1] == 0x9abcdef0u)) return;
 #endif
-        {
-        *reinterpret_cast<u32x4*>(smem_c + st + lds + X_PLANE) = p1;
-        *reinterpret_cast<u32x4*>(smem_c + st + lds + 2 * X_PLANE) = p2;
-        }
+        *reinterpret_cast<u32x4*>(smem_c + st + lds + pl * X_PLANE) = pl == 0 ? p0 : pl == 1 ? p1 : p2;
     }
+    __device__ __forceinline__ void write(int st) { write_plane(st, 0); write_plane(st, 1); write_plane(st, 2); }
 };
 
 template <bool AKC, bool BKC>
@@ -948,11 +952,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     // One k-tile = 24 MFMAs (6 plane pairs x 4 accumulator tiles; an accumulator is reused every 4th MFMA), one unit of side work
     // after each:
-    //   slots 0-7    split of tile t+1: A pairs 0-3 (+ A's three ds_write_b128 in slot 4), B pairs 0-3 (its loads were issued TWO
-    //                tiles ago: a tile is only ~770 MFMA cycles per wave, far less than the memory latency)
-    //   slot  8      B's three ds_write_b128, then the ONE barrier of the tile
-    //   slot  9      global loads of tile t+3 into the register set tile t+1 just left
-    //   slots 10-21  next tile's 12 fragment reads: A2 B0' B2 A0' (slots 10-17), A1 (18, 19), B1 (20, 21)
+    //   slots 0-7    split of tile t+1: A pairs 0-3, B pairs 0-3 (its loads were issued TWO tiles ago: a tile is only ~770 MFMA
+    //                cycles per wave, far less than the memory latency)
+    //   slots 4-6, 8-10   A's / B's three ds_write_b128, one per slot
+    //   slot 11      global loads of tile t+3 into the register set tile t+1 just left
+    //   slot 13      the ONE barrier of the tile (its lgkmcnt wait falls three MFMAs after the last store)
+    //   slots 14-17  next tile's fragment reads A2 B0' B2 A0' (two per slot), slot 20: A1 (dead after MFMA 15), slot 22: B1 (after 19)
     // MODE 0 steady, 1 = stages the LAST tile (k tail zeroed, no further loads), 2 = last tile (compute only).
     auto tile = [&](auto mode_tag, auto stage_tag, int t) {
         constexpr int MODE = decltype(mode_tag)::value;
@@ -976,26 +981,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             if constexpr (MODE != 2) {
                 if (p < 4) sa.template split_pair<O>(p);
                 else if (p < 8) sb.template split_pair<O>(p - 4);
-                if (p == 4) sa.write(OTH);
-                if (p == 8) {
-                    sb.write(OTH);
-                    __builtin_amdgcn_sched_barrier(0);
-                    __syncthreads();
-                }
+                if (p >= 4 && p < 7) sa.write_plane(OTH, p - 4);          // one 16-byte store per gap: the store path takes ~13 cycles each
+                if (p >= 8 && p < 11) sb.write_plane(OTH, p - 8);
                 if constexpr (MODE == 0) {
 #if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 8)
-                    if (p == 9 && t + 3 < nkt && g.K == 12345) {
+                    if (p == 11 && t + 3 < nkt && g.K == 12345) {
 #else
-                    if (p == 9 && t + 3 < nkt) {
+                    if (p == 11 && t + 3 < nkt) {
 #endif
                         sa.template load<O>(rsA, (t + 3) * kstepA); sb.template load<O>(rsB, (t + 3) * kstepB);
                     }
                 }
+                if (p == X3_BARRIER_GAP) {                                // a few MFMAs after the last store: its lgkmcnt wait is short
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                }
 #if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 4)
-                if (p >= 10 && p < 22 && g.K == 12345) frag_unit(SetO{}, p - 10, OTH);
-#else
-                if (p >= 10 && p < 22) frag_unit(SetO{}, p - 10, OTH);
+                if (g.K == 12345)
 #endif
+                {
+                    // 12 fragment reads in the gaps after the barrier; A1 may be refilled after MFMA 15, B1 after MFMA 19
+                    constexpr int R0 = X3_BARRIER_GAP + 1;
+                    if (p == R0) { frag_unit(SetO{}, 0, OTH); frag_unit(SetO{}, 1, OTH); }
+                    else if (p == R0 + 1) { frag_unit(SetO{}, 2, OTH); frag_unit(SetO{}, 3, OTH); }
+                    else if (p == R0 + 2) { frag_unit(SetO{}, 4, OTH); frag_unit(SetO{}, 5, OTH); }
+                    else if (p == R0 + 3) { frag_unit(SetO{}, 6, OTH); frag_unit(SetO{}, 7, OTH); }
+                    if (p == 20) { frag_unit(SetO{}, 8, OTH); frag_unit(SetO{}, 9, OTH); }
+                    if (p == 22) { frag_unit(SetO{}, 10, OTH); frag_unit(SetO{}, 11, OTH); }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -491,6 +491,10 @@ class VecTaskPythonWrapper:
         self.obs_space = Box(-float("inf"), float("inf"), (self.num_obs,))
         self.act_space = Box(-1.0, 1.0, (self.num_actions,))
         self.rl_device = rl_device
+        # The reference returns a FRESH tensor every step (torch.clamp(obs_buf, ...), vec_task.py:152-157), so a caller may keep
+        # it across steps.  pulse_amd's own agents copy the observation into the experience buffer before the next step and opt
+        # into the aliased buffer (saves a 16 MB copy per step at 4096 envs); any other caller gets the reference's semantics.
+        self.alias_obs = False
 
     def step(self, actions):
         actions_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)
@@ -498,6 +502,8 @@ class VecTaskPythonWrapper:
         obs = self.task.obs_buf
         if self.clip_obs != float("inf"):
             obs = torch.clamp(obs, -self.clip_obs, self.clip_obs)
+        elif not self.alias_obs:
+            obs = obs.clone()
         return obs, self.task.rew_buf, self.task.reset_buf, self.task.extras
 
     def reset(self, env_ids=None):

@@ -185,6 +185,7 @@ class CommonAgent:
     # ------------------------------------------------------------------ init_tensors (common_agent.py:92-98)
     def init_tensors(self):
         net = self.model
+        self._claim_env_buffers()
         self.experience_buffer = rlg.ExperienceBuffer(self.num_actors, self.horizon_length, self.obs_shape[0], self.obs_pitch,
                                                       self.actions_num, net.a_pitch, self.ppo_device)
         self.experience_buffer.add("next_obses", like="obses")
@@ -231,6 +232,12 @@ class CommonAgent:
 
     def _env_reset_masked(self, mask):
         return self.obs_to_tensors(self.vec_env.reset_masked(mask))
+
+    def _claim_env_buffers(self):
+        """This agent never holds a returned observation across env steps (it is copied into the experience buffer first), so the
+        wrapper may hand out its own buffer instead of a fresh clone per step (see VecTaskPythonWrapper.alias_obs)."""
+        if hasattr(self.vec_env, "alias_obs"):
+            self.vec_env.alias_obs = True
 
     def env_step(self, actions):
         if self.clip_actions and getattr(self.vec_env, "clip_actions", None) != 1.0:

@@ -3,7 +3,7 @@
 Mirrors HumanoidImDistill.step (phc/env/tasks/humanoid_im_distill.py:143-231, ``has_pnn`` branch):
 
     full_obs  = clamp((obs - running_mean) / sqrt(running_var + 1e-5), +-5)          teacher's own statistics (:165-183)
-    x_k       = pnn.actors[k](full_obs),  k < num_prim                                 PNN without lateral links (pnn.py:84-131)
+    x_k       = pnn.actors[k](full_obs),  k < num_prim                                 PNN forward, with or without lateral links (pnn.py:84-131)
     weights   = composer(full_obs)                                                     MLP WITH a trailing activation (network_loader.py:40-42)
     gt_action = sum_k weights[:, k, None] * x_k                                        (:195-198)
 
@@ -11,13 +11,17 @@ and the loaders ``load_pnn`` / ``load_mcp_mlp`` (phc/learning/network_loader.py:
 tensors, keys ``a2c_network.pnn.actors.<k>.<2i>.{weight,bias}`` and ``a2c_network.composer.<2i>.{weight,bias}``.
 All num_prim + 1 MLPs read the same normalised observation buffer; the primitives' outputs land side by side in one
 (N, num_prim * 72) buffer, so the mixture is one broadcast-multiply-reduce.
-Only the no-lateral PNN (every released PHC checkpoint: ``has_lateral: False``) is supported.
+``has_lateral: True`` (pnn.py:24-37, 90-123; the released PHC checkpoints use False): column c's second layer adds
+``sum_{j<c} u[c-1][j][0](h1_j)`` to its pre-activation before the activation (the action-space transfer ``u[..][1]`` is disabled in
+the reference, :104).  Here the first-layer outputs of all columns sit side by side in ONE buffer and column c's second layer is a
+single GEMM over the contiguous range [h1_0 .. h1_c] against the row-concatenated weights [u[c-1][0] | .. | u[c-1][c-1] | W2_c]:
+no extra launches, no adds.  Like the reference (:96) this supports two hidden layers per column.
 """
 import torch
 
 from .. import kernels as K
 from .._lib import ACT_RELU, ACT_SILU
-from .graph import MlpGraph, ParamBook, r4
+from .graph import Linear, MlpGraph, ParamBook, r4
 
 _ACTS = {"relu": ACT_RELU, "silu": ACT_SILU}
 
@@ -35,8 +39,6 @@ def _layer_sizes(model, prefix):
 
 class PnnTeacher:
     def __init__(self, pnn_checkpoint, composer_checkpoint, num_prim, num_envs, activation="silu", has_lateral=False, device="cuda:0"):
-        if has_lateral:
-            raise NotImplementedError("PNN lateral connections (pnn.py:90-123) are not used by the released teachers")
         if activation not in _ACTS:
             raise NotImplementedError(f"teacher activation {activation!r}: relu / silu are built")
         pm, cm = pnn_checkpoint["model"], composer_checkpoint["model"]
@@ -49,12 +51,33 @@ class PnnTeacher:
         self.a_pitch = r4(self.num_actions)
         self.x = g.buffer("x", self.in_dim)
         g.buffer("acts", num_prim * self.a_pitch)
-        self._lins = []
-        for k in range(num_prim):
-            sizes = _layer_sizes(pm, f"a2c_network.pnn.actors.{k}")
-            units = [s[0] for s in sizes[:-1]]
-            self._lins += g.mlp(self.book, f"a2c_network.pnn.actors.{k}", "x", self.in_dim, units, act, [f"p{k}h{i}" for i in range(len(units))],
-                                final_linear=sizes[-1][0], final_dst="acts", final_dst_col=k * self.a_pitch)
+        self._lins, self._lat = [], []
+        self.has_lateral = bool(has_lateral)
+        if self.has_lateral:
+            if len(first) != 3:
+                raise NotImplementedError("lateral PNN columns have exactly two hidden layers (pnn.py:96)")
+            u0, u1 = first[0][0], first[1][0]
+            if u0 % 4:
+                raise ValueError("first hidden width must be a multiple of 4 floats")
+            g.buffer("h1all", num_prim * u0)
+            for k in range(num_prim):                                   # every column's first layer lands in its slice of h1all
+                lin = Linear(self.book, f"a2c_network.pnn.actors.{k}.0", self.in_dim, u0, act)
+                g.linear(lin, "x", "h1all", dst_col=k * u0)
+                self._lins.append(lin)
+            for k in range(num_prim):
+                lat = Linear(self.book, f"pnn_lateral.{k}", (k + 1) * u0, u1, act)          # [u[k-1][0..k-1][0] | actors[k][2]]
+                g.buffer(f"p{k}h2", u1)
+                g.linear(lat, "h1all", f"p{k}h2")
+                self._lat.append((lat, k, u0))
+                lin = Linear(self.book, f"a2c_network.pnn.actors.{k}.4", u1, self.num_actions)
+                g.linear(lin, f"p{k}h2", "acts", dst_col=k * self.a_pitch)
+                self._lins.append(lin)
+        else:
+            for k in range(num_prim):
+                sizes = _layer_sizes(pm, f"a2c_network.pnn.actors.{k}")
+                units = [s[0] for s in sizes[:-1]]
+                self._lins += g.mlp(self.book, f"a2c_network.pnn.actors.{k}", "x", self.in_dim, units, act, [f"p{k}h{i}" for i in range(len(units))],
+                                    final_linear=sizes[-1][0], final_dst="acts", final_dst_col=k * self.a_pitch)
         csizes = _layer_sizes(cm, "a2c_network.composer")
         cunits = [s[0] for s in csizes]
         if cunits[-1] != num_prim:
@@ -64,6 +87,10 @@ class PnnTeacher:
         for lin in self._lins:
             self.book.set(lin.w.name, pm[lin.w.name])
             self.book.set(lin.b.name, pm[lin.b.name])
+        for lat, k, u0 in self._lat:
+            cols = [pm[f"a2c_network.pnn.u.{k - 1}.{j}.0.weight"] for j in range(k)] + [pm[f"a2c_network.pnn.actors.{k}.2.weight"]]
+            self.book.set(lat.w.name, torch.cat([c.to(torch.float32) for c in cols], dim=1))
+            self.book.set(lat.b.name, pm[f"a2c_network.pnn.actors.{k}.2.bias"])
         for lin in self._clins:
             self.book.set(lin.w.name, cm[lin.w.name])
             self.book.set(lin.b.name, cm[lin.b.name])

@@ -141,6 +141,29 @@ def test_gemm_linearity_full_size(f32_mode, dev):
     assert_close64(y1[:64], ref, k)
 
 
+@pytest.mark.parametrize("m,n,k", [(512, 512, 4096), (1024, 256, 934)])
+def test_gemm_x3_is_fp32_grade(dev, m, n, k):
+    """The three-way bf16 split is an fp32 GEMM, not a reduced-precision one: against an fp64 reference its error is no larger than
+    the fp32 MFMA's (same operands, wide dynamic range across rows), and far below what ONE bf16 rounding of the operands gives."""
+    g = torch.Generator().manual_seed(k)
+    x = rnd(g, m, k) * torch.logspace(-6, 4, m).unsqueeze(1)             # rows spanning ten decades
+    w = rnd(g, n, k) / math.sqrt(k)
+    ref = x.double() @ w.double().T
+    scale = ref.abs().amax(dim=1, keepdim=True)                          # per-row scale: small rows must be as accurate as large ones
+    errs = {}
+    for mode in ("x3", "mfma32"):
+        out = torch.empty(m, n, device=dev)
+        K.gemm(x.to(dev), w.to(dev), out, M=m, N=n, K=k, lda=k + (-k) % 4, ldb=k + (-k) % 4, ldc=n, f32_mode=mode) if k % 4 == 0 else \
+            K.gemm(padded(x, k + (-k) % 4, dev), padded(w, k + (-k) % 4, dev), out, M=m, N=n, K=k, lda=k + (-k) % 4, ldb=k + (-k) % 4, ldc=n,
+                   f32_mode=mode)
+        e = ((out.cpu().double() - ref).abs() / scale)
+        errs[mode] = (e.max().item(), e.pow(2).mean().sqrt().item())
+    bf = ((x.bfloat16().double() @ w.bfloat16().double().T) - ref).abs().div(scale).max().item()
+    assert errs["x3"][0] <= 1.5 * errs["mfma32"][0] + 1e-9, errs
+    assert errs["x3"][1] <= 1.5 * errs["mfma32"][1] + 1e-10, errs
+    assert errs["x3"][0] < 1e-3 * bf, (errs, bf)
+
+
 def test_colsum(dev):
     g = torch.Generator().manual_seed(1)
     m, n, chunks = 5000, 333, 7

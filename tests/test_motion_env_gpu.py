@@ -200,3 +200,19 @@ def test_amp_window_lockstep_with_cpu_twin(dev):
         twin.reset(ids.cpu(), *state(), task._motion_start_times.cpu(), from_motion=True)
         np.testing.assert_allclose(task._amp_obs_buf.cpu().numpy(), twin.buf.numpy(), atol=3e-5, rtol=1e-5, err_msg=f"window after reset {step}")
     assert n_reset > 0
+
+
+def test_step_returns_a_fresh_observation_like_the_reference(dev):
+    """vec_task.py:152-157 returns torch.clamp(obs_buf, ...): a caller may keep the tensor across steps.  The wrapper does the same
+    unless an agent that copies it right away opts into the aliased buffer (alias_obs)."""
+    n = 16
+    env, _ = configs.make_env(n, 8, dev, seed=5, reference="motion_lib")
+    env.reset()
+    o1, *_ = env.step(torch.zeros(n, 69, device=dev))
+    keep = o1.clone()
+    o2, *_ = env.step(torch.zeros(n, 69, device=dev))
+    assert o1.data_ptr() != env.task.obs_buf.data_ptr() and o2.data_ptr() != o1.data_ptr()
+    assert torch.equal(o1, keep) and not torch.equal(o1, o2)
+    env.alias_obs = True
+    o3, *_ = env.step(torch.zeros(n, 69, device=dev))
+    assert o3.data_ptr() == env.task.obs_buf.data_ptr()

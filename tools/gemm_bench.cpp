@@ -17,12 +17,13 @@ extern "C" int pulse_gemm_set_debug_buffer(long long* device_buffer);
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-__global__ void fill_kernel(float* p, long long n, unsigned seed, float scale) {
+__global__ void fill_kernel(float* p, long long n, unsigned seed, float scale, int relu = 0) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (long long)gridDim.x * blockDim.x) {
         unsigned h = (unsigned)i * 2654435761u ^ seed;
         h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-        p[i] = ((h & 0xffffff) / 8388608.0f - 1.0f) * scale;
+        const float v = ((h & 0xffffff) / 8388608.0f - 1.0f) * scale;
+        p[i] = relu && v < 0.f ? 0.f : v;              // --relu: activations / masked gradients as the networks see them (half zeros)
     }
 }
 
@@ -70,7 +71,7 @@ int main(int argc, char** argv) {
     int iters = 20, warm = 3;
     std::string only;
     std::vector<std::pair<int, int>> opts;
-    bool sweep = false, clocks = false, bf16_cases = false, x3_cases = false;
+    bool sweep = false, clocks = false, bf16_cases = false, x3_cases = false; int relu_data = 0;
     std::vector<std::vector<int>> custom;      // --fwd M N K lda ldb ldc
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
@@ -81,6 +82,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--clocks")) clocks = true;
         else if (!strcmp(argv[i], "--bf16")) bf16_cases = true;
         else if (!strcmp(argv[i], "--x3")) x3_cases = true;
+        else if (!strcmp(argv[i], "--relu")) relu_data = 1;
         else if (!strcmp(argv[i], "--fwd")) { std::vector<int> v; for (int j = 0; j < 6; ++j) v.push_back(atoi(argv[++i])); custom.push_back(v); }
     }
     for (auto& o : opts) pulse_gemm_set_option(o.first, o.second);
@@ -90,9 +92,9 @@ int main(int argc, char** argv) {
     float *X, *W, *H, *AUX, *BIAS, *maxerr; CaseP* dcase;
     CK(hipMalloc(&X, big * 4)); CK(hipMalloc(&W, big * 4)); CK(hipMalloc(&H, big * 4)); CK(hipMalloc(&AUX, big * 4));
     CK(hipMalloc(&BIAS, 8192 * 4)); CK(hipMalloc(&maxerr, 4)); CK(hipMalloc(&dcase, sizeof(CaseP)));
-    fill_kernel<<<1024, 256>>>(X, big, 1u, 1.0f);
+    fill_kernel<<<1024, 256>>>(X, big, 1u, 1.0f, relu_data);
     fill_kernel<<<1024, 256>>>(W, big, 2u, 0.05f);
-    fill_kernel<<<1024, 256>>>(AUX, big, 3u, 1.0f);
+    fill_kernel<<<1024, 256>>>(AUX, big, 3u, 1.0f, relu_data);
     fill_kernel<<<8, 256>>>(BIAS, 8192, 4u, 0.5f);
     CK(hipDeviceSynchronize());
 

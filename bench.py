@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock bound of the CPU baseline subprocess (s)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true", help="do not bracket GEMM launches with events")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the sustained-clock probe (60 extra launches of the layer-1 forward GEMM after the timed region)")
     ap.add_argument("--keep-gc", action="store_true", help="leave Python's cyclic garbage collector running during the timed region")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank owns the config's env count; strong: the config's env count is divided over the ranks")
@@ -312,7 +313,7 @@ def main():
                 out["roofline_fp32_gemm"] = r32
         elif r32 is not None:
             out["roofline"] = r32
-        if rank == 0 and "roofline" in out:
+        if rank == 0 and "roofline" in out and not a.no_clock_probe:
             try:
                 net = getattr(agent.model, "a2c_network", agent.model)
                 units = getattr(net, "units", None) or [1024]

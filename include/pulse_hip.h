@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 10
+#define PULSE_ABI_VERSION 11
 
 typedef void* pulse_stream_t; /* hipStream_t */
 

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2

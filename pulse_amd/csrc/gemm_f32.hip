@@ -342,8 +342,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
     // buffer resources based at this workgroup's tile origin and k start (all offsets stay far below 2^31)
     const float* Ab = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
     const float* Bb = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, 0xffffffffu, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, 0xffffffffu, RSRC_FLAGS);
+    // [red][out] operands: the shifted window of the last k-tile may name up to three k rows past the operand's last row; the buffer
+    // extent makes those loads return zero without touching memory (they are masked anyway)
+    const unsigned recA = AKC ? 0xffffffffu : (unsigned)((g.K - kbeg - 1) * g.lda + ((min(BM, g.M - m0) + 3) & ~3)) * 4u;
+    const unsigned recB = BKC ? 0xffffffffu : (unsigned)((g.K - kbeg - 1) * g.ldb + ((min(BN, g.N - n0) + 3) & ~3)) * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, recA, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, recB, RSRC_FLAGS);
     const int kstepA = AKC ? 4 : g.lda * 4, kstepB = BKC ? 4 : g.ldb * 4;        // bytes per unit of k
     auto koff = [&](int t) { return t == nkt - 1 ? wlast : t * BK; };              // scalar
 
@@ -633,8 +637,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs g) {
 
     const float* Ab = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
     const float* Bb = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, 0xffffffffu, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, 0xffffffffu, RSRC_FLAGS);
+    // [red][out] operands: the shifted window of the last k-tile may name up to three k rows past the operand's last row; the buffer
+    // extent makes those loads return zero without touching memory (they are masked anyway)
+    const unsigned recA = AKC ? 0xffffffffu : (unsigned)((g.K - kbeg - 1) * g.lda + ((min(BM, g.M - m0) + 3) & ~3)) * 4u;
+    const unsigned recB = BKC ? 0xffffffffu : (unsigned)((g.K - kbeg - 1) * g.ldb + ((min(BN, g.N - n0) + 3) & ~3)) * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, recA, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, recB, RSRC_FLAGS);
     const int kstepA = AKC ? 4 : g.lda * 4, kstepB = BKC ? 4 : g.ldb * 4;
     auto koff = [&](int t) { return t == nkt - 1 ? wlast : t * BK16; };
 

@@ -287,14 +287,16 @@ class A2CNetwork:
             # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
             if l == 0:
                 p.split = len(p.ops)        # everything before this point only touches gradient elements >= w_off[1] (layers 2.., heads)
+                s1 = K.dw_split(((2 * uu + 127) // 128) * ((k + 127) // 128), S)
                 p.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
-                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=S, split_stride=P, algo_n=self.in_dim,
+                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=s1, split_stride=P, algo_n=self.in_dim,
                        rowsum=slabs, rowsum_off=self.b_off[0])
             else:
                 up = u[l - 1]
+                sl = K.dw_split(2 * ((uu + 127) // 128) * ((up + 127) // 128), S)
                 p.gemm(dz, ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],
-                       split_k=S, split_stride=P, rowsum=slabs, rowsum_off=self.b_off[l], stride_rowsum=uu)
+                       split_k=sl, split_stride=P, rowsum=slabs, rowsum_off=self.b_off[l], stride_rowsum=uu)
                 p.gemm(dz, f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
                        batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
                        aux=aux[l - 1], ldaux=2 * up, stride_aux=up)

@@ -881,7 +881,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int xcd = bid & 7, loc = bid >> 3;
     const int q8 = ntile >> 3, rr = ntile & 7;
     const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
-    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.y;
     const int bz = z / g.splitk, sp = z - bz * g.splitk;
@@ -987,17 +987,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             const bf16x8 b = term == 1 ? fb2[j] : (term == 2 || term == 4) ? fb1[j] : fb0[S][j];
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
             if constexpr (MODE != 2) {
+#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 16)
+                if (g.K == 12345 || MODE == 1)        // timing only: steady tiles keep re-reading the first tiles' planes (no split, no stores)
+#endif
+                {
                 if (p < 4) sa.template split_pair<O>(p);
                 else if (p < 8) sb.template split_pair<O>(p - 4);
                 if (p >= 4 && p < 7) sa.write_plane(OTH, p - 4);          // one 16-byte store per gap: the store path takes ~13 cycles each
                 if (p >= 8 && p < 11) sb.write_plane(OTH, p - 8);
+                }
                 if constexpr (MODE == 0) {
 #if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 8)
                     if (p == 11 && t + 3 < nkt && g.K == 12345) {
 #else
                     if (p == 11 && t + 3 < nkt) {
 #endif
+#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 32)
+                        sa.template load<O>(rsA, 0); sb.template load<O>(rsB, 0);                         // timing only: every tile re-reads k-tile 0 (always cached)
+#elif defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 64)
+                        sa.template load<O>(rsA, (t + 3) * 2 * kstepA); sb.template load<O>(rsB, (t + 3) * 2 * kstepB);   // timing only: every other k-tile (each 128-B line touched once)
+#else
                         sa.template load<O>(rsA, (t + 3) * kstepA); sb.template load<O>(rsB, (t + 3) * kstepB);
+#endif
                     }
                 }
                 if (p == X3_BARRIER_GAP) {                                // a few MFMAs after the last store: its lgkmcnt wait is short

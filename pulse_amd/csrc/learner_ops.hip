@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __
 // of a row per instruction).  Needs 16-byte aligned rows on both sides and y_cols % 4 == 0.
 constexpr int kRmsVecGroups = 3;   // 256 threads x 4 columns x 3 groups = 3072 columns
 constexpr int kRmsRowsPerPass = 64;
+constexpr int kRmsRowsInFlight = 4;
 
 __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,
@@ -117,28 +118,30 @@ __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __
         __syncthreads();
         if (tid < nr) s_src[tid] = row_idx ? row_idx[rb + tid] : (long long)(rb + tid);
         __syncthreads();
-        for (int q = 0; q < nr; q += 2) {
-            const bool two = q + 1 < nr;
-            const float* xr0 = x + s_src[q] * x_stride;
-            const float* xr1 = x + s_src[two ? q + 1 : q] * x_stride;
-            float4 v0[kRmsVecGroups], v1[kRmsVecGroups];
+        for (int q = 0; q < nr; q += kRmsRowsInFlight) {
+            // kRmsRowsInFlight rows' loads are issued before the first is consumed: a workgroup's row loop is latency-bound
+            // (one 3.7 KB row per memory round trip otherwise)
+            float4 v[kRmsRowsInFlight][kRmsVecGroups];
 #pragma unroll
-            for (int j = 0; j < kRmsVecGroups; ++j) {
-                const int c = (tid + 256 * j) * 4;
-                v0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                v1[j] = v0[j];
-                if (c < cols) { v0[j] = *reinterpret_cast<const float4*>(xr0 + c); v1[j] = *reinterpret_cast<const float4*>(xr1 + c); }
+            for (int h = 0; h < kRmsRowsInFlight; ++h) {
+                const float* xr = x + s_src[q + h < nr ? q + h : q] * x_stride;
+#pragma unroll
+                for (int j = 0; j < kRmsVecGroups; ++j) {
+                    const int c = (tid + 256 * j) * 4;
+                    v[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < cols) v[h][j] = *reinterpret_cast<const float4*>(xr + c);
+                }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 1 && !two) break;
+            for (int h = 0; h < kRmsRowsInFlight; ++h) {
+                if (q + h >= nr) break;
                 float* yr = y + (long long)(rb + q + h) * y_stride;
 #pragma unroll
                 for (int j = 0; j < kRmsVecGroups; ++j) {
                     const int c = (tid + 256 * j) * 4;
                     if (c < y_cols) {
-                        const float4 v = h == 0 ? v0[j] : v1[j];
-                        float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+                        const float4 vv = v[h][j];
+                        float in[4] = {vv.x, vv.y, vv.z, vv.w}, o[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             if (c + k < cols) {

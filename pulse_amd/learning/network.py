@@ -287,7 +287,7 @@ class A2CNetwork:
             # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
             if l == 0:
                 p.split = len(p.ops)        # everything before this point only touches gradient elements >= w_off[1] (layers 2.., heads)
-                s1 = K.dw_split(((2 * uu + 127) // 128) * ((k + 127) // 128), S)
+                s1 = self._l0_slabs = K.dw_split(((2 * uu + 127) // 128) * ((k + 127) // 128), S)
                 p.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=s1, split_stride=P, algo_n=self.in_dim,
                        rowsum=slabs, rowsum_off=self.b_off[0])
@@ -322,6 +322,7 @@ class A2CNetwork:
         K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat - cut, self.grad, scale=grad_scale, slabs_off=cut, out_off=cut)
         on_bucket(self.grad[cut:])
         plan.run(plan.split, None)
-        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, cut, self.grad, scale=grad_scale)
+        # the layer-1 region [0, cut) holds only the slabs its dW GEMM wrote (the others stay zero): reduce just those
+        K.reduce_slabs(self._slabs, getattr(self, "_l0_slabs", self.split_k), self.n_flat, cut, self.grad, scale=grad_scale)
         on_bucket(self.grad[:cut])
         return self.grad

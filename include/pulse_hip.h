@@ -526,6 +526,14 @@ int pulse_advantage_normalize(float* adv, int64_t count, const double* partials,
  * gradient (from pulse_sqnorm_partial); clip coefficient = min(1, max_norm / (norm + 1e-6)); max_norm <= 0
  * disables clipping.  step is the 1-based Adam step count. */
 int pulse_sqnorm_partial(const float* x, int64_t count, float* partials, int32_t num_blocks, pulse_stream_t s);
+
+/* AMPAgent._disc_loss head, phc/learning/amp_agent.py:895-952 (disc_loss_neg / disc_loss_pos :954-969, _compute_disc_acc :971-977), on
+ * the logits of the 3b stacked rows [agent | replay | demo] (row i at logits[i * logit_stride]):
+ *   stats[0] = 0.5 (BCEWithLogits(agent U replay, 0) + BCEWithLogits(demo, 1)),  [1], [2] the two means,
+ *   stats[3] = mean(agent logit < 0), [4] = mean(demo logit > 0), [5], [6] = mean agent / demo logit, [7] = 0
+ *   dlogits[i * dlogit_stride] = scale * d stats[0] / d logit_i          (scale = disc_coef / world_size) */
+int pulse_disc_head(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride,
+                    float* stats, pulse_stream_t s);
 int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                     const float* sqnorm_partials, int32_t num_partials, float* grad_norm_out, pulse_stream_t s);

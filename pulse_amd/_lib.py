@@ -199,6 +199,7 @@ SIGNATURES = {
     "pulse_advantage_moments": (c_int, [P, P, c_int64, P, P, c_int32, P]),
     "pulse_advantage_normalize": (c_int, [P, c_int64, P, c_int32, P]),
     "pulse_sqnorm_partial": (c_int, [P, c_int64, P, c_int32, P]),
+    "pulse_disc_head": (c_int, [P, c_int64, c_int32, c_float, P, c_int64, P, P]),
     "pulse_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_float, P, c_int32, P, P]),
 }
 

@@ -881,7 +881,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int xcd = bid & 7, loc = bid >> 3;
     const int q8 = ntile >> 3, rr = ntile & 7;
     const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
-const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.y;
     const int bz = z / g.splitk, sp = z - bz * g.splitk;

@@ -418,6 +418,44 @@ __global__ void __launch_bounds__(256) adv_normalize_kernel(float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // gradient norm + Adam over the flat parameter buffer
 // ------------------------------------------------------------------------------------------------
+// AMPAgent._disc_loss head (phc/learning/amp_agent.py:895-952) on the logits of the 3b stacked rows [agent | replay | demo]:
+// prediction loss 0.5 (BCEWithLogits(agent U replay, 0) + BCEWithLogits(demo, 1)), its gradient w.r.t. every logit (times
+// ``scale`` = disc_coef / world_size), the two accuracies and the two logit means -- one launch instead of ~45 tiny tensor ops and an
+// autograd pass per minibatch.  One workgroup: 3b logits are a few hundred KB; reductions in double, fixed order.
+__global__ void __launch_bounds__(1024) disc_head_kernel(const float* __restrict__ logits, long long ls, int b, float scale,
+                                                         float* __restrict__ dlogits, long long ds, float* __restrict__ stats) {
+    __shared__ double red[16][6];
+    const int n = 3 * b, na = 2 * b;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // BCE agent, BCE demo, #agent < 0, #demo > 0, sum agent logit, sum demo logit
+    const float ga = scale * 0.5f / (float)na, gd = scale * 0.5f / (float)b;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = logits[(long long)i * ls];
+        const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));        // softplus(x) = BCEWithLogits(x, 0); BCE(x, 1) = softplus(x) - x
+        const float sg = 1.f / (1.f + expf(-x));
+        if (i < na) {
+            acc[0] += (double)sp; acc[2] += x < 0.f ? 1.0 : 0.0; acc[4] += (double)x;
+            dlogits[(long long)i * ds] = ga * sg;
+        } else {
+            acc[1] += (double)(sp - x); acc[3] += x > 0.f ? 1.0 : 0.0; acc[5] += (double)x;
+            dlogits[(long long)i * ds] = gd * (sg - 1.f);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[6];
+        for (int k = 0; k < 6; ++k) { t[k] = 0.0; for (int w = 0; w < 16; ++w) t[k] += red[w][k]; }
+        const double la = t[0] / na, ld = t[1] / b;
+        stats[0] = (float)(0.5 * (la + ld)); stats[1] = (float)la; stats[2] = (float)ld;
+        stats[3] = (float)(t[2] / na); stats[4] = (float)(t[3] / b); stats[5] = (float)(t[4] / na); stats[6] = (float)(t[5] / b); stats[7] = 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256) sqnorm_partial_kernel(const float* __restrict__ x, long long count, float* __restrict__ partials) {
     __shared__ float red[4];
     float s = 0.f;
@@ -564,6 +602,15 @@ int pulse_sqnorm_partial(const float* x, int64_t count, float* partials, int32_t
     PULSE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "pulse_sqnorm_partial: x must be 16-byte aligned");
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)count, partials);
     return check_launch("pulse_sqnorm_partial");
+}
+
+int pulse_disc_head(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride, float* stats,
+                    pulse_stream_t s) {
+    PULSE_REQUIRE(b >= 1 && logit_stride >= 1 && dlogit_stride >= 1, "pulse_disc_head: bad sizes");
+    PULSE_REQUIRE(logits && dlogits && stats, "pulse_disc_head: null pointer");
+    hipLaunchKernelGGL(disc_head_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, (long long)logit_stride, b, scale, dlogits,
+                       (long long)dlogit_stride, stats);
+    return check_launch("pulse_disc_head");
 }
 
 int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1, float beta2,

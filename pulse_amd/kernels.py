@@ -250,6 +250,16 @@ def sqnorm_partial(x, count, partials):
     _lib.check(_lib.load().pulse_sqnorm_partial(_p(x), count, _p(partials), partials.numel(), _stream()), "pulse_sqnorm_partial")
 
 
+def disc_head(logits, b, scale, dlogits, stats):
+    """AMPAgent._disc_loss head on the (3b, 1) logit column (any row stride): fills ``dlogits`` (same shape) and ``stats`` (8 floats:
+    pred loss, agent BCE, demo BCE, agent acc, demo acc, agent logit mean, demo logit mean, 0)."""
+    _chk(logits, "logits"), _chk(dlogits, "dlogits"), _chk(stats, "stats")
+    if logits.shape[0] != 3 * b or dlogits.shape[0] != 3 * b or stats.numel() < 8 or not stats.is_contiguous():
+        raise ValueError("disc_head: logits / dlogits must have 3b rows and stats 8 contiguous floats")
+    _lib.check(_lib.load().pulse_disc_head(_p(logits), logits.stride(0), b, float(scale), _p(dlogits), dlogits.stride(0), _p(stats), _stream()),
+               "pulse_disc_head")
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               max_norm=0.0, sqnorm_partials=None, grad_norm_out=None):
     for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (sqnorm_partials, "sqnorm_partials"),

@@ -223,25 +223,20 @@ class AMPAgent(CommonAgent):
         rms.forward(rep_src, row_idx=rep_idx[sub] if rep_idx is not None else sub, out=X[b:2 * b], out_cols=self._amp_pitch)   # amp_obs_replay
         rms.forward(self._amp_obs_demo_buffer.data, row_idx=d["_amp_demo_idx"][sub], out=X[2 * b:3 * b], out_cols=self._amp_pitch)  # amp_obs_demo
         logits = self.disc.forward(ws)
-        with torch.enable_grad():
-            lg = logits.detach().clone().requires_grad_(True)
-            agent_logit, demo_logit = lg[:2 * b], lg[2 * b:]
-            disc_loss_agent = self._bce(agent_logit, torch.zeros_like(agent_logit))
-            disc_loss_demo = self._bce(demo_logit, torch.ones_like(demo_logit))
-            pred = 0.5 * (disc_loss_agent + disc_loss_demo)
-            (self._disc_coef * pred / self.world_size).backward()
-        ws["dlogits"].copy_(lg.grad)
+        # prediction loss, its logit gradients, accuracies and logit means in ONE launch (pulse_disc_head); the dict entries are views of
+        # this minibatch's own 8-float result row
+        st = torch.empty(8, dtype=torch.float32, device=self.ppo_device)
+        K.disc_head(logits, b, self._disc_coef / self.world_size, ws["dlogits"], st)
         penalty = self.disc.backward(ws, self._disc_grad_penalty, self._disc_logit_reg, self._disc_weight_decay,
                                      scale=self._disc_coef / self.world_size)
         w3 = self.disc.get_disc_logit_weights()
         logit_loss = torch.sum(torch.square(w3))
-        disc_loss = pred.detach() + self._disc_logit_reg * logit_loss + self._disc_grad_penalty * penalty
+        disc_loss = st[0] + self._disc_logit_reg * logit_loss + self._disc_grad_penalty * penalty
         if self._disc_weight_decay != 0:
             wsum = sum(torch.sum(torch.square(self.disc.book.get(l.w.name))) for l in (self.disc.l1, self.disc.l2, self.disc.l3))
             disc_loss = disc_loss + self._disc_weight_decay * wsum
-        return {"disc_loss": disc_loss, "disc_grad_penalty": penalty.detach(), "disc_logit_loss": logit_loss.detach(),
-                "disc_agent_acc": torch.mean((agent_logit.detach() < 0).float()), "disc_demo_acc": torch.mean((demo_logit.detach() > 0).float()),
-                "disc_agent_logit": agent_logit.detach().mean(), "disc_demo_logit": demo_logit.detach().mean()}
+        return {"disc_loss": disc_loss, "disc_grad_penalty": penalty, "disc_logit_loss": logit_loss,
+                "disc_agent_acc": st[3], "disc_demo_acc": st[4], "disc_agent_logit": st[5], "disc_demo_logit": st[6]}
 
     # ------------------------------------------------------------------ checkpoint surface (amp_agent.py:81-118, 181-190)
     def get_stats_weights(self):

@@ -84,6 +84,7 @@ class DiscNetwork:
         ws = {"b": b, "X": z(m, self.k0p), "H1": z(m, self.u1), "H2": z(m, self.u2), "Z1": z(m, self.u1), "Z2": z(m, self.u2),
               "L": z(m, 4), "dL": z(m, 4), "G": z(b, self.k0p)}
         ws["dL"][3 * b:, 0] = 1.0                      # the penalty path's "ones" column for dw3
+        ws["pen_partials"] = z(1, 256).view(-1)
         ws["logits"] = ws["L"][:3 * b, :1]
         ws["dlogits"] = ws["dL"][:3 * b, :1]
         ws["fwd"] = self._plan_forward(ws, 3 * b, bf16=self.mixed_precision)
@@ -171,8 +172,9 @@ class DiscNetwork:
         b = ws["b"]
         ws["bwd_bce"].run()
         ws["pen_fwd"].run()
-        g = ws["G"][:, :self.k0]
-        penalty = (g * g).sum(dim=-1).mean()
+        # mean_demo ||dD/dx||^2: sum of squares of the whole (b, k0p) buffer (its pad columns are never written and stay zero)
+        K.sqnorm_partial(ws["G"], ws["G"].numel(), ws["pen_partials"])
+        penalty = ws["pen_partials"].sum() / b
         torch.mul(ws["G"], 2.0 * grad_penalty_coef * scale / b, out=ws["X"][3 * b:])      # dg
         ws["pen_bwd"].run()
         ws["wgrad"].run()

@@ -65,3 +65,30 @@ def test_disc_eval_rollout_batch(dev):
     disc.load_state_dict(ref.state_dict_ref())
     x = torch.randn(1000, 1960)
     rel_close(disc.eval_disc(x.to(dev).contiguous()), ref.eval_disc(x), 3e-5, "eval_disc")
+
+
+@pytest.mark.parametrize("b", [1, 37, 4096])
+def test_disc_head_matches_torch_bce_and_autograd(dev, b):
+    """pulse_disc_head vs the reference's expression (amp_agent.py:895-977): BCEWithLogitsLoss on agent / demo logits, the gradient
+    autograd gives for scale * 0.5 (agent + demo), accuracies and logit means."""
+    from pulse_amd import kernels as K
+    g = torch.Generator().manual_seed(b)
+    buf = torch.zeros(3 * b, 4)
+    buf[:, 0] = torch.randn(3 * b, generator=g) * 3
+    lg = buf[:, :1].clone().requires_grad_(True)
+    bce = torch.nn.BCEWithLogitsLoss()
+    la, ld = bce(lg[:2 * b], torch.zeros(2 * b, 1)), bce(lg[2 * b:], torch.ones(b, 1))
+    pred = 0.5 * (la + ld)
+    scale = 5.0 / 2
+    (scale * pred).backward()
+    dbuf = buf.to(dev)
+    dl = torch.zeros(3 * b, 4, device=dev)
+    st = torch.empty(8, device=dev)
+    K.disc_head(dbuf[:, :1], b, scale, dl[:, :1], st)
+    st = st.cpu()
+    np.testing.assert_allclose(st[:3].numpy(), [pred.item(), la.item(), ld.item()], rtol=2e-6)
+    # sigmoid(x) - 1 cancels for confident demo rows (in torch's backward as well): a few ulps of sigmoid show up as 1e-5 relative
+    np.testing.assert_allclose(dl[:, 0].cpu().numpy(), lg.grad[:, 0].numpy(), rtol=1e-4, atol=1e-12)
+    assert torch.equal(dl[:, 1:].cpu(), torch.zeros(3 * b, 3))
+    want = [(lg[:2 * b] < 0).float().mean().item(), (lg[2 * b:] > 0).float().mean().item(), lg[:2 * b].mean().item(), lg[2 * b:].mean().item()]
+    np.testing.assert_allclose(st[3:7].numpy(), want, rtol=1e-5, atol=1e-6)

@@ -156,16 +156,17 @@ struct Stager {
     }
 };
 
-// ---- epilogue (shared by the fp32 and the bf16 main loops) -----------------------------------------------------------
+// ---- epilogue (shared by all main loops; WM = 32-row MFMA tiles per wave: tile height 64 WM) -----------------------------------------------------------
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 // ``round_bf16``: results leave as bf16-representable fp32 values -- what a bf16 autocast Linear hands to the next op.
 __device__ __forceinline__ float rbf(float v) { return (float)(__bf16)v; }
 
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int tid, int m0, int n0, int bz, int sp, int wm, int wn,
+template <int WM>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[WM][2], int tid, int m0, int n0, int bz, int sp, int wm, int wn,
                                               int half, int l31) {
     if (g.round_bf16) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -177,27 +178,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
     const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
 
     if (g.vec_epi) {
-        const bool fast = m0 + BM <= g.M && n0 + BN <= g.N && (g.epi == 1 || (g.epi == 0 && g.act != 2));
+        const bool fast = m0 + 64 * WM <= g.M && n0 + BN <= g.N && (g.epi == 1 || (g.epi == 0 && g.act != 2));
         const int c4 = (tid & 31) * 4;
         const int rl0 = tid >> 5;
-        f32x4 ax[16];
+        f32x4 ax[8 * WM];
         if (fast && g.epi == 1) {                  // relu-grad: the 16 aux loads fly while the accumulators go through LDS
             const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
                                                                                 0xffffffffu, RSRC_FLAGS);
             const int voX = (rl0 * g.ldaux + c4) * 4;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) ax[q] = buf_load(rsX, voX, q * 8 * g.ldaux * 4);
+            for (int q = 0; q < 8 * WM; ++q) ax[q] = buf_load(rsX, voX, q * 8 * g.ldaux * 4);
         }
         // The accumulators are transposed through LDS (the staging buffers are free after the main loop) so every global
         // access of the epilogue is a 16-byte access covering 512 contiguous bytes of one row per half-wave.
         float* sC = smem;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
+                    sC[(wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
         __syncthreads();
         if (g.dbg && tid == 0) g.dbg[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 6] = clock64();
         if (fast) {
@@ -209,14 +210,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
             if (g.epi == 0) {
                 const bool relu = g.act == 1;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < 8 * WM; ++q) {
                     f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < 8 * WM; ++q) {
                     const f32x4 a = ax[q];
                     f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
                     v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
@@ -229,7 +230,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         if (col < g.N) {
             const bool full = col + 3 < g.N;
 #pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 8 * WM; ++q) {
                 const int rl = rl0 + 8 * q;
                 const int row = m0 + rl;
                 if (row >= g.M) continue;
@@ -278,10 +279,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         const int col = n0 + wn * 64 + j * 32 + l31;
         if (col >= g.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row >= g.M) continue;
                 float v = acc[i][j][r];
                 if (g.epi == 0) {
@@ -868,8 +869,11 @@ struct StagerX {
     __device__ __forceinline__ void write(int st) { write_plane(st, 0); write_plane(st, 1); write_plane(st, 2); }
 };
 
-template <bool AKC, bool BKC>
+// WM = 32-row MFMA tiles per wave: 2 = the 128-row tile, 1 = a 64-row tile (half the MFMAs per k-tile beside the same B staging) for
+// skinny launches whose 128-row tiling would leave the chip at one workgroup per CU (the mu / value heads).
+template <bool AKC, bool BKC, int WM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_x3_kernel(const GemmArgs g) {
+    constexpr int BMx = 64 * WM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -882,7 +886,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int q8 = ntile >> 3, rr = ntile & 7;
     const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
     const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BMx, n0 = tn * BN;
     const int z = blockIdx.y;
     const int bz = z / g.splitk, sp = z - bz * g.splitk;
     const int kbeg = sp * g.kchunk;
@@ -895,7 +899,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (g.dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
 
     // buffer resources with the TRUE extent from this workgroup's origin: anything outside reads as zero (no memory access)
-    const int extA = min(BM, g.M - m0), extB = min(BN, g.N - n0);
+    const int extA = min(BMx, g.M - m0), extB = min(BN, g.N - n0);
     const int k4rem = ((g.K + 3) & ~3) - kbeg;                   // readable k positions of a reduction-contiguous row from kbeg
     const float* Ab = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
     const float* Bb = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
@@ -911,12 +915,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     sb.init(tid, g.ldb, X_IMG);
 
     // fragment read addresses: lane (l31, half) reads out (wm|wn) * 64 + {0, 32} + l31, k-chunk = half, plane p at + p * X_PLANE
-    const int frA0 = (half * X_CSTRIDE + slot_of(wm * 64 + l31)) * 16;
-    const int frA1 = (half * X_CSTRIDE + slot_of(wm * 64 + 32 + l31)) * 16;
+    const int frA0 = (half * X_CSTRIDE + slot_of(wm * 32 * WM + l31)) * 16;
+    const int frA1 = (half * X_CSTRIDE + slot_of(wm * 32 * WM + 32 + l31)) * 16;      // WM == 2 only
     const int frB0 = X_IMG + (half * X_CSTRIDE + slot_of(wn * 64 + l31)) * 16;
     const int frB1 = X_IMG + (half * X_CSTRIDE + slot_of(wn * 64 + 32 + l31)) * 16;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][2];
     {
         float b0 = 0.f, b1 = 0.f;
         if (g.epi == 0 && g.bias) {
@@ -926,7 +930,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (c0 + 32 < g.N) b1 = bias[c0 + 32];
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
     }
@@ -936,7 +940,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // Fragment registers: plane 0 in two sets (tile parity), planes 1 and 2 in ONE set that is refilled as soon as the tile's last
     // MFMA reading it has issued.  Term order (A plane, B plane): (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)  =>  A2 is dead after MFMA 3,
     // B2 after 7, A1 after 15, B1 after 19.
-    bf16x8 fa0[2][2], fb0[2][2], fa1[2], fb1[2], fa2[2], fb2[2];
+    bf16x8 fa0[2][WM], fb0[2][2], fa1[WM], fb1[2], fa2[WM], fb2[2];
     // fragment read unit u (0..11) of the stage at byte offset st (plane 0 into set S), in the order the slots allow
     auto frag_unit = [&](auto set_tag, int u, int st) {
         constexpr int S = decltype(set_tag)::value;
@@ -944,15 +948,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         auto rd = [&](int addr) { return *reinterpret_cast<const bf16x8*>(smem_c + st + addr); };
         switch (u) {
             case 0: fa2[0] = rd(frA0 + 2 * X_PLANE); break;
-            case 1: fa2[1] = rd(frA1 + 2 * X_PLANE); break;
+            case 1: if constexpr (WM == 2) fa2[1] = rd(frA1 + 2 * X_PLANE); break;
             case 2: fb0[S][0] = rd(frB0); break;
             case 3: fb0[S][1] = rd(frB1); break;
             case 4: fb2[0] = rd(frB0 + 2 * X_PLANE); break;
             case 5: fb2[1] = rd(frB1 + 2 * X_PLANE); break;
             case 6: fa0[S][0] = rd(frA0); break;
-            case 7: fa0[S][1] = rd(frA1); break;
+            case 7: if constexpr (WM == 2) fa0[S][1] = rd(frA1); break;
             case 8: fa1[0] = rd(frA0 + X_PLANE); break;
-            case 9: fa1[1] = rd(frA1 + X_PLANE); break;
+            case 9: if constexpr (WM == 2) fa1[1] = rd(frA1 + X_PLANE); break;
             case 10: fb1[0] = rd(frB0 + X_PLANE); break;
             default: fb1[1] = rd(frB1 + X_PLANE); break;
         }
@@ -980,12 +984,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (do_rs) rs_acc += sa.template sum8<O>();
             }
         }
+        // the side-work schedule is written in 24 SLOTS (slot s belongs to term s / 4); with WM == 2 every slot follows its own MFMA,
+        // with WM == 1 the tile has 12 MFMAs and each is followed by two slots
+        constexpr int SPM = 2 / WM;
 #pragma unroll
-        for (int p = 0; p < 24; ++p) {
-            const int term = p >> 2, i = (p >> 1) & 1, j = p & 1;
-            const bf16x8 a = term == 0 ? fa2[i] : (term == 2 || term == 3) ? fa1[i] : fa0[S][i];
-            const bf16x8 b = term == 1 ? fb2[j] : (term == 2 || term == 4) ? fb1[j] : fb0[S][j];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+        for (int q = 0; q < 12 * WM; ++q) {
+            {
+                const int term = q / (2 * WM), i = (q >> 1) % WM, j = q & 1;
+                const bf16x8 a = term == 0 ? fa2[i] : (term == 2 || term == 3) ? fa1[i] : fa0[S][i];
+                const bf16x8 b = term == 1 ? fb2[j] : (term == 2 || term == 4) ? fb1[j] : fb0[S][j];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int p = q * SPM; p < (q + 1) * SPM; ++p)
             if constexpr (MODE != 2) {
 #if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 16)
                 if (g.K == 12345 || MODE == 1)        // timing only: steady tiles keep re-reading the first tiles' planes (no split, no stores)
@@ -1071,7 +1082,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             extern __shared__ __attribute__((aligned(16))) float smem[];
             smem[tid] = rs_acc;                                   // thread (kch = tid >> 7, out = tid & 127) summed its 8 k rows of every tile
             __syncthreads();
-            if (tid < 128 && m0 + tid < g.M) g.rowsum[bz * g.sRowsum + sp * g.sSplit + m0 + tid] = smem[tid] + smem[tid + 128];
+            if (tid < BMx && m0 + tid < g.M) g.rowsum[bz * g.sRowsum + sp * g.sSplit + m0 + tid] = smem[tid] + smem[tid + 128];
             __syncthreads();
         }
     }
@@ -1211,6 +1222,12 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
+    // x3 only: a 64-row tile for skinny outputs (one column tile: the mu / value heads) whose 128-row tiling leaves the chip at one
+    // workgroup per CU or less.  Measured: heads at M = 16384 36.2 -> 32.8 us, at M = 4096 28.5 -> 21.6 us; full-width outputs at the same
+    // workgroup count get SLOWER with the half tile (twice the B staging per MFMA: rollout layer 2 52.8 -> 58.3 us), so they keep 128 rows.
+    const bool half_tile = d->compute_type == PULSE_GEMM_COMPUTE_F32X3 && d->M >= 256 && g.tiles_n == 1 &&
+                           (long long)g.tiles_m * d->batch * d->split_k < 384 && g_opt[2] == 0;
+    if (half_tile) g.tiles_m = (d->M + 63) / 64;
     g.dbg = g_dbg;
     PULSE_REQUIRE(d->compute_type == PULSE_GEMM_COMPUTE_F32 || d->compute_type == PULSE_GEMM_COMPUTE_BF16 ||
                   d->compute_type == PULSE_GEMM_COMPUTE_F32X3, "pulse_gemm_f32: bad compute_type");
@@ -1228,7 +1245,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
     // The 64.5 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling
     // hipFuncSetAttribute on every launch serialises the host against the stream).
-    static size_t attr_done[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static size_t attr_done[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipError_t e = hipSuccess;
 #define LAUNCH(IDX, AK, BK_)                                                                                       \
     if (attr_done[IDX] != lds) {                                                                                      \
@@ -1246,18 +1263,22 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
         attr_done[IDX] = lds;                                                                                     \
     }                                                                                                             \
     hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
-#define LAUNCHX(IDX, AK, BK_)                                                                                      \
+#define LAUNCHX(IDX, AK, BK_, WM_)                                                                                 \
     if (attr_done[IDX] != lds) {                                                                                  \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<AK, BK_>),                           \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<AK, BK_, WM_>),                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_f32: LDS attribute: %s", hipGetErrorString(e)); \
         attr_done[IDX] = lds;                                                                                     \
     }                                                                                                             \
-    hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(256), lds, as_stream(s), g)
-    if (x3) {
-        if (akc && bkc) { LAUNCHX(6, true, true); }
-        else if (akc && !bkc) { LAUNCHX(7, true, false); }
-        else { LAUNCHX(8, false, false); }
+    hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_, WM_>), grid, dim3(256), lds, as_stream(s), g)
+    if (x3 && half_tile) {
+        if (akc && bkc) { LAUNCHX(9, true, true, 1); }
+        else if (akc && !bkc) { LAUNCHX(10, true, false, 1); }
+        else { LAUNCHX(11, false, false, 1); }
+    } else if (x3) {
+        if (akc && bkc) { LAUNCHX(6, true, true, 2); }
+        else if (akc && !bkc) { LAUNCHX(7, true, false, 2); }
+        else { LAUNCHX(8, false, false, 2); }
     } else if (bf) {
         if (akc && bkc) { LAUNCH16(3, true, true); }
         else if (akc && !bkc) { LAUNCH16(4, true, false); }

@@ -270,10 +270,26 @@ class A2CNetwork:
         p = K.Plan(bf16=self.mixed_precision)
 
         dhd = ws["dheads"]
+        # Order: the whole dX chain first, then the layer-1 weight gradient -- the largest GEMM and the largest gradient bucket
+        # (flat elements < w_off[1]: 8 of 12 MB for [1024, 512]) -- then the upper layers' and the heads' weight gradients.  With
+        # data parallelism the big bucket is on the wire while ~270 us of GEMMs are still to run, and only the small one is exposed
+        # (the forward order of the weight-gradient GEMMs does not matter: nothing consumes them before the optimiser).
         # heads -> dH_L for both nets in one launch (activation derivative fused)
         p.gemm(dhd, f, ws["dh"][-1], M=m, N=uL, K=hr, lda=2 * ap, ldb=uL, ldc=2 * uL, b_layout=GEMM_OUT_CONTIG, batch=2,
                stride_a=ap, stride_b=hr * uL, stride_c=uL, stride_aux=uL, b_off=self.wh_off, epilogue=egrad, aux=aux[-1],
                ldaux=2 * uL, algo_k=(self.actions_num + 1) / 2.0)
+        for l in range(L - 1, 0, -1):
+            uu, up = u[l], u[l - 1]
+            p.gemm(ws["dh"][l], f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
+                   batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
+                   aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
+        # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
+        uu, k = u[0], self.in_w[0]
+        s1 = self._l0_slabs = K.dw_split(((2 * uu + 127) // 128) * ((k + 127) // 128), S)
+        p.gemm(ws["dh"][0], ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
+               b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=s1, split_stride=P, algo_n=self.in_dim,
+               rowsum=slabs, rowsum_off=self.b_off[0])
+        p.split = len(p.ops)                # everything after this point only touches gradient elements >= w_off[1] (layers 2.., heads)
         # head weight gradients: tiny outputs (2 x [A][uL]) over a long reduction -> split wide into a scratch
         hs, HS = self._head_scratch, self._head_split if m >= 32 * self._head_split else 1
         hb = self.bh_off - self.wh_off                       # the scratch rows mirror the flat layout [head weights | head biases]
@@ -281,35 +297,21 @@ class A2CNetwork:
                b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=ap, stride_b=uL, stride_c=hr * uL, split_k=HS, split_stride=hs.stride(0),
                algo_k=m * (self.actions_num + 1) / (2.0 * hr), rowsum=hs, rowsum_off=hb, stride_rowsum=ap)
         p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), hb + 2 * ap, slabs.data_ptr() + 4 * self.wh_off, 1.0)
-        for l in range(L - 1, -1, -1):
-            uu, k = u[l], self.in_w[l]
-            dz = ws["dh"][l]
-            # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
-            if l == 0:
-                p.split = len(p.ops)        # everything before this point only touches gradient elements >= w_off[1] (layers 2.., heads)
-                s1 = self._l0_slabs = K.dw_split(((2 * uu + 127) // 128) * ((k + 127) // 128), S)
-                p.gemm(dz, ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
-                       b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=s1, split_stride=P, algo_n=self.in_dim,
-                       rowsum=slabs, rowsum_off=self.b_off[0])
-            else:
-                up = u[l - 1]
-                sl = K.dw_split(2 * ((uu + 127) // 128) * ((up + 127) // 128), S)
-                p.gemm(dz, ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
-                       b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],
-                       split_k=sl, split_stride=P, rowsum=slabs, rowsum_off=self.b_off[l], stride_rowsum=uu)
-                p.gemm(dz, f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
-                       batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
-                       aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
+        for l in range(L - 1, 0, -1):
+            uu, up = u[l], u[l - 1]
+            sl = K.dw_split(2 * ((uu + 127) // 128) * ((up + 127) // 128), S)
+            p.gemm(ws["dh"][l], ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
+                   b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],
+                   split_k=sl, split_stride=P, rowsum=slabs, rowsum_off=self.b_off[l], stride_rowsum=uu)
         return p
 
     def backward(self, ws, m, grad_scale=1.0, on_bucket=None):
         """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
         Deterministic: split-K slabs + ordered reduces.
 
-        ``on_bucket(grad_view)``: data-parallel overlap hook.  The backward produces the gradient of the upper layers and the heads
-        (flat elements >= w_off[1], 4.2 of 12 MB for [1024, 512]) before the layer-1 weight-gradient GEMM -- the largest GEMM of
-        the step -- starts; that bucket is reduced and handed over first so its all-reduce runs beside the layer-1 GEMM, the layer-1
-        bucket follows when its GEMM is done."""
+        ``on_bucket(grad_view)``: data-parallel overlap hook.  The plan computes the layer-1 weight gradient (flat elements < w_off[1],
+        8 of 12 MB for [1024, 512]) before the upper layers' and the heads' weight gradients: that bucket is reduced and handed over first
+        so its all-reduce runs beside the remaining GEMMs; the small bucket follows."""
         plan = ws["plan_bwd"]
         if on_bucket is None or len(self.units) < 2:
             plan.run()
@@ -319,10 +321,10 @@ class A2CNetwork:
             return self.grad
         cut = self.w_off[1]
         plan.run(0, plan.split)
-        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat - cut, self.grad, scale=grad_scale, slabs_off=cut, out_off=cut)
-        on_bucket(self.grad[cut:])
-        plan.run(plan.split, None)
         # the layer-1 region [0, cut) holds only the slabs its dW GEMM wrote (the others stay zero): reduce just those
         K.reduce_slabs(self._slabs, getattr(self, "_l0_slabs", self.split_k), self.n_flat, cut, self.grad, scale=grad_scale)
         on_bucket(self.grad[:cut])
+        plan.run(plan.split, None)
+        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat - cut, self.grad, scale=grad_scale, slabs_off=cut, out_off=cut)
+        on_bucket(self.grad[cut:])
         return self.grad

@@ -243,7 +243,9 @@ def _rank_worker(rank, world, port, outdir, overlap=False):
     agent._end_loss_ring()
     th.cuda.synchronize()
     th.save({"before": flat_before.cpu(), "after_setup_rank0_view": None, "pre": pre, "post": post, "flat": agent.model.flat.cpu(),
-             "obs_sum": float(agent.experience_buffer.tensor_dict["obses"].double().sum())}, os.path.join(outdir, f"rank{rank}_{int(overlap)}.pt"))
+             "obs_sum": float(agent.experience_buffer.tensor_dict["obses"].double().sum()),
+             "sums": {k: float(v.double().sum()) for k, v in agent.experience_buffer.tensor_dict.items() if v.is_floating_point()},
+             "adv_sum": float(agent.dataset.values_dict["advantages"].double().sum())}, os.path.join(outdir, f"rank{rank}_{int(overlap)}.pt"))
     agent.dist.barrier()
     agent.dist.shutdown()
 
@@ -251,10 +253,10 @@ def _rank_worker(rank, world, port, outdir, overlap=False):
 def test_two_ranks_share_gpu_gradient_mean_and_identical_parameters(dev):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    port = _free_port()
     with tempfile.TemporaryDirectory() as outdir:
         for overlap in (False, True):
-            procs = [ctx.Process(target=_rank_worker, args=(r, 2, port + int(overlap), outdir, overlap)) for r in range(2)]
+            port = _free_port()                                            # a fresh free port per rendezvous (port + 1 may be taken)
+            procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, outdir, overlap)) for r in range(2)]
             for p in procs:
                 p.start()
             for p in procs:
@@ -265,7 +267,12 @@ def test_two_ranks_share_gpu_gradient_mean_and_identical_parameters(dev):
     # overlapped path (two gradient buckets all-reduced asynchronously beside the layer-1 weight-gradient GEMM): six bucket calls,
     # the same parameters, bit for bit, as the single blocking all-reduce
     assert len(o0["pre"]) == 6 and o0["pre"][0].numel() + o0["pre"][1].numel() == r0["pre"][0].numel()
-    assert torch.equal(o0["flat"], o1["flat"]) and torch.equal(o0["flat"], r0["flat"])
+    assert torch.equal(o0["flat"], o1["flat"]), "overlapped path: parameters diverged across ranks"
+    d = (o0["flat"] - r0["flat"]).abs()
+    assert torch.equal(o0["flat"], r0["flat"]), (f"overlapped vs blocking parameters differ: {int((d > 0).sum())} of {d.numel()} elements, max |diff| {d.max().item():.3e}, "
+                                                  f"first at {int(torch.nonzero(d > 0)[0])}; rollout sums equal: {({k: r0['sums'][k] == o0['sums'][k] for k in r0['sums']})}, "
+                                                  f"advantages equal: {r0['adv_sum'] == o0['adv_sum']}; local gradients equal per step: "
+                                                  f"{[bool(torch.equal(torch.cat([o0['pre'][2 * i], o0['pre'][2 * i + 1]]), r0['pre'][i])) for i in range(3)]}")
     assert not torch.equal(r0["before"], r1["before"])                      # ranks started from different weights ...
     assert abs(r0["obs_sum"] - r1["obs_sum"]) > 1e-3                        # ... and own different env shards
     assert len(r0["pre"]) == len(r1["pre"]) == 3

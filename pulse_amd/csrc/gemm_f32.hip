@@ -778,8 +778,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs g) {
 // 8 elements of A and 8 of B are split (about 44 VALU each, spread over the first MFMAs of the tile), 6 ds_write_b128, 12
 // ds_read_b128 (next tile's fragments, second register set), 24 MFMAs.  Global loads: reduction-contiguous operands 2 x 16 B per
 // thread (two lanes per row), [red][out] operands 8 dwords per thread (lane = out: no register transpose).  The buffer resources
-// carry the true extent, so rows / k positions outside the operand read as zero in hardware: no address clamps, and the k tail needs
-// only a compare-and-zero in the tile that stages the last k-tile.
+// carry the operand's true extent, so loads the hardware range check catches (rows / outs past the operand, k rows past its end) return
+// zero without touching memory and no address is clamped.  Correctness does not lean on the check: the k tail is zeroed by a compare in the
+// tile that stages the last k-tile, and rows / outs beyond the extent only feed outputs that are never stored.
 // =====================================================================================================================
 constexpr int XK = 16;
 constexpr int X_CSTRIDE = 136;                       // 16-byte slots per 8-k chunk block
@@ -898,7 +899,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     long long dbg_c0 = 0, dbg_w0 = 0, dbg_c1 = 0, dbg_w1 = 0;
     if (g.dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
 
-    // buffer resources with the TRUE extent from this workgroup's origin: anything outside reads as zero (no memory access)
+    // buffer resources with the TRUE extent from this workgroup's origin: what the range check catches reads as zero (no memory access)
     const int extA = min(BMx, g.M - m0), extB = min(BN, g.N - n0);
     const int k4rem = ((g.K + 3) & ~3) - kbeg;                   // readable k positions of a reduction-contiguous row from kbeg
     const float* Ab = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);

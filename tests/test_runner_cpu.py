@@ -58,3 +58,19 @@ def test_config_surface_matches_reference_yaml():
         assert k in mine["config"], k
         if isinstance(v, (int, float, bool)):
             assert float(mine["config"][k]) == float(v), (k, mine["config"][k], v)
+
+
+def test_dw_split_picks_the_fewest_slabs_that_fill_the_chip():
+    """kernels.dw_split: host logic of the per-layer batch split of the weight-gradient GEMMs (no GPU needed)."""
+    from pulse_amd.kernels import dw_split
+    assert dw_split(128, 8) == 4          # cfg2 layer 1: 16 x 8 tiles -> 4 slabs = 512 workgroups
+    assert dw_split(64, 8) == 8           # cfg2 layer 2 (2 nets x 4 x 8 tiles): all 8 slabs = 512 workgroups
+    assert dw_split(4096, 8) == 1         # a huge layer needs no batch split at all
+    assert dw_split(1, 8) == 8 and dw_split(1, 1) == 1
+    assert dw_split(200, 6) == 3          # odd slab counts only halve while they stay even
+    for tiles in (1, 7, 64, 100, 128, 500, 5000):
+        for s in (1, 2, 4, 8, 16):
+            d = dw_split(tiles, s)
+            assert 1 <= d <= s and s % d == 0
+            assert d == s or tiles * d >= 512                      # never below the fill target unless the maximum is
+            assert d == 1 or d % 2 or tiles * (d // 2) < 512       # and never more slabs than needed

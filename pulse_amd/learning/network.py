@@ -204,7 +204,7 @@ class A2CNetwork:
         if ws is not None:
             return ws
         dev, u = self.device, self.units
-        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        e = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)     # one-time allocations: defined contents from the start
         ws = {"x": e(m, self.in_pitch), "h": [e(m, 2 * uu) for uu in u], "heads": torch.zeros(m, 2 * self.a_pitch, device=dev)}
         ws["mu"] = ws["heads"][:, :self.actions_num]                        # (m, A) view, row pitch 2*a_pitch
         ws["val"] = ws["heads"][:, self.a_pitch:self.a_pitch + 1]           # (m, 1) view

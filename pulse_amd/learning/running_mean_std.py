@@ -80,7 +80,7 @@ class RunningMeanStd:
     def _moment_buffer(self, rows):
         nblk = max(1, min(512, rows // 16))
         if self._partials is None or self._partials.shape[0] != nblk:
-            self._partials = torch.empty(nblk, 2, self.mean_size, dtype=torch.float64, device=self.device)
+            self._partials = torch.zeros(nblk, 2, self.mean_size, dtype=torch.float64, device=self.device)
         return self._partials
 
     def forward(self, input, unnorm=False, *, row_idx=None, out=None, out_cols=None, update=None, norm_with=None):

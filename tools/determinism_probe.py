@@ -48,10 +48,11 @@ def poison_empty():
     torch.Tensor.new_empty = lambda self, *a, **k: fill(orig_new(self, *a, **k))
 
 
-def one_run(seed, config, poison=False):
+def one_run(seed, config, poison=False, dump=None):
     import torch
     if poison:
         poison_empty()
+    saved = {}
     from pulse_amd import configs
     torch.manual_seed(1000)
     agent, _ = configs.make_agent(config, device="cuda:0", seed=seed, permutation_device="cpu")
@@ -63,6 +64,9 @@ def one_run(seed, config, poison=False):
     sim = task.sim
 
     def env_stage(tag):
+        if dump:
+            saved[f"{tag}/obs_buf"] = task.obs_buf.detach().cpu().clone()
+            saved[f"{tag}/rew_buf"] = task.rew_buf.detach().cpu().clone()
         out[f"{tag}/obs_buf"] = digest(task.obs_buf)
         for name in ("rigid_body_state", "dof_pos", "dof_vel"):
             if hasattr(sim, name):
@@ -88,7 +92,33 @@ def one_run(seed, config, poison=False):
         out[f"step{i}/flat"] = digest(agent.model.flat) + (f"!nan{int(torch.isnan(agent.model.flat).sum())}" if torch.isnan(agent.model.flat).any() else "")
     agent._end_loss_ring()
     torch.cuda.synchronize()
+    if dump:
+        torch.save(saved, dump)
     return out
+
+
+def locate(dump_dir, repeats):
+    """Where do the saved env-stage tensors of run 0 and the other runs differ?  Rows (envs), columns and magnitudes."""
+    import torch
+    runs = [torch.load(os.path.join(dump_dir, f"run{i}.pt")) for i in range(repeats)]
+    for key in runs[0]:
+        for i in range(1, repeats):
+            a, b = runs[0][key].double(), runs[i][key].double()
+            d = (a - b).abs()
+            neq = (a != b) & ~(torch.isnan(a) & torch.isnan(b))
+            if not bool(neq.any()):
+                bits = not torch.equal(runs[0][key].view(torch.int32), runs[i][key].view(torch.int32)) if runs[0][key].dtype == torch.float32 else False
+                if bits:
+                    print(f"  {key}: run 0 vs {i}: numerically equal, BIT patterns differ (signed zeros / NaN payloads)")
+                continue
+            if a.dim() == 2:
+                rows = torch.nonzero(neq.any(dim=1)).flatten().tolist()
+                cols = torch.nonzero(neq.any(dim=0)).flatten().tolist()
+                print(f"  {key}: run 0 vs {i}: {int(neq.sum())} entries, max |diff| {d[neq].max().item():.3e}, rows {rows[:12]}{'...' if len(rows) > 12 else ''} "
+                      f"({len(rows)}), columns {cols[:24]}{'...' if len(cols) > 24 else ''} ({len(cols)})")
+            else:
+                idx = torch.nonzero(neq.flatten()).flatten().tolist()
+                print(f"  {key}: run 0 vs {i}: {int(neq.sum())} entries, max |diff| {d[neq].max().item():.3e}, at {idx[:24]}")
 
 
 def hammer(stop):
@@ -111,11 +141,13 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--contend", action="store_true", help="run a second process that keeps the GPU busy with GEMMs")
     ap.add_argument("--poison", action="store_true", help="fill every torch.empty allocation with NaN: uninitialised reads become visible")
+    ap.add_argument("--dump", default=None, help="directory: every repeat saves its env-stage tensors there and the differing entries are located")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--child-dump", default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.child:
         import json
-        print("DIGESTS " + json.dumps(one_run(a.seed, a.config, a.poison)), flush=True)
+        print("DIGESTS " + json.dumps(one_run(a.seed, a.config, a.poison, a.child_dump)), flush=True)
         return 0
     proc = stop = None
     if a.contend:
@@ -127,8 +159,11 @@ def main():
         import json
         import subprocess
         runs = []
-        for _ in range(a.repeats):
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--config", a.config, "--seed", str(a.seed)] + (["--poison"] if a.poison else []),
+        if a.dump:
+            os.makedirs(a.dump, exist_ok=True)
+        for rep in range(a.repeats):
+            extra = (["--poison"] if a.poison else []) + (["--child-dump", os.path.join(a.dump, f"run{rep}.pt")] if a.dump else [])
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--config", a.config, "--seed", str(a.seed)] + extra,
                                capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")]
             if r.returncode != 0 or not line:
@@ -144,6 +179,8 @@ def main():
         vals = [r[k] for r in runs]
         print(f"{'DIFF' if k in bad else 'ok  '} {k:28s} {' '.join(vals)}")
     print(f"{len(bad)} of {len(keys)} stages differ across {a.repeats} runs" + (f"; first: {bad[0]}" if bad else ""))
+    if a.dump:
+        locate(a.dump, a.repeats)
     return 1 if bad else 0
 
 

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 11
+#define PULSE_ABI_VERSION 12
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -101,6 +101,7 @@ typedef struct pulse_reward_specs {
 #define PULSE_IM_TASK_OBS 2u  /* compute_imitation_observations_v6 / _v7, humanoid_im.py:1328-1413 */
 #define PULSE_IM_REWARD   4u  /* compute_imitation_reward (+ power term), humanoid_im.py:853-919,1543-1574 */
 #define PULSE_IM_RESET    8u  /* compute_humanoid_im_reset, humanoid_im.py:1119-1192,1600-1628 */
+#define PULSE_IM_DEBUG_POISON_LDS 0x80000000u /* debug: the kernel pre-fills its LDS with NaN (uninitialised-read detector) */
 
 typedef struct pulse_im_step_args {
     /* ---- simulation state (read) ---- */
@@ -195,11 +196,23 @@ typedef struct pulse_im_step_args {
     float traj_dt;
     float* track_rb; int64_t track_rb_stride;   /* (num_envs, J, 13) */
     float* track_dof_pos; float* track_dof_vel; /* (num_envs, (J-1)*3) */
+
+    /* ---- optional: shape / limb-weight rows appended to the self observation (humanoid.py:1724-1728, 1843-1847: has_smpl_params /
+       has_limb_weight_params; self_obs_version 1 and 3 -- the reference's _v2 raises for them): (num_envs, width) each, row stride given */
+    const float* smpl_params; int32_t smpl_params_width; int64_t smpl_params_stride;
+    const float* limb_weights; int32_t limb_weights_width; int64_t limb_weights_stride;
+    /* ---- optional: HumanoidImGetup._compute_reset (humanoid_im_getup.py:203-210) folded into the reset stage: envs whose
+       recovery_counter is > 0 neither reset nor terminate and their progress does not advance (the value written back to
+       progress_rw is p - 1, and the observation stage runs on that clock, as in the reference where _compute_observations follows
+       the decrement, humanoid.py:1325-1328).  Needs progress_rw; only read when ``what`` includes PULSE_IM_RESET. */
+    const int32_t* recovery_counter;
 } pulse_im_step_args;
 
 /* sizeof(pulse_im_step_args) as compiled, so a foreign-language binding can verify its mirror */
 int pulse_sizeof_im_step_args(void);
-/* width of the self / task observation for the given options (self_obs_version 1; _ex covers versions 2 / 3) */
+/* width of the self / task observation for the given options (self_obs_version 1; _ex covers versions 2 / 3 and appended rows:
+   its last argument is the TOTAL width of the rows appended to the self observation -- force sensors (version 3) + shape + limb-weight
+   parameters; ignored for version 2) */
 int pulse_self_obs_width(int num_bodies, int root_height_obs);
 int pulse_self_obs_width_ex(int num_bodies, int root_height_obs, int self_obs_version, int hist_steps, int force_sensor_width);
 int pulse_task_obs_width(int obs_version, int num_track, int time_steps);

@@ -154,7 +154,7 @@ def im_obs_variant(version, root_pos, root_rot, body_pos, body_rot, body_vel, bo
 
 
 def self_obs_smpl_max_general(body_pos, body_rot, body_vel, body_ang_vel, local_root_obs=True, root_height_obs=True, upright=True,
-                              force_sensor=None):
+                              force_sensor=None, smpl_params=None, limb_weight_params=None):
     """compute_humanoid_observations_smpl_max with ``upright`` False (humanoid.py:1675-1731: heading AND the non-local root 6-D block
     from remove_base_rot(root)) and _max_v3 (:1789-1849: the same with the force-sensor readings appended)."""
     n, j, _ = body_pos.shape
@@ -172,6 +172,10 @@ def self_obs_smpl_max_general(body_pos, body_rot, body_vel, body_ang_vel, local_
     parts += [loc_pos, rot6, loc_vel, loc_ang]
     if force_sensor is not None:
         parts.append(force_sensor)
+    if smpl_params is not None:               # has_smpl_params, then has_limb_weight_params (humanoid.py:1724-1728, 1843-1847)
+        parts.append(smpl_params)
+    if limb_weight_params is not None:
+        parts.append(limb_weight_params)
     return torch.cat(parts, dim=-1)
 
 

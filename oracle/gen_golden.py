@@ -194,6 +194,25 @@ def gen_env_variants(n=19):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "env_variants.npz"), **_np(out))
 
 
+def gen_env_shape_obs(n=19):
+    """Shape / limb-weight rows of the self observation (has_smpl_params / has_limb_weight_params, humanoid.py:1724-1728, 1843-1847;
+    enabled by robot has_shape_obs / has_weight_obs in the phc_shape_* configs)."""
+    fn = refload.env_functions()
+    g = syn.make_generator(4242)
+    rb = syn.rigid_body_state(g, n)
+    bp, br, bv, ba = rb[..., 0:3].clone(), rb[..., 3:7].clone(), rb[..., 7:10].clone(), rb[..., 10:13].clone()
+    shapes = torch.randn(n, 11, generator=g)
+    limbs = torch.rand(n, 10, generator=g) + 0.5
+    fs = torch.randn(n, 12, generator=g)
+    out = {"rb": rb, "smpl_params": shapes, "limb_weights": limbs, "force_sensor": fs}
+    for up in (True, False):
+        tag = "" if up else "_noup"
+        for hs, hl, name in ((True, True, "both"), (True, False, "shape"), (False, True, "limb")):
+            out[f"self_obs_{name}{tag}"] = fn["compute_humanoid_observations_smpl_max"](bp, br, bv, ba, shapes, limbs, True, True, up, hs, hl)
+        out[f"self_obs_v3_both{tag}"] = fn["compute_humanoid_observations_smpl_max_v3"](bp, br, bv, ba, fs, shapes, limbs, True, True, up, True, True)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "env_shape_obs.npz"), **_np(out))
+
+
 def gen_env_amp(n=67):
     """AMP per-frame observation from the reference's build_amp_observations_smpl (+ dof_to_obs_smpl)."""
     fn = refload.env_functions()
@@ -387,6 +406,7 @@ def main():
     gen_env_im()
     gen_env_amp()
     gen_env_variants()
+    gen_env_shape_obs()
     gen_agent_math()
     gen_rms()
     gen_motion_lib()

@@ -10,8 +10,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 11
+# PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
+LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
+ABI_VERSION = 12
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -59,6 +60,9 @@ class ImStepArgs(Structure):
         ("cycle_motion", c_int32), ("max_episode_length", c_int32), ("pass_time_out", c_void_p),
         ("use_motion", c_int32), ("motion", MotionTables), ("motion_ids", c_void_p), ("motion_offset", c_void_p), ("traj_dt", c_float),
         ("track_rb", c_void_p), ("track_rb_stride", c_int64), ("track_dof_pos", c_void_p), ("track_dof_vel", c_void_p),
+        ("smpl_params", c_void_p), ("smpl_params_width", c_int32), ("smpl_params_stride", c_int64),
+        ("limb_weights", c_void_p), ("limb_weights_width", c_int32), ("limb_weights_stride", c_int64),
+        ("recovery_counter", c_void_p),
     ]
 
 

@@ -21,7 +21,16 @@ ARCH = "gfx950"
 
 # (source, extra flags).  The parity-critical elementwise kernels are built without FMA
 # contraction so sums/products round like the eager PyTorch reference.
+#
+# EVERY translation unit is built with -fno-slp-vectorize, and the build fails if a packed-fp32 VALU instruction (v_pk_mul_f32 /
+# v_pk_add_f32 / v_pk_fma_f32) shows up in the device code anyway.  Round 3 finding (tools/im_step_repro.py):
+# on gfx950 / ROCm 7.2 those instructions return WRONG values in the last quarter of the wave (lanes 48-63) while a wave of another
+# kernel issues MFMAs on the same SIMD -- the fused env step (632 of them after SLP vectorisation) gave observation rows that
+# differed by O(1) from launch to launch on identical inputs whenever a second process ran GEMMs on the GPU, and was bit-stable
+# alone, beside a VALU / copy competitor, at -O1, or with SLP vectorisation off.  Scalar fp32 VALU code is not affected.
 NO_CONTRACT = ["-ffp-contract=off"]
+NO_PACKED_F32 = ["-fno-slp-vectorize", "-fno-vectorize"]      # SLP and loop vectoriser both form <2 x float> arithmetic
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 SOURCES = [
     ("capi.cpp", []),
     ("rot_ops.hip", NO_CONTRACT),
@@ -33,7 +42,7 @@ SOURCES = [
     ("gae.hip", NO_CONTRACT),
     # MFMA accumulators in VGPR form: no v_accvgpr moves (VALU slots are what the fp32 MFMA loop is short of) and the
     # whole kernel fits the 256-register budget of two waves per SIMD
-    ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]),   # packed-f32 VALU (v_pk_add_f32) beside MFMAs costs more than two plain adds
+    ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),   # (packed-f32 VALU beside MFMAs also costs more than two plain adds)
     ("learner_ops.hip", NO_CONTRACT),
 ]
 
@@ -43,6 +52,21 @@ def hipcc():
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
             return cand
     raise RuntimeError("hipcc not found")
+
+
+def packed_f32_instructions(obj):
+    """Disassemble the gfx950 code object embedded in a host object and return its packed-fp32 arithmetic instructions (must be none)."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat"), os.path.join(tmp, "co")
+        r = subprocess.run([f"{LLVM_BIN}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(fat):
+            return []                                           # host-only object (capi.cpp)
+        subprocess.run([f"{LLVM_BIN}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}",
+                        f"--input={fat}", f"--output={co}"], check=True, capture_output=True)
+        dis = subprocess.run([f"{LLVM_BIN}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    return re.findall(r"\bv_pk_(?:mul|add|fma)_f32\b[^\n]*", dis)
 
 
 def _newer(a, b):
@@ -55,7 +79,7 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(INCLUDE, "pulse_hip.h"))
     headers.append(os.path.abspath(__file__))
     common = ["-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
-              "-Wno-unused-function", f"-I{INCLUDE}", f"-I{HERE}"]
+              "-Wno-unused-function", f"-I{INCLUDE}", f"-I{HERE}"] + NO_PACKED_F32
     jobs = []
     objs = []
     for src, extra in SOURCES:
@@ -80,6 +104,11 @@ def build(force=False, verbose=False):
                 print(f"--- {name} ---\n{out}", flush=True)
             if rc != 0:
                 raise RuntimeError(f"hipcc failed on {name}")
+    for o in objs:
+        bad = packed_f32_instructions(o)
+        if bad:
+            raise RuntimeError(f"{os.path.basename(o)}: {len(bad)} packed-fp32 VALU instructions in the device code (e.g. {bad[0].strip()}); "
+                               "they are unsafe beside MFMA waves on gfx950 (see the note at the top of build.py)")
     if jobs or force or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):
         cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

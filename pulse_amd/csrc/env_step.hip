@@ -48,7 +48,7 @@ __host__ __device__ inline ObsLayout make_layout(int J, int root_height_obs, int
     L.off_vel = L.off_rot + 6 * J;
     L.off_ang = L.off_vel + 3 * J;
     L.self_step = L.off_ang + 3 * J;
-    L.self_w = self_v == 2 ? L.self_step * hist : self_v == 3 ? L.self_step + fs_w : L.self_step;
+    L.self_w = self_v == 2 ? L.self_step * hist : L.self_step + fs_w;      // fs_w: every appended row (force sensors, shape, limb weights)
     L.per_t = task_per_t(obs_version, Jt);
     L.task_w = L.per_t * T;
     return L;
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     const int nd = a.num_dof;
     const int J13p = (J13 + 3) & ~3;          // keep every LDS segment 16-byte aligned
     const int ndp = (nd + 3) & ~3;
-    const int colsp = (a.obs_cols + 3) & ~3;
+    const int colsp = (a.what & (PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)) ? ((a.obs_cols + 3) & ~3) : 0;   // as the host sizes the launch
     // LDS carve-up (floats); every base a multiple of 4 floats
     float* s_rb = smem;                        // [E][J13p]
     float* s_rn = s_rb + E * J13p;             // [E][J13p]   ref at t   : pos|rot|vel|ang
@@ -114,6 +114,11 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     float* s_rd = s_obs + E * colsp;           // [E][ndp]    reference dof positions (obs_version 2 only)
 
     const int tid = threadIdx.x;
+    if (a.what & PULSE_IM_DEBUG_POISON_LDS) {      // debug aid: a read of LDS nobody wrote shows up as NaN in the outputs
+        const int total = E * ((2 + T) * J13p + 3 * ndp + colsp);
+        for (int i = tid; i < total; i += E * kLanesPerEnv) smem[i] = __int_as_float(0x7fc00000);
+        __syncthreads();
+    }
     const int slot = tid / kLanesPerEnv;
     const int lane = tid % kLanesPerEnv;
     const int count = a.env_ids ? a.num_ids : a.num_envs;
@@ -145,13 +150,20 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
         }
     }
 
+    // HumanoidImGetup._compute_reset (humanoid_im_getup.py:203-210): a recovering env's clock does not advance -- reward and the reset
+    // test use p, the value written back and the observation stage use p - 1
+    const bool recovering = valid && (a.what & PULSE_IM_RESET) && a.recovery_counter && a.recovery_counter[e] > 0;
+    const long long prog_obs = prog - (recovering ? 1 : 0);
     const bool do_self = a.what & PULSE_IM_SELF_OBS;
     const bool do_task = a.what & PULSE_IM_TASK_OBS;
     const bool do_rew = a.what & PULSE_IM_REWARD;
     const bool do_rst = a.what & PULSE_IM_RESET;
     const bool need_now = do_rew || do_rst;
     const int H = a.self_obs_version == 2 ? a.hist_steps : 1;
-    const ObsLayout L = make_layout(J, a.root_height_obs, a.obs_version, a.num_track, T, a.self_obs_version, H, a.force_sensor_width);
+    // rows appended to the self observation: force-sensor readings (version 3), then shape, then limb-weight parameters
+    const int fs_w = a.self_obs_version == 3 ? a.force_sensor_width : 0;
+    const int app_w = fs_w + (a.smpl_params ? a.smpl_params_width : 0) + (a.limb_weights ? a.limb_weights_width : 0);
+    const ObsLayout L = make_layout(J, a.root_height_obs, a.obs_version, a.num_track, T, a.self_obs_version, H, app_w);
 
     float* rb_e = s_rb + slot * J13p;
     float* rn_e = s_rn + slot * J13p;
@@ -186,7 +198,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
             }
             if (do_task) {
                 for (int k = 0; k < T; ++k) {
-                    float t = (float)(prog + 1) * a.clock_dt;             // humanoid_im.py:723-731 (next frame, so +1)
+                    float t = (float)(prog_obs + 1) * a.clock_dt;         // humanoid_im.py:723-731 (next frame, so +1)
                     if (T > 1) t = t + (float)k * a.traj_dt;
                     if (a.clock_start_times) t = t + a.clock_start_times[e];
                     if (a.clock_start_offsets) t = t + a.clock_start_offsets[e];
@@ -264,7 +276,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     // ---------------- per-(env, body) math ----------------
     if (valid) {
         if (lane == 0) {                                   // every lane of this env read the old value before the barrier
-            if (a.progress_rw) a.progress_rw[e] = prog;
+            if (a.progress_rw) a.progress_rw[e] = prog_obs;
             if (a.pass_time_out) a.pass_time_out[e] = pass_time ? 1 : 0;
         }
         const V3 root_p{rb_e[0], rb_e[1], rb_e[2]};
@@ -309,6 +321,12 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
             if (a.self_obs_version == 3)                            // force-sensor readings appended (humanoid.py:1838)
                 for (int c = lane; c < a.force_sensor_width; c += kLanesPerEnv)
                     obs_e[L.self_step + c] = a.force_sensor[e * a.force_sensor_width + c];
+            if (a.smpl_params)                                      // has_smpl_params, then has_limb_weight_params (humanoid.py:1724-1728)
+                for (int c = lane; c < a.smpl_params_width; c += kLanesPerEnv)
+                    obs_e[L.self_step + fs_w + c] = a.smpl_params[e * a.smpl_params_stride + c];
+            if (a.limb_weights)
+                for (int c = lane; c < a.limb_weights_width; c += kLanesPerEnv)
+                    obs_e[L.self_step + fs_w + (a.smpl_params ? a.smpl_params_width : 0) + c] = a.limb_weights[e * a.limb_weights_stride + c];
         }
 
         if (do_task && lane < a.num_track) {
@@ -424,6 +442,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                 int64_t term = (a.enable_early_termination && fallen && prog > 1) ? 1 : 0;
                 int64_t rst = pt ? 1 : term;
                 if (a.cycle_counter && !pt && a.cycle_counter[e] > 0) { rst = 0; term = 0; }
+                if (recovering) { rst = 0; term = 0; }
                 a.reset[e] = rst;
                 a.terminate[e] = term;
             }
@@ -458,7 +477,7 @@ int pulse_self_obs_width(int num_bodies, int root_height_obs) {
     return make_layout(num_bodies, root_height_obs, 6, 0, 1).self_w;
 }
 int pulse_self_obs_width_ex(int num_bodies, int root_height_obs, int self_obs_version, int hist_steps, int force_sensor_width) {
-    return make_layout(num_bodies, root_height_obs, 6, 0, 1, self_obs_version, hist_steps, force_sensor_width).self_w;
+    return make_layout(num_bodies, root_height_obs, 6, 0, 1, self_obs_version, hist_steps, self_obs_version == 2 ? 0 : force_sensor_width).self_w;
 }
 int pulse_task_obs_width(int obs_version, int num_track, int time_steps) {
     return make_layout(1, 0, obs_version, num_track, time_steps).task_w;
@@ -469,7 +488,7 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
     const pulse_im_step_args& a = *args;
     PULSE_REQUIRE(a.num_envs >= 0, "pulse_im_step: negative num_envs");
     const int count = a.env_ids ? a.num_ids : a.num_envs;
-    if (count == 0 || a.what == 0) return PULSE_OK;
+    if (count == 0 || (a.what & 15u) == 0) return PULSE_OK;
     PULSE_REQUIRE(a.rb != nullptr, "pulse_im_step: null rb");
     PULSE_REQUIRE(a.num_bodies >= 1 && a.num_bodies <= kLanesPerEnv, "pulse_im_step: num_bodies %d not in [1,32]", a.num_bodies);
     PULSE_REQUIRE(a.rb_env_stride >= (int64_t)a.num_bodies * 13, "pulse_im_step: rb_env_stride too small");
@@ -480,8 +499,13 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
     PULSE_REQUIRE(hist >= 1, "pulse_im_step: hist_steps < 1");
     PULSE_REQUIRE(a.rb_env_stride >= (int64_t)hist * a.num_bodies * 13, "pulse_im_step: rb_env_stride does not cover the history");
     PULSE_REQUIRE(a.self_obs_version != 3 || (a.force_sensor != nullptr && a.force_sensor_width >= 0), "pulse_im_step: self_obs_version 3 needs force_sensor");
-    const ObsLayout L = make_layout(a.num_bodies, a.root_height_obs, a.obs_version, a.num_track, a.time_steps, a.self_obs_version, hist,
-                                    a.force_sensor_width);
+    PULSE_REQUIRE((a.smpl_params == nullptr && a.limb_weights == nullptr) || a.self_obs_version != 2,
+                  "pulse_im_step: shape / limb-weight rows are not defined for self_obs_version 2 (the reference raises, humanoid.py:1780-1784)");
+    PULSE_REQUIRE((!a.smpl_params || (a.smpl_params_width >= 0 && a.smpl_params_stride >= a.smpl_params_width)) &&
+                  (!a.limb_weights || (a.limb_weights_width >= 0 && a.limb_weights_stride >= a.limb_weights_width)), "pulse_im_step: bad shape / limb-weight rows");
+    PULSE_REQUIRE(a.recovery_counter == nullptr || a.progress_rw != nullptr, "pulse_im_step: recovery_counter needs the in-kernel clock (progress_rw)");
+    const int app_w = (a.self_obs_version == 3 ? a.force_sensor_width : 0) + (a.smpl_params ? a.smpl_params_width : 0) + (a.limb_weights ? a.limb_weights_width : 0);
+    const ObsLayout L = make_layout(a.num_bodies, a.root_height_obs, a.obs_version, a.num_track, a.time_steps, a.self_obs_version, hist, app_w);
     if (do_obs) {
         PULSE_REQUIRE(a.obs != nullptr, "pulse_im_step: null obs");
         PULSE_REQUIRE(a.obs_cols >= L.self_w + ((a.what & PULSE_IM_TASK_OBS) ? L.task_w : 0),

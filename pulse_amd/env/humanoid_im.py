@@ -93,8 +93,13 @@ class HumanoidIm:
         lib = ops._lib.load()
         self._force_sensor_width = 6 * len(self.force_sensor_joints) if self.self_obs_v == 3 else 0     # humanoid.py:666-667
         self._hist_steps = self.past_track_steps + 1 if self.self_obs_v == 2 else 1                     # humanoid.py:502-503
+        # shape / limb-weight observation rows (robot has_shape_obs / has_weight_obs, humanoid.py:266-268, 657-661: + 11 / + 10 columns)
+        self._has_shape_obs = bool(env.get("has_shape_obs", False))
+        self._has_limb_weight_obs = bool(env.get("has_weight_obs", False))
+        if (self._has_shape_obs or self._has_limb_weight_obs) and self.self_obs_v == 2:
+            raise NotImplementedError("the reference raises for shape / limb-weight observations with self_obs_v 2 (humanoid.py:1780-1784)")
         self._self_obs_size = lib.pulse_self_obs_width_ex(self.num_bodies, int(self._root_height_obs), self.self_obs_v, self._hist_steps,
-                                                          self._force_sensor_width)
+                                                          self._force_sensor_width + 11 * self._has_shape_obs + 10 * self._has_limb_weight_obs)
         jt = self._track_bodies_id.numel()
         self._task_obs_size = lib.pulse_task_obs_width(self.obs_v, jt, self._num_traj_samples)
         self.num_obs = self._self_obs_size + self._task_obs_size
@@ -120,6 +125,15 @@ class HumanoidIm:
         self._force_sensor = (getattr(sim, "force_sensor", None) if self.self_obs_v == 3 else None)
         if self.self_obs_v == 3 and self._force_sensor is None:
             self._force_sensor = torch.zeros(n, self._force_sensor_width, device=dev)
+        # humanoid_shapes (N, 17) = [gender, 10 betas, 6 unused] and humanoid_limb_and_weights (N, 10) are filled while the robot assets are
+        # built (humanoid.py:739-878: smpl_sim, out of scope); the sim stand-in may provide them, otherwise a fixed synthetic draw per env
+        if self._has_shape_obs or self._has_limb_weight_obs:
+            g = torch.Generator().manual_seed(int(env.get("shape_seed", 99)))
+            shapes = getattr(sim, "humanoid_shapes", None)
+            limbs = getattr(sim, "humanoid_limb_and_weights", None)
+            self.humanoid_shapes = (shapes if shapes is not None else torch.cat([torch.randint(0, 2, (n, 1), generator=g).float(),
+                                                                                torch.randn(n, 16, generator=g)], dim=1)).to(dev).contiguous()
+            self.humanoid_limb_and_weights = (limbs if limbs is not None else torch.rand(n, 10, generator=g) + 0.5).to(dev).contiguous()
         self._motion_len_env = motion_lib._motion_lengths
         if self._use_motion_lib:
             self._init_motion_clock(env)
@@ -346,6 +360,13 @@ class HumanoidIm:
             extra["force_sensor"] = self._force_sensor
         if self.obs_v == 2:
             extra["dof_pos"] = self.sim.dof_pos
+        if self._has_shape_obs:
+            extra["smpl_params"] = self.humanoid_shapes[:, :-6]          # body_shape_params, humanoid.py:1170
+        if self._has_limb_weight_obs:
+            extra["limb_weights"] = self.humanoid_limb_and_weights
+        rc = self._recovery_counter_for_step()
+        if rc is not None:
+            extra["recovery_counter"] = rc
         return ops.im_step(
             rb, what=what, ref_now=ref_now, ref_next=ref_next, upright=self._has_upright_start,
             enable_early_termination=self._enable_early_termination, self_obs_version=self.self_obs_v, **extra,
@@ -357,6 +378,10 @@ class HumanoidIm:
             power_coef=self.power_coefficient, power_reward=self.power_reward, env_ids=env_ids, env_mask=env_mask,
             obs=self._obs_store, obs_cols=self.obs_pitch, rew=self.rew_buf, rew_raw=self.reward_raw,
             reset=self.reset_buf, terminate=self._terminate_buf, clock=clock, motion=motion)
+
+    def _recovery_counter_for_step(self):
+        """HumanoidImGetup hands its recovery counter to the fused step (its _compute_reset, humanoid_im_getup.py:203-210); None here."""
+        return None
 
     def _cycle_motion_update(self):
         """humanoid_im.py:1125-1146 (cycle_motion, neither cycle_motion_xp nor zero_out_far): envs whose motion time ran past the clip

@@ -10,9 +10,8 @@ Mirrors phc/env/tasks/humanoid_im_getup.py:42-210 (the env PULSE is distilled in
                                    from a fall state (same grace); the others get the ordinary reference-state init
   _compute_reset          :203-210 envs in recovery neither reset nor terminate and their progress does not advance
   _init_amp_obs           :189-196 fall starts fill the AMP history with the current frame (_init_amp_obs_default)
-Everything is masked tensor code (no ``nonzero()`` read-backs).  One deliberate simplification: env e takes fall state e (the
-reference draws a random FREE state id, :171-183); the bank is i.i.d. random, so only the pairing differs, and no state is ever
-shared by two envs either way.
+Everything is masked tensor code (no ``nonzero()`` read-backs).  Fall starts take a random state of the bank through a fresh
+permutation per reset (the reference draws random FREE state ids, :171-183: no state is shared by two envs either way).
 """
 import torch
 
@@ -76,14 +75,11 @@ class HumanoidImGetup(HumanoidIm):
         super().pre_physics_step(actions)
         self._recovery_counter.sub_(1).clamp_(min=0)                                              # _update_recovery_count (:198-201)
 
-    def post_physics_step(self):
-        super().post_physics_step()
-        # _compute_reset (:203-210), applied to the buffers the fused step just wrote
-        rec = self._recovery_counter > 0
-        keep = (~rec).to(self.reset_buf.dtype)
-        self.reset_buf.mul_(keep)
-        self._terminate_buf.mul_(keep)
-        self.progress_buf.sub_(rec.to(self.progress_buf.dtype))
+    def _recovery_counter_for_step(self):
+        # _compute_reset (:203-210) runs INSIDE the fused step: envs in recovery neither reset nor terminate, their progress does not
+        # advance and -- because the reference decrements progress before _compute_observations (humanoid.py:1325-1328) -- their next
+        # observation targets the frame of the frozen clock
+        return self._recovery_counter
 
     # ------------------------------------------------------------------ :137-196 for the masked envs
     def reset_masked(self, mask):
@@ -98,7 +94,12 @@ class HumanoidImGetup(HumanoidIm):
         super().reset_masked(normal)
         both = recovery | fall
         if hasattr(self.sim, "set_env_states_masked"):
-            self.sim.set_env_states_masked(fall, self._fall_state)
+            # a random FREE fall state per env (_reset_fall_episode, :171-183): a permutation of the bank, so no state is shared
+            perm = torch.randperm(n, device=self.device, generator=self._getup_gen)
+            self._last_fall_perm = perm
+            self.sim.set_env_states_masked(fall, {k: v[perm] for k, v in self._fall_state.items()})
+        if self.self_obs_v == 2:
+            self._init_tensor_history(fall)           # a fall start's history is its own state repeated (humanoid.py:1301-1306)
         keep = (~both)
         self.progress_buf.mul_(keep)
         self.reset_buf.mul_(keep)

@@ -15,6 +15,7 @@ Reference mapping (paths relative to the reference root):
   discount_values                          phc/learning/common_agent.py:493-505
 """
 import ctypes
+import os
 
 import torch
 
@@ -184,13 +185,17 @@ def pack_rb(body_pos, body_rot, body_vel, body_ang_vel):
     return torch.cat([_dev(t, "body tensor") for t in ts], dim=-1).contiguous()
 
 
+# PULSE_IM_DEBUG_POISON_LDS (include/pulse_hip.h): debug builds of a run can ask the fused step to pre-fill its LDS with NaN
+_IM_DEBUG_BITS = 0x80000000 if os.environ.get("PULSE_IM_DEBUG_POISON_LDS") == "1" else 0
+
+
 def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=None, dof_vel=None,
             progress=None, pass_time=None, cycle_counter=None, track_ids=None, reset_ids=None, term_dist=None,
             reset_use_mean=False, full_body_reward=True, obs_version=6, local_root_obs=True,
             root_height_obs=True, specs=None, power_coef=0.0005, power_reward=True,
             env_ids=None, env_mask=None, obs=None, obs_cols=None, rew=None, rew_raw=None, reset=None,
             terminate=None, clock=None, motion=None, upright=True, enable_early_termination=True, self_obs_version=1,
-            force_sensor=None, dof_pos=None, ref_next_dof_pos=None):
+            force_sensor=None, dof_pos=None, ref_next_dof_pos=None, smpl_params=None, limb_weights=None, recovery_counter=None):
     """``clock``: dict(progress_rw, inc, dt, start_times, start_offsets, motion_len, cycle_motion, max_episode_length,
     pass_time_out) -- the episode clock advanced / evaluated in-kernel.  ``motion``: dict(lib, ids, offset, traj_dt, track_rb,
     track_dof_pos, track_dof_vel) -- the reference evaluated in-kernel from a MotionLib instead of ref_now / ref_next.
@@ -231,6 +236,16 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
     if force_sensor is not None:
         a.force_sensor, a.force_sensor_width = P(force_sensor, "force_sensor"), force_sensor.shape[-1]
         fsw = force_sensor.shape[-1]
+    for name, t in (("smpl_params", smpl_params), ("limb_weights", limb_weights)):     # rows appended to the self observation
+        if t is not None:
+            _dev(t, name)
+            if t.dim() != 2 or t.shape[0] != n or t.stride(1) != 1:
+                raise ValueError(f"{name}: (num_envs, width) with contiguous rows expected")
+            keep.append(t)
+            setattr(a, name, t.data_ptr()); setattr(a, name + "_width", t.shape[1]); setattr(a, name + "_stride", t.stride(0))
+            fsw += t.shape[1]
+    if recovery_counter is not None:
+        a.recovery_counter = P(recovery_counter, "recovery_counter", torch.int32)
     a.dof_pos, a.ref_next_dof_pos = P(dof_pos, "dof_pos"), P(ref_next_dof_pos, "ref_next_dof_pos")
     if dof_pos is not None and dof_force is None:
         a.num_dof = dof_pos.shape[-1]
@@ -268,7 +283,7 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         a.reset_ids, a.num_reset = t.data_ptr(), t.numel()
     a.term_dist = P(term_dist, "term_dist")
     a.reset_use_mean, a.full_body_reward = int(reset_use_mean), int(full_body_reward)
-    a.what, a.obs_version = what, obs_version
+    a.what, a.obs_version = what | _IM_DEBUG_BITS, obs_version
     a.local_root_obs, a.root_height_obs = int(local_root_obs), int(root_height_obs)
     a.specs = _specs_struct(specs, power_coef, power_reward)
 
@@ -323,11 +338,11 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
 def compute_humanoid_observations_smpl_max(body_pos, body_rot, body_vel, body_ang_vel, smpl_params=None,
                                            limb_weight_params=None, local_root_obs=True, root_height_obs=True,
                                            upright=True, has_smpl_params=False, has_limb_weight_params=False):
-    """phc/env/tasks/humanoid.py:1675-1731 (no shape / limb obs); upright=False applies remove_base_rot (:1616-1620)."""
-    if has_smpl_params or has_limb_weight_params:
-        raise NotImplementedError("shape / limb-weight observations are not supported")
+    """phc/env/tasks/humanoid.py:1675-1731 (shape / limb-weight rows appended when has_* is set, :1724-1728); upright=False applies
+    remove_base_rot (:1616-1620)."""
     rb = pack_rb(body_pos, body_rot, body_vel, body_ang_vel)
-    return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=local_root_obs, root_height_obs=root_height_obs, upright=upright)["obs"]
+    return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=local_root_obs, root_height_obs=root_height_obs, upright=upright,
+                   smpl_params=smpl_params if has_smpl_params else None, limb_weights=limb_weight_params if has_limb_weight_params else None)["obs"]
 
 
 def compute_humanoid_observations_smpl_max_v2(body_pos, body_rot, body_vel, body_ang_vel, smpl_params=None, limb_weight_params=None,
@@ -343,12 +358,11 @@ def compute_humanoid_observations_smpl_max_v2(body_pos, body_rot, body_vel, body
 def compute_humanoid_observations_smpl_max_v3(body_pos, body_rot, body_vel, body_ang_vel, force_sensor_readings, smpl_params=None,
                                               limb_weight_params=None, local_root_obs=True, root_height_obs=True, upright=True,
                                               has_smpl_params=False, has_limb_weight_params=False):
-    """phc/env/tasks/humanoid.py:1789-1849: _smpl_max + the force-sensor readings."""
-    if has_smpl_params or has_limb_weight_params:
-        raise NotImplementedError("shape / limb-weight observations are not supported")
+    """phc/env/tasks/humanoid.py:1789-1849: _smpl_max + the force-sensor readings (+ shape / limb-weight rows, :1843-1847)."""
     rb = pack_rb(body_pos, body_rot, body_vel, body_ang_vel)
     return im_step(rb, what=PULSE_IM_SELF_OBS, local_root_obs=local_root_obs, root_height_obs=root_height_obs, upright=upright,
-                   self_obs_version=3, force_sensor=force_sensor_readings)["obs"]
+                   self_obs_version=3, force_sensor=force_sensor_readings,
+                   smpl_params=smpl_params if has_smpl_params else None, limb_weights=limb_weight_params if has_limb_weight_params else None)["obs"]
 
 
 def remove_base_rot(quat):

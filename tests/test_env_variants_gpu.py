@@ -137,3 +137,33 @@ def test_task_resets_bit_exact(dev):
     pw[t("progress") <= 3] = 0
     np.testing.assert_allclose(o["rew"].cpu().numpy(), ZT["speed_rew"] + pw.cpu().numpy(), atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(o["rew_raw"][:, 1].cpu().numpy(), pw.cpu().numpy(), atol=1e-5, rtol=1e-5)
+
+
+def test_shape_and_limb_weight_observation_rows(dev):
+    """has_smpl_params / has_limb_weight_params (humanoid.py:1724-1728, 1843-1847) vs the golden written by the reference's functions;
+    also through the env (robot has_shape_obs / has_weight_obs -> + 11 / + 10 columns, humanoid.py:657-661)."""
+    S = np.load(os.path.join(GOLD, "env_shape_obs.npz"))
+    g = lambda k: torch.from_numpy(S[k]).to(dev)
+    rb = g("rb")
+    bp, br, bv, ba = (rb[..., 0:3], rb[..., 3:7], rb[..., 7:10], rb[..., 10:13])
+    sh, lw, fs = g("smpl_params"), g("limb_weights"), g("force_sensor")
+    for up, tag in ((True, ""), (False, "_noup")):
+        for name, hs, hl in (("both", True, True), ("shape", True, False), ("limb", False, True)):
+            got = ops.compute_humanoid_observations_smpl_max(bp, br, bv, ba, sh, lw, True, True, up, hs, hl)
+            want = g(f"self_obs_{name}{tag}")
+            assert got.shape == want.shape and (got - want).abs().max().item() < 2e-6, (name, tag)
+            assert torch.equal(got[:, 358:], want[:, 358:])                          # the appended rows are copies
+        got = ops.compute_humanoid_observations_smpl_max_v3(bp, br, bv, ba, fs, sh, lw, True, True, up, True, True)
+        want = g(f"self_obs_v3_both{tag}")
+        assert got.shape == want.shape and (got - want).abs().max().item() < 2e-6 and torch.equal(got[:, 358:], want[:, 358:])
+    with pytest.raises(Exception):                                                    # the reference's _v2 raises for these options
+        ops.im_step(torch.zeros(4, 2, 24, 13, device=dev), what=1, self_obs_version=2, smpl_params=torch.zeros(4, 11, device=dev))
+    from pulse_amd import configs
+    agent, _ = configs.make_agent("cfg1", device=dev, seed=3, env_overrides={"has_shape_obs": True, "has_weight_obs": True})
+    task = agent.vec_env.env.task
+    assert task.get_self_obs_size() == 379 and task.num_obs == 379 + 576
+    agent.init_tensors()
+    agent.env_reset()
+    task.step(torch.zeros(task.num_envs, task.num_actions, device=dev))
+    assert torch.equal(task.obs_buf[:, 358:369], task.humanoid_shapes[:, :11]) and torch.equal(task.obs_buf[:, 369:379], task.humanoid_limb_and_weights)
+    assert torch.isfinite(task.obs_buf).all()

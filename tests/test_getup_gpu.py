@@ -24,7 +24,8 @@ def test_three_way_reset_split_and_recovery_grace(dev):
     n = 96
     task = make(dev, n, recoveryEpisodeProb=1.0, fallInitProb=1.0, recoverySteps=5)
     task.reset()                                              # initial reset: nothing was terminated -> every env starts from ITS fall state
-    assert torch.equal(task.sim.rigid_body_state, task._fall_state["rb_records"])
+    assert torch.equal(task.sim.rigid_body_state, task._fall_state["rb_records"][task._last_fall_perm])      # a permutation: no state shared
+    assert torch.equal(torch.sort(task._last_fall_perm).values, torch.arange(n, device=dev))
     assert (task._recovery_counter == 5).all() and (task.progress_buf == 0).all()
     assert (task.sim.rigid_body_state[..., 7:13] == 0).all() and (task.sim.rigid_body_state[..., 2].min(dim=1).values - 0.05).abs().max() < 1e-5
     # during the grace period nothing resets or terminates and progress stands still (:203-210)
@@ -44,7 +45,7 @@ def test_three_way_reset_split_and_recovery_grace(dev):
     before = task.sim.rigid_body_state.clone()
     task.reset_masked(mask)
     assert torch.equal(task.sim.rigid_body_state[:10], before[:10])                            # recovery: state kept
-    assert torch.equal(task.sim.rigid_body_state[10:20], task._fall_state["rb_records"][10:20])   # fall start
+    assert torch.equal(task.sim.rigid_body_state[10:20], task._fall_state["rb_records"][task._last_fall_perm][10:20])   # fall start
     assert torch.equal(task.sim.rigid_body_state[20:], before[20:])
     assert (task._recovery_counter[:20] == 5).all() and (task.progress_buf[:20] == 0).all() and (task.reset_buf[:20] == 0).all()
     assert torch.isfinite(task.obs_buf).all()
@@ -68,3 +69,36 @@ def test_getup_schedule_and_normal_init(dev):
     task.reset()
     frac = float(task._reset_fall_mask.float().mean())
     assert 0.1 < frac < 0.55, frac
+
+
+@pytest.mark.parametrize("cycle", [False, True])
+def test_recovering_env_observes_the_frozen_clock_frame(dev, cycle):
+    """humanoid_im_getup.py:203-210 + humanoid.py:1325-1328: _compute_reset takes the recovering envs' progress back BEFORE
+    _compute_observations, so their task observation targets the frame at (frozen progress + 1), not one frame further."""
+    from pulse_amd import ops
+    from pulse_amd._lib import PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS
+    n = 64
+    task = make(dev, n, recoveryEpisodeProb=1.0, fallInitProb=1.0, recoverySteps=6, cycle_motion=cycle)
+    task.reset()
+    for _ in range(3):
+        task.step(torch.zeros(n, 69, device=dev))
+    assert (task.progress_buf == 0).all() and (task._recovery_counter == 3).all()
+
+    def expected(shift):
+        t = (task.progress_buf + shift).float() * task.dt
+        t = t + task._motion_start_times
+        t = t + task._motion_start_times_offset
+        ref = task._motion_lib.query(task._sampled_motion_ids, t.contiguous(), task._global_offset)
+        out = ops.im_step(task.sim.rigid_body_state, what=PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS,
+                          ref_next={"pos": ref["rg_pos"], "rot": ref["rb_rot"], "vel": ref["body_vel"], "ang": ref["body_ang_vel"]},
+                          track_ids=task._track_bodies_id, obs_version=task.obs_v)
+        return out["obs"]
+    want, ahead = expected(1), expected(2)
+    assert torch.equal(task.obs_buf, want), (task.obs_buf - want).abs().max().item()
+    assert not torch.equal(task.obs_buf, ahead)
+    # once the grace period is over the clock advances again and the observation follows it
+    for _ in range(4):
+        task.step(torch.zeros(n, 69, device=dev))
+    moving = task.progress_buf > 0
+    assert moving.any()
+    assert torch.equal(task.obs_buf[moving], expected(1)[moving])

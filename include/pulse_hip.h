@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 12
+#define PULSE_ABI_VERSION 13
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -463,6 +463,37 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
  * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID. */
 int pulse_gemm_set_option(int key, int value);
 int pulse_gemm_set_debug_buffer(long long* device_buffer);
+/* ------------------------------------------------------------------------- *
+ * 4b. The same fp32-grade GEMM (PULSE_GEMM_COMPUTE_F32X3 arithmetic) over operands kept PRE-SPLIT in HBM: a matrix is stored as
+ *     three bf16 "planes" (x = p0 + p1 + p2 exactly, p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1), round to nearest
+ *     even); element (r, c) of plane p lives at base[p * plane_stride + r * ld + c] (uint16 bit patterns).  Whoever produces a
+ *     matrix writes its planes once (pulse_split_planes, the Cp output of this GEMM, the optimiser step for the weights); the GEMM
+ *     main loop is LDS-DMA + ds_read + MFMA only.  Same reference call sites as section 4.
+ *     Rules: pitches multiples of 8 elements; the k extent of a reduction-contiguous operand is zero-padded to a multiple of 32
+ *     inside its pitch (pulse_split_planes and the Cp epilogue write those zeros); rows / outs past M / N are not read.
+ * ------------------------------------------------------------------------- */
+typedef struct pulse_gemm_x3p_desc {
+    const void* A; int64_t a_plane_stride; int32_t lda;   /* planes of A(m, k); bf16 elements */
+    const void* B; int64_t b_plane_stride; int32_t ldb;   /* planes of B(n, k) */
+    int32_t a_layout, b_layout;                           /* PULSE_GEMM_*_CONTIG (this build: both reduction-contiguous) */
+    float* C; int32_t ldc;                                /* optional fp32 output */
+    void* Cp; int64_t c_plane_stride; int32_t ldcp;       /* optional: the output's own planes (columns [N, roundup8(N)) zero-filled) */
+    float* C2; int32_t ldc2;                              /* optional pre-activation output (EPI_BIAS_ACT + SILU) */
+    const float* bias; const float* aux; int32_t ldaux;
+    int32_t M, N, K;
+    int32_t batch;
+    int64_t stride_a, stride_b, stride_c, stride_cp, stride_c2, stride_bias, stride_aux;   /* per-array element units */
+    int32_t split_k; int64_t split_stride;
+    int32_t activation, epilogue;                         /* PULSE_ACT_*, PULSE_EPI_* */
+    float* rowsum; int64_t stride_rowsum;
+} pulse_gemm_x3p_desc;
+int pulse_sizeof_gemm_x3p_desc(void);
+int pulse_gemm_x3p(const pulse_gemm_x3p_desc* desc, pulse_stream_t s);
+/* fp32 (rows x cols, pitch ld_in floats) -> planes of rows_out x cols_out with pitch ld_out (multiple of 8; columns [cols_out, ld_out)
+ * zero-filled).  transpose != 0: out(r, c) = in(c, r).  row_idx (optional, no transpose): out row r = in row row_idx[r]. */
+int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t cols_out, void* out, int64_t plane_stride, int32_t ld_out,
+                       int32_t transpose, const int64_t* row_idx, pulse_stream_t s);
+
 /* out[i] = scale * sum_s slabs[s*slab_stride + i]  (deterministic split-K / partial-sum reduction) */
 int pulse_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count, float* out,
                        float scale, pulse_stream_t s);

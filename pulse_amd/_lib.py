@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -122,6 +122,21 @@ class PdSimArgs(Structure):
                 ("reset_mask", c_void_p)]
 
 
+class GemmX3pDesc(Structure):
+    _fields_ = [("A", c_void_p), ("a_plane_stride", c_int64), ("lda", c_int32),
+                ("B", c_void_p), ("b_plane_stride", c_int64), ("ldb", c_int32),
+                ("a_layout", c_int32), ("b_layout", c_int32),
+                ("C", c_void_p), ("ldc", c_int32),
+                ("Cp", c_void_p), ("c_plane_stride", c_int64), ("ldcp", c_int32),
+                ("C2", c_void_p), ("ldc2", c_int32),
+                ("bias", c_void_p), ("aux", c_void_p), ("ldaux", c_int32),
+                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32),
+                ("stride_a", c_int64), ("stride_b", c_int64), ("stride_c", c_int64), ("stride_cp", c_int64), ("stride_c2", c_int64),
+                ("stride_bias", c_int64), ("stride_aux", c_int64),
+                ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
+                ("rowsum", c_void_p), ("stride_rowsum", c_int64)]
+
+
 class GemmDesc(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p), ("aux", c_void_p),
@@ -193,6 +208,9 @@ SIGNATURES = {
     "pulse_gae": (c_int, [P, P, P, P, c_int32, c_int32, c_int64, c_int64, c_float, c_float, P, P, P]),
     "pulse_sizeof_gemm_desc": (c_int, []),
     "pulse_gemm_f32": (c_int, [POINTER(GemmDesc), P]),
+    "pulse_gemm_x3p": (c_int, [POINTER(GemmX3pDesc), P]),
+    "pulse_sizeof_gemm_x3p_desc": (c_int, []),
+    "pulse_split_planes": (c_int, [P, c_int64, c_int32, c_int32, P, c_int64, c_int32, c_int32, P, P]),
     "pulse_reduce_slabs": (c_int, [P, c_int32, c_int64, c_int64, P, c_float, P]),
     "pulse_colsum_partial": (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, c_int64, P]),
     "pulse_rms_normalize": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, c_int32, P, c_int64, c_int32, P, c_int32, P]),

@@ -43,6 +43,7 @@ SOURCES = [
     # MFMA accumulators in VGPR form: no v_accvgpr moves (VALU slots are what the fp32 MFMA loop is short of) and the
     # whole kernel fits the 256-register budget of two waves per SIMD
     ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),   # (packed-f32 VALU beside MFMAs also costs more than two plain adds)
+    ("gemm_x3p.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("learner_ops.hip", NO_CONTRACT),
 ]
 

@@ -520,6 +520,9 @@ class VecTaskPythonWrapper:
         # it across steps.  pulse_amd's own agents copy the observation into the experience buffer before the next step and opt
         # into the aliased buffer (saves a 16 MB copy per step at 4096 envs); any other caller gets the reference's semantics.
         self.alias_obs = False
+        # for envs that were not reset, the observation step() returns IS what the next policy step sees (no auto-reset inside step, no
+        # observation noise): lets the agent reuse values[t + 1] as the bootstrap value of step t (CommonAgent._bootstrap_values)
+        self.obs_carries_over = True
 
     def step(self, actions):
         actions_tensor = torch.clamp(actions, -self.clip_actions, self.clip_actions)

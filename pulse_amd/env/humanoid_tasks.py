@@ -125,6 +125,7 @@ class HumanoidTask:
         self.actions = actions
         self._prev_root_pos.copy_(self.sim.rigid_body_state[:, 0, 0:3])                 # humanoid_speed.py:72-75
         self.sim.set_dof_position_target_tensor(actions)
+        self._update_task()          # HumanoidAMPTask.pre_physics_step (humanoid_amp_task.py:57-59): BEFORE progress_buf advances
 
     def step(self, actions):
         self.pre_physics_step(actions)
@@ -133,7 +134,6 @@ class HumanoidTask:
 
     def post_physics_step(self):
         self.progress_buf += 1
-        self._update_task()                                                              # humanoid_amp_task.py:68-71
         # reward -> reset (one launch), then the observation row for the next step (humanoid.py:1322-1325)
         self._task_step(TASK_REWARD | TASK_RESET)
         self._compute_observations()

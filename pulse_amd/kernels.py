@@ -163,6 +163,96 @@ class Plan:
                 _lib.check(op[1](*op[2], st), op[3])
 
 
+# --------------------------------------------------------------------------- #
+# planar ("x3p") fp32-grade GEMM: operands kept pre-split in HBM as three bf16 planes (include/pulse_hip.h section 4b)
+# --------------------------------------------------------------------------- #
+def planes_pitch(cols):
+    """Element pitch of a planes row: the k extent is zero-padded to a multiple of 32 inside the pitch."""
+    return (cols + 31) // 32 * 32
+
+
+def alloc_planes(rows, cols, device):
+    """(3, rows, pitch) int16 (bf16 bit patterns), zero-initialised: the pad columns must read as zero."""
+    return torch.zeros(3, rows, planes_pitch(cols), dtype=torch.int16, device=device)
+
+
+def split_planes(x, out=None, *, rows=None, cols=None, transpose=False, row_idx=None, x_off=0, ld_in=None, out_off=0):
+    """fp32 matrix -> its three bf16 planes (x == p0 + p1 + p2 exactly).  ``x`` is a 2-D tensor (or a base tensor with x_off / ld_in /
+    rows / cols given explicitly); transpose=True writes the planes of x.T."""
+    _chk(x, "x")
+    if ld_in is None:
+        if x.dim() != 2 or x.stride(1) != 1:
+            raise ValueError("split_planes: 2-D tensor with contiguous rows expected (or explicit geometry)")
+        ld_in = x.stride(0)
+        r_in, c_in = x.shape
+        rows_out, cols_out = (c_in, r_in) if transpose else (r_in, c_in)
+        if row_idx is not None:
+            rows_out = row_idx.numel()
+    else:
+        rows_out, cols_out = rows, cols
+    if out is None:
+        out = alloc_planes(rows_out, cols_out, x.device)
+    if out.dtype != torch.int16 or out.dim() != 3 or out.shape[0] != 3 or out.stride(2) != 1 or not out.is_cuda:
+        raise TypeError("split_planes: out must be a (3, rows, pitch) int16 CUDA tensor")
+    _chk(row_idx, "row_idx", torch.int64)
+    _lib.check(_lib.load().pulse_split_planes(x.data_ptr() + 4 * x_off, ld_in, rows_out, cols_out, out.data_ptr() + 2 * out_off, out.stride(0),
+                                              out.stride(1), 1 if transpose else 0, _p(row_idx), _stream()), "pulse_split_planes")
+    return out
+
+
+def join_planes(p):
+    """The fp32 matrix a planes tensor represents (test helper): p0 + p1 + p2 evaluated exactly."""
+    f = (p.to(torch.int32) << 16).view(torch.float32)
+    return (f[0].double() + f[1].double() + f[2].double()).float()
+
+
+def make_gemm_x3p_desc(A, B, *, M, N, K, C=None, Cp=None, bias=None, activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None,
+                       ldc2=0, ldc=0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_cp=0, stride_c2=0, stride_bias=0, stride_aux=0,
+                       a_off=0, b_off=0, c_off=0, cp_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None):
+    """A / B / Cp are planes tensors (3, rows, pitch) int16; *_off are element offsets inside a plane.  Returns (descriptor, algorithmic
+    FLOPs, tag) like make_gemm_desc."""
+    for t, nm in ((A, "A"), (B, "B"), (Cp, "Cp")):
+        if t is not None and (t.dtype != torch.int16 or t.dim() != 3 or t.shape[0] != 3 or t.stride(2) != 1 or not t.is_cuda):
+            raise TypeError(f"gemm_x3p: {nm} must be a (3, rows, pitch) int16 CUDA planes tensor")
+    d = _lib.GemmX3pDesc()
+    d.A, d.a_plane_stride, d.lda = A.data_ptr() + 2 * a_off, A.stride(0), A.stride(1)
+    d.B, d.b_plane_stride, d.ldb = B.data_ptr() + 2 * b_off, B.stride(0), B.stride(1)
+    d.a_layout = d.b_layout = GEMM_RED_CONTIG
+    if C is not None:
+        _chk(C, "C")
+        d.C, d.ldc = C.data_ptr() + 4 * c_off, ldc
+    if Cp is not None:
+        d.Cp, d.c_plane_stride, d.ldcp = Cp.data_ptr() + 2 * cp_off, Cp.stride(0), Cp.stride(1)
+    d.C2 = (C2.data_ptr() + 4 * c2_off) if C2 is not None else None
+    d.ldc2 = ldc2
+    d.bias = (bias.data_ptr() + 4 * bias_off) if bias is not None else None
+    d.aux = (aux.data_ptr() + 4 * aux_off) if aux is not None else None
+    d.ldaux = ldaux
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.stride_a, d.stride_b, d.stride_c, d.stride_cp, d.stride_c2 = stride_a, stride_b, stride_c, stride_cp, stride_c2
+    d.stride_bias, d.stride_aux = stride_bias, stride_aux
+    d.split_k, d.split_stride, d.activation, d.epilogue = 1, 0, activation, epilogue
+    flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
+    return d, flops, "x3p_fwd"
+
+
+def launch_gemm_x3p(d, flops=0.0, tag="x3p_fwd", stream=None):
+    lib = _lib.load()
+    st = _stream() if stream is None else stream
+    if PROFILER.enabled:
+        ev0, ev1 = PROFILER._event(), PROFILER._event()
+        ev0.record()
+        _lib.check(lib.pulse_gemm_x3p(ctypes.byref(d), st), "pulse_gemm_x3p")
+        ev1.record()
+        PROFILER.records.append((ev0, ev1, flops, tag))
+        return
+    _lib.check(lib.pulse_gemm_x3p(ctypes.byref(d), st), "pulse_gemm_x3p")
+
+
+def gemm_x3p(A, B, **kw):
+    launch_gemm_x3p(*make_gemm_x3p_desc(A, B, **kw))
+
+
 def linear_forward(x, w, bias=None, activation=ACT_NONE, out=None):
     """Convenience: y = act(x @ w.T + bias) for 2-D row-major tensors with 16-byte aligned rows."""
     x, w = _dev(x, "x"), _dev(w, "w")

@@ -148,6 +148,7 @@ class CommonAgent:
         self._entropy = None
         self._tensors_ready = False
         self._boot_idx = self._boot_val = None
+        self._boot_shortcut = None           # decided on the first rollout (_bootstrap_values)
         self._rollout_noise = None
 
     # ------------------------------------------------------------------ construction helpers
@@ -366,9 +367,22 @@ class CommonAgent:
         n, t = self.num_actors, self.horizon_length
         nxt, out, term = eb.flat("next_obses"), eb.flat("next_values"), eb.flat("terminates")
         vals, dones = eb.flat("values"), eb.flat("dones")
-        out.view(n, t)[:, :-1].copy_(vals.view(n, t)[:, 1:])
         need = dones.view(n, t) != 0
         need[:, t - 1] = True
+        # The shortcut holds only for envs whose step() hands back, for envs that were not reset, exactly the observation the next
+        # policy step sees (no auto-reset inside step, no per-step observation noise): the env wrapper declares it
+        # (``obs_carries_over``) and the first rollout verifies it on the data; otherwise every row gets its own critic pass.
+        if self._boot_shortcut is None:
+            ok = bool(getattr(self.vec_env, "obs_carries_over", False))
+            if ok and t > 1:
+                w = self.obs_shape[0]
+                cur, nx = eb.flat("obses").view(n, t, -1)[..., :w], nxt.view(n, t, -1)[..., :w]
+                ok = bool(((nx[:, :-1] == cur[:, 1:]).all(dim=-1) | need[:, :-1]).all().item())      # one host read, first epoch only
+            self._boot_shortcut = ok
+        if self._boot_shortcut:
+            out.view(n, t)[:, :-1].copy_(vals.view(n, t)[:, 1:])
+        else:
+            need[:] = True
         rows = torch.nonzero(need.reshape(-1)).reshape(-1)                 # (count,) -- device->host sync on the count, once per epoch
         count = rows.numel()
         chunk = min(self.minibatch_size, max(n, 1024))

@@ -129,3 +129,29 @@ def test_reference_style_gathered_minibatch(dev):
     agent.calc_gradients({k: d[k] for k in ("old_values", "old_logp_actions", "advantages", "returns", "actions", "obs", "mu", "sigma")})
     assert torch.isfinite(agent.train_result["actor_loss"]).item()
     assert not torch.equal(before, agent.model.flat)
+
+
+def test_bootstrap_value_shortcut_equals_full_critic_pass(dev):
+    """CommonAgent._bootstrap_values reuses values[t + 1] as the bootstrap value of step t for envs that were not reset: the
+    result must equal a critic pass over every next observation (amp_agent.py:394-398), and the shortcut must switch itself off for an
+    env wrapper that does not declare ``obs_carries_over``."""
+    def played(carries):
+        torch.manual_seed(99)                                             # identical initial weights and rollouts
+        agent, _ = configs.make_agent("cfg1", device=dev, seed=11, reference="motion_lib")
+        agent.vec_env.obs_carries_over = carries
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        agent._tensors_ready = True
+        agent.play_steps()
+        return agent
+    a = played(True)
+    assert a._boot_shortcut is True
+    fast = a.experience_buffer.flat("next_values").clone()
+    a._boot_shortcut = False                                              # same rollout, every row through the critic
+    a._bootstrap_values()
+    full = a.experience_buffer.flat("next_values").clone()
+    tol = 1e-5 * max(1.0, full.abs().max().item())
+    assert (fast - full).abs().max().item() <= tol
+    b = played(False)                                                     # an env that does not promise observation continuity
+    assert b._boot_shortcut is False
+    assert (b.experience_buffer.flat("next_values") - full).abs().max().item() <= tol

@@ -1,0 +1,126 @@
+"""GPU: the planar fp32-grade GEMM (pulse_gemm_x3p, include/pulse_hip.h 4b) -- operands pre-split into three bf16 planes in HBM,
+LDS-DMA staging -- against an fp64 reference, against the in-kernel-split x3 kernel it replaces, and its structural properties
+(exact planes, exact small-integer products, tile-position independence, outputs' own planes)."""
+import pytest
+import torch
+
+from pulse_amd import kernels as K
+from pulse_amd._lib import ACT_NONE, ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(m, n, k, dev, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(m, k, generator=g) * scale).to(dev)
+    b = (torch.randn(n, k, generator=g) * 0.05).to(dev)
+    return a, b
+
+
+def test_split_planes_is_exact_and_padded(dev):
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(37, 69, generator=g) * torch.logspace(-6, 4, 37).unsqueeze(1)).to(dev)
+    p = K.split_planes(x)
+    assert p.shape == (3, 37, 96) and (p[:, :, 69:] == 0).all()
+    assert torch.equal(K.join_planes(p)[:, :69], x)                      # 8 + 8 + 8 significand bits: the split is exact
+    # plane 0 is the round-to-nearest-even bf16 of x
+    assert torch.equal(p[0, :, :69], x.to(torch.bfloat16).view(torch.int16))
+    pt = K.split_planes(x, transpose=True)
+    assert pt.shape == (3, 69, 64) and torch.equal(K.join_planes(pt)[:, :37], x.t()) and (pt[:, :, 37:] == 0).all()
+    idx = torch.tensor([5, 0, 36, 5], device=dev)
+    pg = K.split_planes(x, row_idx=idx)
+    assert torch.equal(K.join_planes(pg)[:, :69], x[idx])
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 128, 32), (300, 200, 100), (130, 69, 934), (4096, 1024, 960), (1024, 1, 512), (64, 2048, 69), (515, 129, 33)])
+def test_x3p_matches_fp64_and_the_x3_kernel(dev, m, n, k):
+    a, b = _mk(m, n, k, dev, seed=m + n + k)
+    bias = torch.randn(n, device=dev)
+    pa, pb = K.split_planes(a), K.split_planes(b)
+    c = torch.full((m, n + 3), float("nan"), device=dev)[:, :n]
+    ldc = c.stride(0)
+    # ldc must be a multiple of 4: use a padded pitch
+    cbuf = torch.full((m, (n + 3) // 4 * 4 + 4), float("nan"), device=dev)
+    K.gemm_x3p(pa, pb, M=m, N=n, K=k, C=cbuf, ldc=cbuf.stride(0), bias=bias)
+    got = cbuf[:, :n]
+    want = a.double() @ b.double().t() + bias.double()
+    ref32 = torch.empty(m, n, device=dev)
+    lda = (k + 3) // 4 * 4
+    a4 = torch.zeros(m, lda, device=dev); a4[:, :k] = a
+    b4 = torch.zeros(n, lda, device=dev); b4[:, :k] = b
+    cref = torch.empty(m, (n + 3) // 4 * 4, device=dev)
+    K.gemm(a4, b4, cref, M=m, N=n, K=k, lda=lda, ldb=lda, ldc=cref.stride(0), bias=bias, f32_mode="x3")
+    err = (got.double() - want).abs().max().item()
+    err_x3 = (cref[:, :n].double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert torch.isnan(cbuf[:, n:]).all()                               # nothing written past N
+    assert err <= 2e-6 * scale + 1e-6, (err, scale)
+    assert err <= 2.0 * err_x3 + 1e-7 * scale, (err, err_x3)            # same arithmetic as the in-kernel split
+
+
+def test_x3p_small_integer_products_are_exact_and_tile_position_independent(dev):
+    g = torch.Generator().manual_seed(3)
+    m, n, k = 700, 260, 96
+    a = torch.randint(-8, 9, (m, k), generator=g).float().to(dev)
+    b = torch.randint(-8, 9, (n, k), generator=g).float().to(dev)
+    c = torch.empty(m, 264, device=dev)
+    K.gemm_x3p(K.split_planes(a), K.split_planes(b), M=m, N=n, K=k, C=c, ldc=264)
+    assert torch.equal(c[:, :n], (a.double() @ b.double().t()).float())
+    # a row of A and a row of B give the same output wherever they sit in the tiling
+    a2, b2 = a.roll(131, 0), b.roll(77, 0)
+    c2 = torch.empty(m, 264, device=dev)
+    a3, b3 = torch.randn(m, k, generator=g).to(dev), torch.randn(n, k, generator=g).to(dev)
+    c3 = torch.empty(m, 264, device=dev)
+    K.gemm_x3p(K.split_planes(a3), K.split_planes(b3), M=m, N=n, K=k, C=c3, ldc=264)
+    K.gemm_x3p(K.split_planes(a3.roll(131, 0)), K.split_planes(b3.roll(77, 0)), M=m, N=n, K=k, C=c2, ldc=264)
+    assert torch.equal(c2[:, :n], c3[:, :n].roll(131, 0).roll(77, 1))
+
+
+@pytest.mark.parametrize("act", [ACT_NONE, ACT_RELU, ACT_SILU])
+def test_x3p_epilogues_and_output_planes(dev, act):
+    m, n, k = 520, 192, 160
+    a, b = _mk(m, n, k, dev, seed=9)
+    bias = torch.randn(n, device=dev) * 0.1
+    pa, pb = K.split_planes(a), K.split_planes(b)
+    c = torch.empty(m, n, device=dev)
+    z = torch.empty(m, n, device=dev)
+    cp = K.alloc_planes(m, n, dev)
+    cp.fill_(0x7fc0)                                                     # poison: every element of the valid region must be written
+    K.gemm_x3p(pa, pb, M=m, N=n, K=k, C=c, ldc=n, Cp=cp, bias=bias, activation=act, C2=z if act == ACT_SILU else None, ldc2=n)
+    pre = a.double() @ b.double().t() + bias.double()
+    want = pre if act == ACT_NONE else torch.relu(pre) if act == ACT_RELU else pre * torch.sigmoid(pre)
+    assert (c.double() - want).abs().max().item() <= 3e-6 * max(1.0, want.abs().max().item())
+    if act == ACT_SILU:
+        assert (z.double() - pre).abs().max().item() <= 3e-6 * max(1.0, pre.abs().max().item())
+    assert torch.equal(K.join_planes(cp)[:, :n], c)                      # the output's planes are the exact split of the fp32 output
+    # gradient epilogues: C = acc * act'(aux)
+    dy, w = _mk(m, k, n, dev, seed=11)                                   # dX = dY (m x n) . W (n x k) -> B operand = W^T planes (k x n)
+    dy = torch.randn(m, n, device=dev)
+    wt = torch.randn(n, k, device=dev) * 0.05
+    pdy, pwt = K.split_planes(dy), K.split_planes(wt, transpose=True)
+    aux = torch.randn(m, k, device=dev)
+    dx = torch.empty(m, k, device=dev)
+    if act != ACT_NONE:
+        K.gemm_x3p(pdy, pwt, M=m, N=k, K=n, C=dx, ldc=k, epilogue=EPI_RELU_GRAD if act == ACT_RELU else EPI_SILU_GRAD, aux=aux, ldaux=k)
+        acc = dy.double() @ wt.double()
+        if act == ACT_RELU:
+            wantg = acc * (aux > 0)
+        else:
+            sg = torch.sigmoid(aux.double())
+            wantg = acc * (sg * (1 + aux.double() * (1 - sg)))
+        assert (dx.double() - wantg).abs().max().item() <= 3e-6 * max(1.0, wantg.abs().max().item())
+
+
+def test_x3p_batched(dev):
+    m, n, k = 384, 128, 64
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(m, 2 * k, generator=g).to(dev)                       # two problems side by side in the columns of A ([actor | critic] layout)
+    b = torch.randn(2 * n, k, generator=g).to(dev) * 0.1
+    pa = K.split_planes(a)                                               # pitch 128: batch z reads columns z * 64 ..
+    pb = K.split_planes(b)
+    c = torch.empty(m, 2 * n, device=dev)
+    bias = torch.randn(2 * n, device=dev)
+    K.gemm_x3p(pa, pb, M=m, N=n, K=k, C=c, ldc=2 * n, bias=bias, batch=2, stride_a=k, stride_b=n * pb.stride(1), stride_c=n, stride_bias=n)
+    for zb in range(2):
+        want = a[:, zb * k:(zb + 1) * k].double() @ b[zb * n:(zb + 1) * n].double().t() + bias[zb * n:(zb + 1) * n].double()
+        assert (c[:, zb * n:(zb + 1) * n].double() - want).abs().max().item() <= 3e-6 * want.abs().max().item()

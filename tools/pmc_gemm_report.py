@@ -1,0 +1,41 @@
+"""Summarise the counter CSVs of tools/pmc_gemm.sh: per kernel (name, grid) the mean of every counter over the launches after the first,
+plus derived figures: effective clock = GRBM_GUI_ACTIVE / duration, MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x
+GRBM_GUI_ACTIVE) (the counter sums busy cycles over all SIMDs)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+dur = defaultdict(list)
+for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        key = (r["Kernel_Name"].split("(")[0][:60], r.get("Grid_Size", ""), r.get("Workgroup_Size", ""))
+        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "Start_Timestamp" in r and "End_Timestamp" in r and r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES"):
+            dur[key].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+for f in glob.glob(os.path.join(root, "p*", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        key = (r["Kernel_Name"].split("(")[0][:60], r.get("Grid_Size", ""), r.get("Workgroup_Size", ""))
+        dur[key].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+print("# SQ / GRBM counters per kernel launch (mean over launches 2..), rocprofv3 --pmc, MI355X")
+for key in sorted(acc):
+    if "gemm" not in key[0]:
+        continue
+    c = {k: sum(v[1:]) / max(1, len(v[1:])) if len(v) > 1 else v[0] for k, v in acc[key].items()}
+    d = sorted(dur.get(key, [0.0]))
+    dns = d[len(d) // 2]
+    print(f"\n## {key[0]}  grid {key[1]} wg {key[2]}  median duration {dns * 1e-3:.1f} us (under the profiler)")
+    for k in sorted(c):
+        print(f"  {k:28s} {c[k]:16.0f}")
+    if "GRBM_GUI_ACTIVE" in c and dns > 0:
+        clk = c["GRBM_GUI_ACTIVE"] / 8.0 / dns          # the counter is summed over the 8 XCDs
+        print(f"  -> effective clock (GUI_ACTIVE / 8 XCDs / duration)   {clk:.3f} GHz")
+    if "GRBM_GUI_ACTIVE" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        print(f"  -> MFMA pipe busy = MFMA_BUSY_CYCLES / (1024 SIMDs x GUI_ACTIVE / 8)  {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * c['GRBM_GUI_ACTIVE'] / 8.0):.3f}")
+    if "SQ_WAVE_CYCLES" in c:
+        for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+            if k in c:
+                print(f"  -> {k} / SQ_WAVE_CYCLES   {c[k] / c['SQ_WAVE_CYCLES']:.3f}")

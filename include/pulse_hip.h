@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 13
+#define PULSE_ABI_VERSION 14
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -493,6 +493,52 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* desc, pulse_stream_t s);
  * zero-filled).  transpose != 0: out(r, c) = in(c, r).  row_idx (optional, no transpose): out row r = in row row_idx[r]. */
 int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t cols_out, void* out, int64_t plane_stride, int32_t ld_out,
                        int32_t transpose, const int64_t* row_idx, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
+ * 4c. PULSE VAE head algebra (no autograd on the product path): form_embedding (amp_network_z_builder.py:79-121), the losses of
+ *     AMPAgent._optimize_kin (amp_agent.py:771-849; kl_multi loss_functions.py:3-10) and their head-level gradients.
+ *     Heads rows are [mu (E) | raw logvar (E)]; clamp_logvar applies clamp(logvar, -5, clamp_max) (use_vae_clamped_prior).
+ * ------------------------------------------------------------------------- */
+typedef struct pulse_vae_embed_args {
+    const float* heads; int64_t heads_stride;   /* encoder heads (rows, >= 2E) */
+    const float* eps; int64_t eps_stride;       /* re-parameterisation noise (rows, E) or NULL (z = mu, flags.test) */
+    const float* x; int64_t x_stride;           /* normalised observation; its first self_obs_size columns are copied */
+    float* ain; int64_t ain_stride;             /* decoder input: [self obs | .. | z at column z_col] */
+    float* cin; int64_t cin_stride;             /* optional: critic input, self obs columns only */
+    int32_t rows, embedding_size, self_obs_size, z_col;
+    int32_t clamp_logvar; float clamp_max;
+} pulse_vae_embed_args;
+int pulse_vae_embed(const pulse_vae_embed_args* args, pulse_stream_t s);
+
+typedef struct pulse_vae_kin_args {
+    const float* pred; int64_t pred_stride;     /* decoder output mu (rows, A) */
+    const float* gt; int64_t gt_stride;         /* kin_dict['gt_action'] */
+    const float* zheads; int64_t zheads_stride;
+    const float* pheads; int64_t pheads_stride; /* learned prior heads */
+    const int64_t* progress;                    /* kin_dict['progress_buf'] (rows), env-major sequences of ``horizon`` steps */
+    int32_t rows, num_actions, embedding_size, horizon;
+    int32_t clamp_logvar; float clamp_max;
+    int32_t use_ar1, use_regu;
+    float* dmu; int64_t dmu_stride;             /* out: d mean||pred - gt|| / d pred */
+    float* partials; int32_t num_blocks;        /* out: (num_blocks, 8) sums: action norm, KL, AR(1) norm, prior_mu^2, vae_mu^2, prior_lv^2, vae_lv^2, 0 */
+} pulse_vae_kin_args;
+int pulse_vae_kin_loss(const pulse_vae_kin_args* args, pulse_stream_t s);
+
+typedef struct pulse_vae_head_bwd_args {
+    const float* zheads; int64_t zheads_stride;
+    const float* pheads; int64_t pheads_stride; /* NULL: no KL / regulariser terms (the PPO backward through the VAE) */
+    const float* eps; int64_t eps_stride;       /* the noise the forward used (NULL: z = mu) */
+    const float* dz; int64_t dz_stride;         /* d loss / d z from the decoder's input gradient (NULL: none) */
+    const int64_t* progress;
+    int32_t rows, embedding_size, horizon;
+    int32_t clamp_logvar; float clamp_max;
+    float c_kl;    /* kld_coefficient / rows */
+    float c_ar1;   /* ar1_coefficient / (sequences * (horizon - 1)) or 0 */
+    float c_regu;  /* 0.005 * 0.001 / (rows * E) or 0 */
+    float* dzheads; int64_t dzheads_stride;     /* out (rows, 2E) */
+    float* dpheads; int64_t dpheads_stride;     /* out (rows, 2E), optional */
+} pulse_vae_head_bwd_args;
+int pulse_vae_head_backward(const pulse_vae_head_bwd_args* args, pulse_stream_t s);
 
 /* out[i] = scale * sum_s slabs[s*slab_stride + i]  (deterministic split-K / partial-sum reduction) */
 int pulse_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count, float* out,

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -122,6 +122,29 @@ class PdSimArgs(Structure):
                 ("reset_mask", c_void_p)]
 
 
+class VaeEmbedArgs(Structure):
+    _fields_ = [("heads", c_void_p), ("heads_stride", c_int64), ("eps", c_void_p), ("eps_stride", c_int64), ("x", c_void_p), ("x_stride", c_int64),
+                ("ain", c_void_p), ("ain_stride", c_int64), ("cin", c_void_p), ("cin_stride", c_int64),
+                ("rows", c_int32), ("embedding_size", c_int32), ("self_obs_size", c_int32), ("z_col", c_int32),
+                ("clamp_logvar", c_int32), ("clamp_max", c_float)]
+
+
+class VaeKinArgs(Structure):
+    _fields_ = [("pred", c_void_p), ("pred_stride", c_int64), ("gt", c_void_p), ("gt_stride", c_int64),
+                ("zheads", c_void_p), ("zheads_stride", c_int64), ("pheads", c_void_p), ("pheads_stride", c_int64), ("progress", c_void_p),
+                ("rows", c_int32), ("num_actions", c_int32), ("embedding_size", c_int32), ("horizon", c_int32),
+                ("clamp_logvar", c_int32), ("clamp_max", c_float), ("use_ar1", c_int32), ("use_regu", c_int32),
+                ("dmu", c_void_p), ("dmu_stride", c_int64), ("partials", c_void_p), ("num_blocks", c_int32)]
+
+
+class VaeHeadBwdArgs(Structure):
+    _fields_ = [("zheads", c_void_p), ("zheads_stride", c_int64), ("pheads", c_void_p), ("pheads_stride", c_int64),
+                ("eps", c_void_p), ("eps_stride", c_int64), ("dz", c_void_p), ("dz_stride", c_int64), ("progress", c_void_p),
+                ("rows", c_int32), ("embedding_size", c_int32), ("horizon", c_int32), ("clamp_logvar", c_int32), ("clamp_max", c_float),
+                ("c_kl", c_float), ("c_ar1", c_float), ("c_regu", c_float),
+                ("dzheads", c_void_p), ("dzheads_stride", c_int64), ("dpheads", c_void_p), ("dpheads_stride", c_int64)]
+
+
 class GemmX3pDesc(Structure):
     _fields_ = [("A", c_void_p), ("a_plane_stride", c_int64), ("lda", c_int32),
                 ("B", c_void_p), ("b_plane_stride", c_int64), ("ldb", c_int32),
@@ -209,6 +232,9 @@ SIGNATURES = {
     "pulse_sizeof_gemm_desc": (c_int, []),
     "pulse_gemm_f32": (c_int, [POINTER(GemmDesc), P]),
     "pulse_gemm_x3p": (c_int, [POINTER(GemmX3pDesc), P]),
+    "pulse_vae_embed": (c_int, [POINTER(VaeEmbedArgs), P]),
+    "pulse_vae_kin_loss": (c_int, [POINTER(VaeKinArgs), P]),
+    "pulse_vae_head_backward": (c_int, [POINTER(VaeHeadBwdArgs), P]),
     "pulse_sizeof_gemm_x3p_desc": (c_int, []),
     "pulse_split_planes": (c_int, [P, c_int64, c_int32, c_int32, P, c_int64, c_int32, c_int32, P, P]),
     "pulse_reduce_slabs": (c_int, [P, c_int32, c_int64, c_int64, P, c_float, P]),

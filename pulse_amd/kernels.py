@@ -164,6 +164,50 @@ class Plan:
 
 
 # --------------------------------------------------------------------------- #
+# PULSE VAE head algebra (include/pulse_hip.h section 4c)
+# --------------------------------------------------------------------------- #
+def vae_embed(heads, x, ain, *, rows, embedding_size, self_obs_size, z_col, eps=None, cin=None, clamp=True, clamp_max=2.0):
+    a = _lib.VaeEmbedArgs()
+    a.heads, a.heads_stride = _chk(heads, "heads"), heads.stride(0)
+    a.eps, a.eps_stride = _chk(eps, "eps"), (eps.stride(0) if eps is not None else 0)
+    a.x, a.x_stride = _chk(x, "x"), x.stride(0)
+    a.ain, a.ain_stride = _chk(ain, "ain"), ain.stride(0)
+    a.cin, a.cin_stride = _chk(cin, "cin"), (cin.stride(0) if cin is not None else 0)
+    a.rows, a.embedding_size, a.self_obs_size, a.z_col = rows, embedding_size, self_obs_size, z_col
+    a.clamp_logvar, a.clamp_max = int(bool(clamp)), float(clamp_max)
+    _lib.check(_lib.load().pulse_vae_embed(ctypes.byref(a), _stream()), "pulse_vae_embed")
+
+
+def vae_kin_loss(pred, gt, zheads, pheads, progress, dmu, partials, *, rows, num_actions, embedding_size, horizon, clamp=True, clamp_max=2.0,
+                 use_ar1=True, use_regu=False):
+    a = _lib.VaeKinArgs()
+    a.pred, a.pred_stride, a.gt, a.gt_stride = _chk(pred, "pred"), pred.stride(0), _chk(gt, "gt"), gt.stride(0)
+    a.zheads, a.zheads_stride, a.pheads, a.pheads_stride = _chk(zheads, "zheads"), zheads.stride(0), _chk(pheads, "pheads"), pheads.stride(0)
+    a.progress = _chk(progress, "progress", torch.int64)
+    a.rows, a.num_actions, a.embedding_size, a.horizon = rows, num_actions, embedding_size, horizon
+    a.clamp_logvar, a.clamp_max, a.use_ar1, a.use_regu = int(bool(clamp)), float(clamp_max), int(bool(use_ar1)), int(bool(use_regu))
+    a.dmu, a.dmu_stride = _chk(dmu, "dmu"), dmu.stride(0)
+    a.partials, a.num_blocks = _chk(partials, "partials"), partials.shape[0]
+    _lib.check(_lib.load().pulse_vae_kin_loss(ctypes.byref(a), _stream()), "pulse_vae_kin_loss")
+
+
+def vae_head_backward(zheads, dzheads, *, rows, embedding_size, horizon=1, pheads=None, dpheads=None, eps=None, dz=None, progress=None, clamp=True,
+                      clamp_max=2.0, c_kl=0.0, c_ar1=0.0, c_regu=0.0):
+    a = _lib.VaeHeadBwdArgs()
+    a.zheads, a.zheads_stride = _chk(zheads, "zheads"), zheads.stride(0)
+    a.pheads, a.pheads_stride = _chk(pheads, "pheads"), (pheads.stride(0) if pheads is not None else 0)
+    a.eps, a.eps_stride = _chk(eps, "eps"), (eps.stride(0) if eps is not None else 0)
+    a.dz, a.dz_stride = _chk(dz, "dz"), (dz.stride(0) if dz is not None else 0)
+    a.progress = _chk(progress, "progress", torch.int64)
+    a.rows, a.embedding_size, a.horizon = rows, embedding_size, horizon
+    a.clamp_logvar, a.clamp_max = int(bool(clamp)), float(clamp_max)
+    a.c_kl, a.c_ar1, a.c_regu = float(c_kl), float(c_ar1), float(c_regu)
+    a.dzheads, a.dzheads_stride = _chk(dzheads, "dzheads"), dzheads.stride(0)
+    a.dpheads, a.dpheads_stride = _chk(dpheads, "dpheads"), (dpheads.stride(0) if dpheads is not None else 0)
+    _lib.check(_lib.load().pulse_vae_head_backward(ctypes.byref(a), _stream()), "pulse_vae_head_backward")
+
+
+# --------------------------------------------------------------------------- #
 # planar ("x3p") fp32-grade GEMM: operands kept pre-split in HBM as three bf16 planes (include/pulse_hip.h section 4b)
 # --------------------------------------------------------------------------- #
 def planes_pitch(cols):

@@ -71,11 +71,6 @@ class ReplayBuffer:
         return self.data[self.sample_indices(n)]
 
 
-def kl_multi(qm, qv, pm, pv):
-    """phc/learning/loss_functions.py:3-10."""
-    return (0.5 * (pv - qv + qv.exp() / pv.exp() + (qm - pm).pow(2) / pv.exp() - 1)).sum(-1)
-
-
 class AMPAgent(CommonAgent):
     def __init__(self, base_name, config):
         super().__init__(base_name, config)
@@ -101,6 +96,7 @@ class AMPAgent(CommonAgent):
             self.kin_dict_info = None
         self.running_mean_std_temp = self.running_mean_std.clone_frozen()
         self.z_noise_provider = None                                      # tests inject the re-parameterisation noise
+        self._kin_partials = None
 
     # ------------------------------------------------------------------ AMP discriminator (amp_agent.py:851-1057)
     def _load_amp_config(self, config):
@@ -122,7 +118,6 @@ class AMPAgent(CommonAgent):
         self.disc_exp_avg = torch.zeros(self.disc.n_flat, device=self.ppo_device)
         self.disc_exp_avg_sq = torch.zeros(self.disc.n_flat, device=self.ppo_device)
         self._amp_replay_keep_prob = float(config["amp_replay_keep_prob"])
-        self._bce = torch.nn.BCEWithLogitsLoss()
 
     def _build_amp_buffers(self):
         gen = torch.Generator()
@@ -382,47 +377,50 @@ class AMPAgent(CommonAgent):
         self.train_result.update(info)
 
     def _optimize_kin(self, ws, mb, kin_dict):
-        """amp_agent.py:771-849 (z_type 'vae', learned prior)."""
+        """amp_agent.py:771-849 (z_type 'vae', learned prior): action RMSE + kld_coefficient KL(q || prior) + ar1_coefficient AR(1) latent
+        smoothness (seams masked through progress_buf) + 0.005 regulariser, own Adam(kin_lr).  Head algebra: pulse_vae_kin_loss (losses +
+        d loss / d pred_action) and pulse_vae_head_backward (encoder / prior head gradients); no autograd."""
         task = self.vec_env.env.task
         model = self.model
+        net = model.net
         gt_action = kin_dict["gt_action"]
         if self.z_noise_provider is not None:
             ws["z_noise"] = self.z_noise_provider(mb)
-        model.forward_actor(ws, mb, need_grad=True)
-        prior_mu, prior_log_var = model.compute_prior(ws, need_grad=True)
+        model.forward_actor(ws, mb)
+        model.compute_prior(ws)
+        g = ws["g"]
+        E, t = net.embedding_size, self.horizon_length
+        use_ar1, use_regu = bool(getattr(task, "use_ar1_prior", False)), bool(getattr(task, "use_vae_prior_regu", False))
+        prog = kin_dict["progress_buf"].reshape(-1).contiguous() if use_ar1 else None
+        if self._kin_partials is None:
+            self._kin_partials = torch.zeros(256, 8, device=self.ppo_device)
+        gt = gt_action if gt_action.stride(-1) == 1 else gt_action.contiguous()
+        K.vae_kin_loss(ws["mu"], gt, g.act_bufs["zheads"], g.act_bufs["pheads"], prog, ws["dmu"], self._kin_partials, rows=mb,
+                       num_actions=self.actions_num, embedding_size=E, horizon=t, clamp=net.use_vae_clamped_prior, clamp_max=net.vae_var_clamp_max,
+                       use_ar1=use_ar1, use_regu=use_regu)
+        sums = self._kin_partials.sum(0)                                       # fixed-order reduction of the per-workgroup partials
         info = {}
-        with torch.enable_grad():
-            pred_action = ws["mu"].detach().clone().requires_grad_(True)
-            vae_mu, vae_log_var = ws["vae_mu"], ws["vae_log_var"]
-            kin_action_loss = torch.norm(pred_action - gt_action, dim=-1).mean()
-            kld = kl_multi(vae_mu, vae_log_var, prior_mu, prior_log_var).mean()
-            ar1_prior, regu_prior = 0, 0
-            if getattr(task, "use_ar1_prior", False):
-                t = self.horizon_length
-                time_zs = vae_mu.view(mb // t, t, -1)
-                error = time_zs[:, 1:] - time_zs[:, :-1] * 0.99
-                idxes = kin_dict["progress_buf"].view(mb // t, t, -1)
-                not_consecs = ((idxes[:, 1:] - idxes[:, :-1]) != 1).view(-1)
-                starteres = ((idxes <= 2)[:, 1:] + (idxes <= 2)[:, :-1]).view(-1)
-                keep = (~(not_consecs | starteres)).to(error.dtype)
-                error = error.reshape(-1, error.shape[-1]) * keep[:, None]      # error[mask] = 0
-                ar1_prior = torch.norm(error, dim=-1).mean()
-                info["kin_ar1"] = ar1_prior.detach()
-            if getattr(task, "use_vae_prior_regu", False):
-                regu_prior = ((prior_mu ** 2).mean() + (vae_mu ** 2).mean()) * 0.001 + ((prior_log_var ** 2).mean() + (vae_log_var ** 2).mean()) * 0.001
-                info["kin_prior_regu"] = regu_prior.detach()
-            kin_loss = kin_action_loss + kld * task.kld_coefficient + ar1_prior * task.ar1_coefficient + regu_prior * 0.005
-            g_pred, = torch.autograd.grad(kin_loss, pred_action, retain_graph=True)
-        info["kin_action_loss"], info["kin_KLD"] = kin_action_loss.detach(), kld.detach()
-        if task.kld_anneal:                                                     # :826-832
+        kin_action_loss, kld = sums[0] / mb, sums[1] / mb
+        n_err = (mb // t) * (t - 1)
+        ar1_prior = sums[2] / n_err if use_ar1 else 0
+        if use_ar1:
+            info["kin_ar1"] = ar1_prior
+        regu_prior = 0
+        if use_regu:
+            regu_prior = (sums[3] + sums[4]) / (mb * E) * 0.001 + (sums[5] + sums[6]) / (mb * E) * 0.001
+            info["kin_prior_regu"] = regu_prior
+        kld_w = float(task.kld_coefficient)
+        kin_loss = kin_action_loss + kld * kld_w + ar1_prior * task.ar1_coefficient + regu_prior * 0.005
+        info["kin_action_loss"], info["kin_KLD"] = kin_action_loss, kld
+        if task.kld_anneal:                                                     # :826-832 (after the loss: this step used the old weight)
             if self.epoch_num > 2500:
                 mn = task.kld_coefficient_min
                 task.kld_coefficient = (0.01 - mn) * max((5000 - self.epoch_num) / 2500, 0) + mn
             info["kin_kld_w"] = task.kld_coefficient
-        # ---- backward through the GEMM plans; head-level gradients come from the autograd graph above
+        # ---- backward through the GEMM plans; the head-level gradients join at the encoder / prior heads
         model.book.slabs.zero_()
-        ws["dmu"].copy_(g_pred)
-        model.backward_actor(ws, extra_loss=kin_loss)
+        model.backward_actor(ws, kin={"c_kl": kld_w / mb, "c_ar1": (task.ar1_coefficient / n_err) if use_ar1 else 0.0,
+                                      "c_regu": (0.005 * 0.001 / (mb * E)) if use_regu else 0.0, "progress": prog, "horizon": t})
         model.backward_prior(ws)
         model.book.reduce_grads(1.0 / self.world_size)
         if self.multi_gpu:
@@ -431,6 +429,6 @@ class AMPAgent(CommonAgent):
         K.sqnorm_partial(model.grad, model.n_flat, self._sq_partials[:256])
         K.adam_step(model.flat, model.grad, self.kin_exp_avg, self.kin_exp_avg_sq, model.n_flat, lr=self.kin_lr, step=self.kin_step,
                     max_norm=self.grad_norm, sqnorm_partials=self._sq_partials[:256], grad_norm_out=self._grad_norm)
-        info["kin_loss"] = kin_loss.detach()
+        info["kin_loss"] = kin_loss
         info["grad_norm"] = self._grad_norm.clone()
         return info

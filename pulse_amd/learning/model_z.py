@@ -3,11 +3,13 @@ AMPAgent drive: workspace(m, train) / forward / eval_critic / backward over one 
 
 Forward of the policy follows AMPZBuilder.Network.eval_actor (amp_network_z_builder.py:422-467):
 encoder plan -> form_embedding (log-var clamp, re-parameterisation with fresh N(0,1) noise, :82-121) ->
-cat(self_obs, z) -> decoder plan -> mu.  The (B,32) head algebra runs as ordinary tensor ops on a detached
-leaf so that the SAME formulas provide the gradients (d z / d mu, d z / d logvar with the clamp mask) when
-the decoder's input gradient comes back from the GEMM plans.
+cat(self_obs, z) -> decoder plan -> mu.  The (B,32) head algebra is two fused launches (pulse_amd/csrc/vae_head.hip):
+pulse_vae_embed on the way forward, pulse_vae_head_backward (d z / d mu, d z / d logvar with the clamp mask, plus the KL / AR(1) /
+regulariser terms of _optimize_kin) when the decoder's input gradient comes back from the GEMM plans.  No autograd tape.
 """
 import torch
+
+from .. import kernels as K
 
 from .network_z import AMPZNetwork
 
@@ -57,26 +59,30 @@ class AMPZModel:
             self._ws[m] = ws
         return ws
 
-    def _embed(self, ws, need_grad):
-        """form_embedding on the encoder heads; writes z and self_obs into the decoder's concat buffer."""
+    def _embed(self, ws):
+        """form_embedding (amp_network_z_builder.py:79-121) on the encoder heads in one launch: clamp, re-parameterise, and place z and the
+        self observation in the decoder's (and the critic's) concat buffer.  The noise is ws['z_noise'] when a test injected it, a fresh
+        draw otherwise; z = mu in test mode."""
         net, g = self.net, ws["g"]
-        E, S, zc = net.embedding_size, net.self_obs_size, net.z_col
-        heads = g.act_bufs["zheads"].detach()
-        if need_grad:
-            heads = heads.clone().requires_grad_(True)
-        with torch.enable_grad() if need_grad else torch.no_grad():
-            vae_mu, vae_logvar = net.split_heads(heads)
-            eps = ws["z_noise"] if ws["z_noise"] is not None else torch.randn(heads.shape[0], E, device=self.device, generator=self.generator)
-            z = vae_mu + torch.exp(0.5 * vae_logvar) * eps
-        ain = g.act_bufs["ain"]
-        ain[:, :S].copy_(ws["x"][:, :S])
-        ain[:, zc:zc + E].copy_(z.detach())
-        ws.update({"heads_leaf": heads, "vae_mu": vae_mu, "vae_log_var": vae_logvar, "z": z, "eps": eps})
+        E, S = net.embedding_size, net.self_obs_size
+        heads = g.act_bufs["zheads"]
+        m = heads.shape[0]
+        if getattr(self, "deterministic_z", False):
+            eps = None
+        elif ws["z_noise"] is not None:
+            eps = ws["z_noise"]
+        else:
+            eps = ws.get("_eps_buf")
+            if eps is None:
+                eps = ws["_eps_buf"] = torch.empty(m, E, device=self.device)
+            eps.normal_(generator=self.generator)
+        K.vae_embed(heads, ws["x"], g.act_bufs["ain"], rows=m, embedding_size=E, self_obs_size=S, z_col=net.z_col, eps=eps, cin=g.act_bufs["cin"],
+                    clamp=net.use_vae_clamped_prior, clamp_max=net.vae_var_clamp_max)
+        ws["eps"] = eps
 
     def forward_actor(self, ws, m, need_grad=None):
-        need_grad = self.training if need_grad is None else need_grad
         ws["G"]["fwd_enc"].run()
-        self._embed(ws, need_grad)
+        self._embed(ws)
         ws["G"]["fwd_dec"].run()
 
     def eval_critic(self, ws, m):
@@ -85,40 +91,33 @@ class AMPZModel:
         ws["G"]["fwd_critic"].run()
 
     def forward(self, ws, m):
-        self.forward_actor(ws, m)
-        self.eval_critic(ws, m)
+        self.forward_actor(ws, m)                                    # (_embed also fills the critic's self-observation columns)
+        ws["G"]["fwd_critic"].run()
 
     def compute_prior(self, ws, need_grad=False):
-        """compute_prior (:226-241) -> (prior_mu, prior_logvar) as tensors on a detached leaf."""
+        """compute_prior (:226-241): runs the prior MLP; the raw heads [mu | logvar] stay in the graph buffer 'pheads' (split_heads clamps)."""
         ws["G"]["fwd_prior"].run()
-        ph = ws["g"].act_bufs["pheads"].detach()
-        if need_grad:
-            ph = ph.clone().requires_grad_(True)
-        with torch.enable_grad() if need_grad else torch.no_grad():
-            pm, pv = self.net.split_heads(ph)
-        ws["prior_leaf"] = ph
-        return pm, pv
+        return self.net.split_heads(ws["g"].act_bufs["pheads"])
 
     # ---- backward
-    def backward_actor(self, ws, extra_loss=None):
-        """d loss/d mu is already in ws['dmu'].  Back-propagates decoder -> z -> encoder; ``extra_loss`` is an
-        optional scalar built from ws['vae_mu'] / ws['vae_log_var'] (e.g. the KL term) whose gradient is added
-        at the heads."""
+    def backward_actor(self, ws, kin=None):
+        """d loss/d mu is already in ws['dmu'].  Back-propagates decoder -> z -> encoder.  ``kin``: the head-level terms of _optimize_kin
+        (dict c_kl, c_ar1, c_regu, progress, horizon) whose gradients join the re-parameterisation path at the encoder / prior heads; one
+        launch of pulse_vae_head_backward either way."""
         g, net = ws["g"], self.net
         E, zc = net.embedding_size, net.z_col
         ws["G"]["bwd_dec"].run()
         dz = g.grad("ain")[:, zc:zc + E]
-        tensors, grads = [ws["z"]], [dz]
-        if extra_loss is not None:
-            tensors.append(extra_loss)
-            grads.append(None)
-        torch.autograd.backward(tensors, grads)
-        g.grad("zheads").copy_(ws["heads_leaf"].grad)
+        heads = g.act_bufs["zheads"]
+        kw = dict(rows=heads.shape[0], embedding_size=E, eps=ws["eps"], dz=dz, clamp=net.use_vae_clamped_prior, clamp_max=net.vae_var_clamp_max)
+        if kin is not None:
+            kw.update(pheads=g.act_bufs["pheads"], dpheads=g.grad("pheads"), progress=kin.get("progress"), horizon=kin.get("horizon", 1),
+                      c_kl=kin["c_kl"], c_ar1=kin.get("c_ar1", 0.0), c_regu=kin.get("c_regu", 0.0))
+        K.vae_head_backward(heads, g.grad("zheads"), **kw)
         ws["G"]["bwd_enc"].run()
 
     def backward_prior(self, ws):
-        ws["g"].grad("pheads").copy_(ws["prior_leaf"].grad)
-        ws["G"]["bwd_prior"].run()
+        ws["G"]["bwd_prior"].run()                                  # d loss / d prior heads was written by backward_actor(kin=...)
 
     def backward(self, ws, m, grad_scale=1.0):
         """PPO backward: actor (through the VAE) + critic; weight gradients of untouched sub-nets stay zero."""

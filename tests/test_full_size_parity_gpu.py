@@ -1,0 +1,192 @@
+"""GPU: FULL-SIZE parity of BASELINE.json configs[2] (cfg3: 8192 envs x 32, PULSE VAE network [3096, 2048, 1024] / [1536, 1024, 512]) and
+configs[4] (cfg5: 8192 envs x 32, AMP discriminator + PPO, fp32 and bf16) -- round-2 verdict, weak #5: these widths (a 127 MB gradient
+buffer, 16384-row minibatches, the split-K slab path) were only pinned at 64 x 16 before.
+
+The CPU oracle cannot replay a 262 144-step rollout through a 29 M-parameter network in test time, so the full-size runs are compared
+where the work is: the FIRST minibatch step (16384 rows, every normaliser / forward / loss / gradient / clip) on the device's own
+full-size dataset against the oracle's restatement of the reference method (phc/learning/amp_agent.py:605-760, 771-849), plus the
+full-size rollout pieces that are cheap to restate (discriminator rewards on a row sample, GAE on the whole (T, N) grid).
+
+north_star bars: fp32 advantages within 1e-5 on the same inputs, first policy grad-norm within 1e-4; bf16: the device sits within the
+bf16 rounding noise of the torch.autocast(bfloat16) oracle (self-calibrating bound, tests/test_bf16_gpu.py).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import agent_oracle as AO
+from oracle import amp_oracle as AMPO
+from oracle import env_oracle as E
+from pulse_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ cfg3: PULSE distillation step
+def test_cfg3_full_size_kin_minibatch(dev):
+    torch.manual_seed(31)
+    agent, _ = configs.make_agent("cfg3", device=str(dev), seed=31)
+    assert (agent.num_actors, agent.horizon_length, agent.minibatch_size) == (8192, 32, 16384)
+    agent.init_tensors()
+    task = agent.vec_env.env.task
+    ref = AO.OracleNetZ()
+    agent.model.load_state_dict(ref.state_dict_ref())
+    assert agent.model.n_flat > 29_000_000
+    t, mb = agent.horizon_length, agent.minibatch_size
+    g = torch.Generator().manual_seed(200)
+    obs = torch.randn(mb, 934, generator=g).clamp(-5, 5)
+    gt = (0.4 * torch.randn(mb, 69, generator=g)).clamp(-1, 1)
+    prog = (torch.randint(0, 40, (mb // t, 1), generator=g) + torch.arange(t)[None, :]).reshape(-1, 1)
+    prog[5 * t + 7:6 * t] = torch.arange(t - 7)[:, None]                      # an episode seam inside sequence 5
+    noise = torch.randn(mb, 32, generator=g)
+    info_ref = AO.oracle_optimize_kin(ref, obs, gt, prog, noise, t, kld_coefficient=float(task.kld_coefficient), ar1_coefficient=task.ar1_coefficient)
+    grads_ref = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
+    gn_ref = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), agent.grad_norm))
+    agent.set_train()
+    agent.epoch_num = 100
+    ws = agent.model.workspace(mb, train=True)
+    ws["x"].zero_()
+    ws["x"][:, :934] = obs.to(dev)
+    agent.z_noise_provider = lambda m: noise.to(dev)
+    info = agent._optimize_kin(ws, mb, {"gt_action": gt.to(dev), "progress_buf": prog.to(dev)})
+    for k in ("kin_action_loss", "kin_KLD", "kin_ar1", "kin_loss"):
+        assert _rel(info[k].item(), info_ref[k].item()) <= 2e-5, (k, info[k].item(), info_ref[k].item())
+    assert _rel(info["grad_norm"].item(), gn_ref) <= 1e-4, (info["grad_norm"].item(), gn_ref)
+    # every parameter gradient of the 29 M-parameter network (the split-K slab path at its real widths)
+    grads = agent.model.net.gradients()
+    for name, gr in grads_ref.items():
+        d = grads["a2c_network." + name].cpu().double().reshape(gr.shape) - gr.double()
+        scale = gr.double().abs().max().item() + 1e-12
+        assert d.abs().max().item() <= 3e-4 * scale, (name, d.abs().max().item(), scale)
+
+
+# ------------------------------------------------------------------------------------------------ cfg3 network under the PPO loss
+def test_cfg3_full_size_ppo_first_minibatch_on_amp_z(dev):
+    torch.manual_seed(33)
+    agent, _ = configs.make_agent("cfg3_ppo", device=str(dev), seed=33, permutation_device="cpu")
+    assert (agent.num_actors, agent.horizon_length, agent.minibatch_size) == (8192, 32, 16384)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent._tensors_ready = True
+    ref = AO.OracleNetZ()
+    agent.model.load_state_dict(ref.state_dict_ref())
+    agent.pre_epoch(1)
+    batch = agent.play_steps()                                              # the full 8192 x 32 rollout on the device
+    batch.pop("played_frames")
+    td = agent.experience_buffer.tensor_dict
+    adv_same = E.gae(td["dones"].float().cpu(), td["values"].cpu(), td["rewards"].cpu(), td["next_values"].cpu(), 0.99, 0.95)
+    adv_dev = agent.discount_values(td["dones"], td["values"], td["rewards"], td["next_values"])
+    np.testing.assert_allclose(adv_dev.cpu().numpy(), adv_same.numpy(), atol=1e-5)       # GAE over the whole (32, 8192) grid
+    agent.set_train()
+    agent.prepare_dataset(batch)
+    ds = agent.dataset.values_dict
+    item = agent.dataset[0]
+    idx = item["idx"]
+    mb = idx.numel()
+    assert mb == 16384
+    noise = torch.randn(mb, 32, generator=torch.Generator().manual_seed(5))
+    agent.model.workspace(mb, train=True)["z_noise"] = noise.to(dev)
+    agent._begin_loss_ring(1)
+    res = agent.train_actor_critic(item)
+    agent._end_loss_ring()
+    # ---- the oracle on the same rows (AMPAgent.calc_gradients, PPO branch, amp_agent.py:605-760: frozen-copy normaliser = the initial
+    #      statistics in the first epoch: (x - 0) / sqrt(1 + 1e-5), clamp +-5)
+    rows = lambda tns: tns[idx].detach().cpu()
+    obs = rows(agent.experience_buffer.flat("obses"))[:, :934]
+    obs_n = torch.clamp(obs / math.sqrt(1.0 + 1e-5), -5.0, 5.0)
+    actions, old_mu = rows(ds["actions"])[:, :69], rows(ds["mu"])[:, :69]
+    old_nlp, adv, ret = rows(ds["old_logp_actions"]).reshape(-1), rows(ds["advantages"]).reshape(-1), rows(ds["returns"]).reshape(-1, 1)
+    mu, logstd, _ = ref.eval_actor(obs_n, noise)
+    values = ref.eval_critic(obs_n)
+    sigma = torch.exp(logstd)
+    nlp = AO.OracleNet.neglogp(actions, mu, sigma, logstd)
+    ratio = torch.exp(old_nlp - nlp)
+    a_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 0.8, 1.2)).mean()
+    c_loss = ((ret - values) ** 2).mean()
+    b_loss = (torch.clamp_max(mu + 1.0, 0.0) ** 2 + torch.clamp_min(mu - 1.0, 0.0) ** 2).sum(-1).mean()
+    loss = a_loss + agent.critic_coef * c_loss + agent.bounds_loss_coef * b_loss
+    loss.backward()
+    gn_ref = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), agent.grad_norm))
+    assert _rel(res["grad_norm"].item(), gn_ref) <= 1e-4, (res["grad_norm"].item(), gn_ref)
+    for key, want in (("actor_loss", a_loss), ("critic_loss", c_loss), ("b_loss", b_loss)):
+        assert abs(float(res[key]) - float(want)) <= 2e-4 * abs(float(want)) + 2e-6, (key, float(res[key]), float(want))
+    with torch.no_grad():
+        kl = AO.policy_kl(mu, sigma, old_mu, torch.exp(old_mu * 0.0 + ref.sigma), True)
+    assert abs(float(res["kl"]) - float(kl)) <= 2e-3 * abs(float(kl)) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ cfg5: AMP discriminator + PPO
+def _cfg5_first_minibatch(dev, mixed, seed=41):
+    torch.manual_seed(seed)
+    ag, _ = configs.make_agent("cfg5", device=str(dev), seed=seed, permutation_device="cpu", mixed_precision=mixed)
+    assert (ag.num_actors, ag.horizon_length, ag.minibatch_size, ag._amp_minibatch_size) == (8192, 32, 16384, 4096)
+    ag.init_tensors()
+    ag.obs = ag.env_reset()
+    ag._tensors_ready = True
+    init = (ag.model.state_dict(), ag.disc.state_dict())
+    ag.pre_epoch(1)
+    batch = ag.play_steps()
+    batch.pop("played_frames")
+    ag.set_train()
+    ag.prepare_dataset(batch)
+    item = ag.dataset[0]
+    ag._begin_loss_ring(1)
+    res = ag.train_actor_critic(item)
+    ag._end_loss_ring()
+    return ag, res, item["idx"], init
+
+
+def _cfg5_oracle(ag, idx, init, mixed):
+    cfg = dict(ag.config)
+    cfg["mixed_precision"] = mixed
+    orc = AMPO.OracleAMPAgent(cfg, ag.obs_shape[0], ag._amp_dim, init[0], init[1], cfg["network"]["mlp"]["units"], (ag.disc.u1, ag.disc.u2))
+    ds, w = ag.dataset.values_dict, ag._amp_dim
+    rows = lambda tns: tns[idx].detach().cpu()
+    eb = ag.experience_buffer
+    sig = torch.exp(rows(ds["mu"])[:, :69] * 0.0 + orc.net.sigma)
+    orc.values_dict = {"old_values": rows(ds["old_values"]), "old_logp_actions": rows(ds["old_logp_actions"]), "advantages": rows(ds["advantages"]),
+                       "returns": rows(ds["returns"]), "actions": rows(ds["actions"])[:, :69], "obs": rows(eb.flat("obses"))[:, :934],
+                       "mu": rows(ds["mu"])[:, :69], "sigma": sig, "amp_obs": rows(eb.flat("amp_obs"))[:, :w]}
+    demo = ag._amp_obs_demo_buffer.data[ds["_amp_demo_idx"][idx]][:, :w].cpu()
+    assert ds["_amp_replay_idx"] is None                                  # first epoch: replay rows = the rollout's own rows
+    replay = orc.values_dict["amp_obs"]
+    n = idx.numel()
+    return orc, orc.update([torch.arange(n)], demo, replay)[0]
+
+
+def test_cfg5_full_size_first_minibatch_fp32(dev):
+    ag, res, idx, init = _cfg5_first_minibatch(dev, mixed=False)
+    td = ag.experience_buffer.tensor_dict
+    # full-size rollout pieces: GAE on the whole grid from the stored inputs; discriminator rewards on a row sample
+    mbr = ag._mb_rewards.transpose(0, 1)
+    adv_same = E.gae(td["dones"].float().cpu(), td["values"].cpu(), mbr.cpu(), td["next_values"].cpu(), 0.99, 0.95)
+    np.testing.assert_allclose(ag.discount_values(td["dones"], td["values"], mbr, td["next_values"]).cpu().numpy(), adv_same.numpy(), atol=1e-5)
+    orc, o = _cfg5_oracle(ag, idx, init, mixed=False)
+    sample = torch.randperm(ag.batch_size, generator=torch.Generator().manual_seed(1))[:4096]
+    amp_rows = ag.experience_buffer.flat("amp_obs")[sample.to(dev)][:, :ag._amp_dim].cpu()
+    fresh = AMPO.OracleAMPAgent(dict(ag.config), ag.obs_shape[0], ag._amp_dim, init[0], init[1], ag.config["network"]["mlp"]["units"], (ag.disc.u1, ag.disc.u2))
+    fresh._mode(False)
+    with torch.no_grad():
+        dr = AO.oracle_disc_rewards(fresh.disc, fresh.amp_mean_std, amp_rows, ag.config["disc_reward_scale"])
+    np.testing.assert_allclose(ag._disc_r.reshape(-1, 1)[sample.to(dev)].cpu().numpy(), dr.numpy(), atol=2e-5, rtol=5e-5)
+    assert _rel(res["grad_norm"].item(), float(o["grad_norm"])) <= 1e-4, (res["grad_norm"].item(), float(o["grad_norm"]))
+    for key in ("actor_loss", "critic_loss", "b_loss", "kl", "disc_loss", "disc_grad_penalty"):
+        assert abs(float(res[key]) - float(o[key])) <= 3e-4 * abs(float(o[key])) + 2e-6, (key, float(res[key]), float(o[key]))
+
+
+def test_cfg5_full_size_first_minibatch_bf16(dev):
+    ag, res, idx, init = _cfg5_first_minibatch(dev, mixed=True)
+    assert ag.mixed_precision and ag.model.mixed_precision and ag.disc.mixed_precision
+    _, o16 = _cfg5_oracle(ag, idx, init, mixed=True)
+    _, o32 = _cfg5_oracle(ag, idx, init, mixed=False)
+    for key in ("actor_loss", "critic_loss", "b_loss", "disc_loss", "disc_grad_penalty", "grad_norm"):
+        a16, a32, d = float(o16[key]), float(o32[key]), float(res[key])
+        gap, err, scale = abs(a16 - a32), abs(d - a16), abs(a16) + 1e-6
+        # same weights on both sides: the device must sit within the bf16 rounding noise of the autocast oracle
+        assert err <= max(2.0 * gap, 4e-3 * scale), (key, d, a16, a32)

@@ -47,7 +47,7 @@ class EpisodeMeter:
         return sum(r for r, _ in v) / max(1.0, sum(l for _, l in v))
 
 
-def run(iters, seed=7, device="cuda:0", window=None, log=print, side="both"):
+def run(iters, seed=7, device="cuda:0", window=None, log=print, side="both", envs=None):
     """side: 'both' trains the two agents in lockstep (short runs / tests); 'device' or 'oracle' trains one of them and returns its
     episode stream -- the CPU oracle needs no GPU, so the long experiment runs its two halves on different machines and
     ``merge`` compares them (seeds, noise and permutations are functions of (seed, epoch) only)."""
@@ -56,12 +56,15 @@ def run(iters, seed=7, device="cuda:0", window=None, log=print, side="both"):
     from pulse_amd import configs
     window = window or max(1, iters // 5)
     cfg, num_envs = configs.agent_config("cfg1")
+    if envs:
+        num_envs = int(envs)
     T = cfg["horizon_length"]
     env_over = {"physics": "pd", "stateInit": "Start"}
     torch.set_num_threads(min(8, torch.get_num_threads()))       # the oracle's ops are tiny: a 128-thread pool only adds overhead
     agent = None
     if side in ("both", "device"):
-        agent, _ = configs.make_agent("cfg1", device=device, seed=seed, reference="motion_lib", env_overrides=env_over, permutation_device="cpu")
+        agent, _ = configs.make_agent("cfg1", device=device, seed=seed, reference="motion_lib", env_overrides=env_over, permutation_device="cpu",
+                                      num_envs_override=num_envs)
     torch.manual_seed(seed)
     oenv = MO.make_agent_env(num_envs, T, seed, physics="pd", state_init_start=True)
 
@@ -110,8 +113,9 @@ def run(iters, seed=7, device="cuda:0", window=None, log=print, side="both"):
             log(f"[return_parity] iter {it}: device {a:.4f} ({na} eps)  oracle {b:.4f} ({nb} eps)  ({t_dev:.0f} s device, {t_ref:.0f} s oracle)")
     if side != "both":
         m = m_dev if side == "device" else m_ref
-        return {"side": side, "iterations": iters, "seed": seed, "finished": m.finished, "seconds": t_dev if side == "device" else t_ref,
-                "torch": torch.__version__}
+        from pulse_amd import kernels as K_
+        return {"side": side, "iterations": iters, "seed": seed, "envs": num_envs, "finished": m.finished, "seconds": t_dev if side == "device" else t_ref,
+                "torch": torch.__version__, "gemm_f32_arithmetic": K_.F32_MODE if side == "device" else "torch CPU fp32"}
     lo = iters - window
     a, na = m_dev.mean_return(lo, iters)
     b, nb = m_ref.mean_return(lo, iters)
@@ -129,7 +133,7 @@ def run(iters, seed=7, device="cuda:0", window=None, log=print, side="both"):
 def merge(dev_path, ref_path, window=None):
     """Compare the episode streams of a 'device' run and an 'oracle' run of the same (seed, iterations)."""
     d, r = json.load(open(dev_path)), json.load(open(ref_path))
-    assert d["iterations"] == r["iterations"] and d["seed"] == r["seed"]
+    assert d["iterations"] == r["iterations"] and d["seed"] == r["seed"] and d.get("envs", 64) == r.get("envs", 64)
     iters = d["iterations"]
     window = window or max(1, iters // 5)
     md, mr = EpisodeMeter(1), EpisodeMeter(1)
@@ -142,7 +146,8 @@ def merge(dev_path, ref_path, window=None):
     for k in range(0, iters, max(1, iters // 10)):
         curve.append({"epochs": [k, min(iters, k + max(1, iters // 10))], "device": md.mean_return(k, k + max(1, iters // 10))[0],
                       "oracle": mr.mean_return(k, k + max(1, iters // 10))[0]})
-    return {"iterations": iters, "config": "cfg1 (64 envs x horizon 16, [512, 512]) on the PD physics stand-in, motion-library reference",
+    return {"iterations": iters, "config": f"cfg1 ({d.get('envs', 64)} envs x horizon 16, [512, 512]) on the PD physics stand-in, motion-library reference",
+            "gemm_f32_arithmetic": d.get("gemm_f32_arithmetic", "unrecorded"),
             "window_epochs": window, "device_mean_episode_return": a, "oracle_mean_episode_return": b, "episodes_in_window": [na, nb],
             "relative_difference": abs(a - b) / abs(b), "device_mean_step_reward": sa, "oracle_mean_step_reward": sb,
             "relative_difference_step_reward": abs(sa - sb) / abs(sb), "learning_curve_mean_episode_return": curve,
@@ -158,11 +163,12 @@ if __name__ == "__main__":
     ap.add_argument("--side", default="both", choices=["both", "device", "oracle"])
     ap.add_argument("--merge", nargs=2, default=None, metavar=("DEVICE_JSON", "ORACLE_JSON"))
     ap.add_argument("--out", default=None)
+    ap.add_argument("--envs", type=int, default=None, help="number of envs (default: cfg1's 64)")
     a = ap.parse_args()
     if a.merge:
         res = merge(*a.merge)
     else:
-        res = run(a.iters, seed=a.seed, side=a.side, log=lambda m: print(m, flush=True))
+        res = run(a.iters, seed=a.seed, side=a.side, log=lambda m: print(m, flush=True), envs=a.envs)
     print(json.dumps({k: v for k, v in res.items() if k != "finished"}, indent=1), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)

@@ -397,6 +397,90 @@ def gen_tasks(n=61):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "tasks.npz"), **_np(out))
 
 
+def synthetic_height_field(rows=260, cols=300, seed=5):
+    """A height field with slopes, steps and noise in Isaac Gym's storage format (int16 samples, vertical scale 0.005 m)."""
+    g = torch.Generator().manual_seed(seed)
+    x, y = torch.meshgrid(torch.arange(rows).float(), torch.arange(cols).float(), indexing="ij")
+    h = 0.6 * torch.sin(x / 23.0) * torch.cos(y / 31.0) + 0.15 * torch.floor(x / 40.0) + 0.05 * torch.randn(rows, cols, generator=g)
+    return torch.round(h / 0.005).to(torch.int16)
+
+
+def gen_terrain(n=37):
+    """HumanoidTraj / HumanoidPedestrianTerrain (terrain traversal): the reference's TrajGenerator (same seed -> same trajectories), its
+    TorchScript functions and the get_heights / get_center_heights / sample_height_points methods executed on a stub object."""
+    T = refload.terrain_functions()
+    g = syn.make_generator(909)
+    num_verts, episode_dur, dt = 101, 300 * (2.0 / 60.0), 2.0 / 60.0
+    rb = syn.rigid_body_state(g, n)
+    rb[:, :, 0:2] += 12.0 + 6.0 * torch.rand(n, 1, 2, generator=g)                   # inside the map (cells of 0.1 m, 260 x 300)
+    root = rb[:, 0].clone()
+    head = rb[:, 13].clone()
+    tg = T["TrajGenerator"](n, episode_dur, num_verts, "cpu", 2.0, 0.0, 3.0, 2.0, 0.02)
+    torch.manual_seed(4321)
+    tg.reset(torch.arange(n), root[:, 0:3])
+    verts = tg._verts.clone()
+    torch.manual_seed(4321)                                                            # the same draws, in the reference's order
+    u = {"dtheta": torch.rand(n, num_verts - 1), "sharp": torch.rand(n, num_verts - 1)}
+    u["sharp_mask"] = torch.bernoulli(0.02 * torch.ones(n, num_verts - 1)) == 1.0
+    u["heading"], u["dspeed"], u["speed0"] = torch.rand(n), torch.rand(n, num_verts - 1), torch.rand(n)
+    progress = torch.randint(0, 300, (n,), generator=g)
+    progress[:3] = torch.tensor([0, 1, 299])
+    stub = refload.stub_self(num_envs=n, device="cpu", dt=dt, progress_buf=progress, _num_traj_samples=10, _traj_sample_timestep=0.5, _traj_gen=tg)
+    samples = T["HumanoidTraj._fetch_traj_samples"](stub)
+    times = progress * dt
+    tar_pos = tg.calc_pos(torch.arange(n), times)
+    hs = synthetic_height_field()
+    sensor_res, ext = 32, 2.0
+    yy = torch.tensor(np.linspace(-ext, ext, sensor_res))
+    xx = torch.tensor(np.linspace(-ext, ext, sensor_res))
+    gx, gy = torch.meshgrid(xx, yy)
+    hp = torch.zeros(n, sensor_res * sensor_res, 3)
+    hp[:, :, 0], hp[:, :, 1] = gx.flatten(), gy.flatten()
+    cy, cx = torch.tensor(np.linspace(-0.2, 0.2, 3)), torch.tensor(np.linspace(-0.1, 0.1, 3))
+    cgx, cgy = torch.meshgrid(cx, cy)
+    cp = torch.zeros(n, 9, 3)
+    cp[:, :, 0], cp[:, :, 1] = cgx.flatten(), cgy.flatten()
+    terrain = refload.stub_self(heightsamples=hs, horizontal_scale=0.1, vertical_scale=0.005)
+    terrain.world_points_to_map = lambda pts: T["Terrain.world_points_to_map"](terrain, pts)
+    terrain.sample_height_points = lambda pts, **kw: T["Terrain.sample_height_points"](terrain, pts, **kw)
+    out = {"rb": rb, "verts": verts, "progress": progress, "traj_samples": samples, "tar_pos": tar_pos, "heightsamples": hs,
+           "height_points": hp[0, :, 0:2].clone(), "center_points": cp[0, :, 0:2].clone(), "dt": torch.tensor(dt),
+           "traj_dt": torch.tensor(episode_dur / (num_verts - 1)), **{"u_" + k: v for k, v in u.items()}}
+    for up in (True, False):
+        tag = "" if up else "_noup"
+        env = refload.stub_self(cfg={"env": {"terrain": {"terrainType": "trimesh"}}}, num_envs=n, device="cpu", humanoid_type="smpl", _has_upright_start=up,
+                                num_height_points=sensor_res * sensor_res, num_center_height_points=9, height_points=hp, center_height_points=cp,
+                                velocity_map=False, _divide_group=False, _group_obs=False, _disable_group_obs=False, terrain=terrain,
+                                _humanoid_root_states=root)
+        heights = T["HumanoidPedestrianTerrain.get_heights"](env, root_states=head[:, 0:7], env_ids=None)
+        center = T["HumanoidPedestrianTerrain.get_center_heights"](env, root_states=root, env_ids=None)
+        out[f"heights{tag}"], out[f"center_heights{tag}"] = heights, center
+        out[f"loc_obs{tag}"] = T["compute_location_observations"](root, samples, up)
+        hobs = torch.clip(center.mean(dim=-1, keepdim=True) - heights, -3, 3.) * 5                     # _compute_task_obs :414-424
+        out[f"task_obs{tag}"] = torch.cat([out[f"loc_obs{tag}"], hobs], dim=1)
+    out["traj_loc_obs"] = T["traj_compute_location_observations"](root, samples)
+    out["loc_rew"] = T["compute_location_reward"](root[:, 0:3], tar_pos)
+    out["loc_rew_fuzzy"] = T["compute_location_reward_fuzzy"](root[:, 0:3], tar_pos + 0.03)
+    contact = torch.zeros(n, 24, 3)
+    contact[::3, 7] = torch.tensor([10.0, 0.0, 400.0])                       # a foot in contact (ignored)
+    contact[1::4, 12] = torch.tensor([30.0, 30.0, 30.0])                     # a non-foot contact above 50 N in norm
+    contact[2::5, 16] = torch.tensor([0.3, 0.0, 0.0])                        # a light non-foot contact (fall_contact of the traj variant, not of the terrain one)
+    contact_ids = torch.tensor([7, 3, 8, 4])
+    far = tar_pos.clone()
+    far[5::6, 0] += 5.0                                                      # too far from the trajectory
+    term_h = torch.full((24,), 0.15)
+    bp = rb[..., 0:3].clone()
+    bp[2::5, 16, 2] = 0.05
+    reset0 = torch.zeros(n, dtype=torch.long)
+    out.update({"contact": contact, "contact_ids": contact_ids, "far_tar_pos": far, "term_h": term_h, "body_pos": bp})
+    out["terrain_reset"], out["terrain_terminated"] = T["terrain_compute_humanoid_reset"](reset0, progress, contact, contact_ids, torch.zeros(n), bp, far,
+                                                                                        300.0, 4.0, True, term_h, False)
+    out["terrain_reset_noearly"], _ = T["terrain_compute_humanoid_reset"](reset0, progress, contact, contact_ids, torch.zeros(n), bp, far, 300.0, 4.0, False,
+                                                                          term_h, False)
+    out["traj_reset"], out["traj_terminated"] = T["traj_compute_humanoid_reset"](reset0, progress, contact, contact_ids, bp, far, 300.0, 4.0, True, term_h)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "terrain.npz"), **_np(out))
+
+
 def main():
     assert refload.available(), "reference tree not found; goldens can only be generated in the build container"
     os.makedirs(GOLDEN_DIR, exist_ok=True)
@@ -407,6 +491,7 @@ def main():
     gen_env_amp()
     gen_env_variants()
     gen_env_shape_obs()
+    gen_terrain()
     gen_agent_math()
     gen_rms()
     gen_motion_lib()

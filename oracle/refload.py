@@ -268,6 +268,56 @@ def task_functions():
     return out
 
 
+def terrain_functions():
+    """HumanoidTraj / HumanoidPedestrianTerrain (README: the terrain-traversal PULSE command): the TorchScript functions
+    compute_location_observations (with the upright flag), compute_location_reward(_fuzzy), quat_apply_yaw and the terrain variant of
+    compute_humanoid_reset (humanoid_pedestrian_terrain.py:1476-1646), HumanoidTraj's compute_humanoid_reset (humanoid_traj.py:256-300),
+    the METHODS get_heights / get_center_heights (:690-772), _fetch_traj_samples (humanoid_traj.py:196-211) and Terrain.world_points_to_map /
+    sample_height_points (:1191-1270), plus the TrajGenerator class (phc/utils/traj_generator.py; its ``np.int`` needs numpy < 1.24, so
+    the name is supplied)."""
+    if "terrain" in _cache:
+        return _cache["terrain"]
+    import numpy as np
+    tasks = os.path.join(REFERENCE_ROOT, "phc", "env", "tasks")
+    out = {}
+    ns = _namespace()
+    flags = types.SimpleNamespace(divide_group=False, no_collision_check=False, fixed_path=False, slow=False, real_path=False, height_debug=False)
+    ns["flags"] = flags
+    # HumanoidTraj's own jit functions first (the terrain file re-defines two of the names)
+    for name, text in _extract(os.path.join(tasks, "humanoid_traj.py"), ["compute_humanoid_reset", "compute_location_observations"]).items():
+        ns_t = dict(ns)
+        exec(compile(text, f"<reference:humanoid_traj.py:{name}>", "exec"), ns_t)
+        out["traj_" + name] = ns_t[name]
+    tf = os.path.join(tasks, "humanoid_pedestrian_terrain.py")
+    for name, text in _extract(tf, ["compute_humanoid_reset", "quat_apply_yaw", "compute_location_observations", "compute_location_reward",
+                                    "compute_location_reward_fuzzy"]).items():
+        exec(compile(text, f"<reference:humanoid_pedestrian_terrain.py:{name}>", "exec"), ns)
+        out["terrain_" + name if name == "compute_humanoid_reset" else name] = ns[name]
+    ns["remove_base_rot"] = env_functions()["remove_base_rot"]
+    for cls, names in (("HumanoidPedestrianTerrain", ["get_heights", "get_center_heights"]), ("Terrain", ["world_points_to_map", "sample_height_points"])):
+        for name, text in _extract(tf, names, methods_of=cls).items():
+            exec(compile(text, f"<reference:{cls}.{name}>", "exec"), ns)
+            out[f"{cls}.{name}"] = ns[name]
+    for name, text in _extract(os.path.join(tasks, "humanoid_traj.py"), ["_fetch_traj_samples"], methods_of="HumanoidTraj").items():
+        exec(compile(text, f"<reference:HumanoidTraj.{name}>", "exec"), ns)
+        out[f"HumanoidTraj.{name}"] = ns[name]
+    if not hasattr(np, "int"):
+        np.int = int                                                 # traj_generator.py:54 (removed from numpy 1.24)
+    _ensure_paths()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_traj_generator", os.path.join(REFERENCE_ROOT, "phc", "utils", "traj_generator.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules.setdefault("joblib", __import__("joblib"))
+    spec.loader.exec_module(mod)
+    out["TrajGenerator"] = mod.TrajGenerator
+    for k in ("fixed_path", "slow", "real_path"):                    # run_hydra.py:284-301 sets these on the global flags object; training: all False
+        if not hasattr(mod.flags, k):
+            setattr(mod.flags, k, False)
+    out["flags"] = mod.flags
+    _cache["terrain"] = out
+    return out
+
+
 class _AttrDict(dict):
     """easydict.EasyDict stand-in (easydict is not installed): attribute access on a dict."""
     __getattr__ = dict.__getitem__

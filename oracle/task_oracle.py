@@ -108,3 +108,180 @@ def strike_reset(reset_buf, progress_buf, contact_buf, contact_body_ids, rigid_b
         terminated = torch.where(has_failed, torch.ones_like(reset_buf), terminated)
     reset = torch.where(progress_buf >= max_episode_length - 1, torch.ones_like(reset_buf), terminated)
     return reset, terminated
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HumanoidTraj / HumanoidPedestrianTerrain (phc/env/tasks/humanoid_traj.py, humanoid_pedestrian_terrain.py, phc/utils/traj_generator.py):
+# trajectory following over a height field -- the README's terrain-traversal command (learning=pulse_z_terrain, network amp_sept).
+#   traj_generate / traj_from_draws   TrajGenerator.reset   phc/utils/traj_generator.py:60-123
+#   traj_calc_pos                TrajGenerator.calc_pos     phc/utils/traj_generator.py:156-171
+#   fetch_traj_samples           HumanoidTraj._fetch_traj_samples   humanoid_traj.py:196-211
+#   traj_location_observations   compute_location_observations      humanoid_pedestrian_terrain.py:1587-1616
+#   location_reward(_fuzzy)      compute_location_reward(_fuzzy)    :1619-1646
+#   terrain_reset / traj_reset   compute_humanoid_reset             :1476-1531 / humanoid_traj.py:256-300
+#   sample_heights               Terrain.world_points_to_map + sample_height_points (no groups)   :1191-1270
+#   terrain_heights / terrain_center_heights   get_heights / get_center_heights   :690-772
+#   terrain_task_obs             _compute_task_obs          :384-440
+# ---------------------------------------------------------------------------------------------------------------------
+import math
+
+
+def traj_generate(init_pos, num_verts, dt, dtheta_max, speed_min, speed_max, accel_max, sharp_turn_prob, generator=None):
+    """TrajGenerator.reset for every env in ``init_pos`` (n, 3); draws exactly as the reference does.  Returns verts (n, num_verts, 3)."""
+    n = init_pos.shape[0]
+    dtheta = 2 * torch.rand([n, num_verts - 1], generator=generator) - 1.0
+    dtheta *= dtheta_max * dt
+    dtheta_sharp = math.pi * (2 * torch.rand([n, num_verts - 1], generator=generator) - 1.0)
+    sharp_probs = sharp_turn_prob * torch.ones_like(dtheta)
+    sharp_mask = torch.bernoulli(sharp_probs, generator=generator) == 1.0
+    dtheta[sharp_mask] = dtheta_sharp[sharp_mask]
+    dtheta[:, 0] = math.pi * (2 * torch.rand([n], generator=generator) - 1.0)
+    dspeed = 2 * torch.rand([n, num_verts - 1], generator=generator) - 1.0
+    dspeed *= accel_max * dt
+    dspeed[:, 0] = (speed_max - speed_min) * torch.rand([n], generator=generator) + speed_min
+    return traj_from_draws(init_pos, dtheta, dspeed, dt, speed_min, speed_max)
+
+
+def traj_from_draws(init_pos, dtheta, dspeed, dt, speed_min, speed_max):
+    """The deterministic half of TrajGenerator.reset (:78-113): speed scan with clipping, heading cumsum, vertex cumsum."""
+    n, segs = dtheta.shape
+    speed = torch.zeros_like(dspeed)
+    speed[:, 0] = dspeed[:, 0]
+    for i in range(1, segs):
+        speed[:, i] = torch.clip(speed[:, i - 1] + dspeed[:, i], speed_min, speed_max)
+    theta = torch.cumsum(dtheta, dim=-1)
+    seg_len = speed * dt
+    dpos = torch.stack([torch.cos(theta), -torch.sin(theta), torch.zeros_like(theta)], dim=-1)
+    dpos = dpos * seg_len.unsqueeze(-1)
+    dpos[..., 0, 0:2] += init_pos[..., 0:2]
+    verts = torch.zeros(n, segs + 1, 3)
+    verts[:, 0, 0:2] = init_pos[..., 0:2]
+    verts[:, 1:] = torch.cumsum(dpos, dim=-2)
+    return verts
+
+
+def traj_calc_pos(verts, traj_ids, times, dt):
+    num_verts = verts.shape[1]
+    traj_dur = num_verts * dt                                   # get_traj_duration (:150-153)
+    num_segs = num_verts - 1
+    phase = torch.clip(times / traj_dur, 0.0, 1.0)
+    seg_idx = phase * num_segs
+    id0, id1 = torch.floor(seg_idx).long(), torch.ceil(seg_idx).long()
+    lerp = (seg_idx - id0).unsqueeze(-1)
+    flat = verts.reshape(-1, 3)
+    pos0, pos1 = flat[traj_ids * num_verts + id0], flat[traj_ids * num_verts + id1]
+    return (1.0 - lerp) * pos0 + lerp * pos1
+
+
+def fetch_traj_samples(verts, progress, step_dt, traj_dt, num_samples, sample_timestep):
+    n = progress.shape[0]
+    beg = progress * step_dt
+    ts = torch.arange(num_samples, dtype=torch.float) * sample_timestep
+    tt = beg.unsqueeze(-1) + ts
+    ids = torch.arange(n).unsqueeze(-1).expand(-1, num_samples)
+    return traj_calc_pos(verts, ids.flatten(), tt.flatten(), traj_dt).reshape(n, num_samples, 3)
+
+
+def _base_rot(q, upright):
+    from .env_oracle import remove_base_rot
+    return q if upright else remove_base_rot(q)
+
+
+def traj_location_observations(root_states, traj_samples, upright=True):
+    root_pos, root_rot = root_states[:, 0:3], _base_rot(root_states[:, 3:7], upright)
+    h = R.heading_q_inv(root_rot)
+    n, t = traj_samples.shape[0], traj_samples.shape[1]
+    he = h.unsqueeze(-2).expand(n, t, 4).reshape(n * t, 4)
+    delta = (traj_samples - root_pos.unsqueeze(-2)).reshape(n * t, 3)
+    return R.qrot(he, delta)[..., 0:2].reshape(n, t * 2)
+
+
+def location_reward(root_pos, tar_pos, fuzzy=False):
+    d = tar_pos[..., 0:2] - root_pos[..., 0:2]
+    err = torch.sum(d * d, dim=-1)
+    if fuzzy:
+        err = err.clone()
+        err[err < 0.0025] = 0
+    return torch.exp(-2.0 * err)
+
+
+def traj_reset(reset_buf, progress_buf, contact_buf, contact_body_ids, rigid_body_pos, tar_pos, max_episode_length, fail_dist,
+               enable_early_termination, termination_heights):
+    terminated = torch.zeros_like(reset_buf)
+    if enable_early_termination:
+        has_fallen, _ = _fall(contact_buf, contact_body_ids, rigid_body_pos, termination_heights)
+        has_fallen = has_fallen * (progress_buf > 1)
+        d = tar_pos[..., 0:2] - rigid_body_pos[..., 0, 0:2]
+        tar_fail = torch.sum(d * d, dim=-1) > fail_dist * fail_dist
+        terminated = torch.where(torch.logical_or(has_fallen, tar_fail), torch.ones_like(reset_buf), terminated)
+    reset = torch.where(progress_buf >= max_episode_length - 1, torch.ones_like(reset_buf), terminated)
+    return reset, terminated
+
+
+def terrain_reset(reset_buf, progress_buf, contact_buf, contact_body_ids, rigid_body_pos, tar_pos, max_episode_length, fail_dist,
+                  enable_early_termination, disable_collision=False):
+    """The terrain variant: a fall is a summed non-foot contact force above 50 N (no height test)."""
+    terminated = torch.zeros_like(reset_buf)
+    if enable_early_termination:
+        masked = contact_buf.clone()
+        masked[:, contact_body_ids, :] = 0
+        has_fallen = torch.sqrt(torch.square(torch.abs(masked.sum(dim=-2))).sum(dim=-1)) > 50
+        has_fallen = has_fallen * (progress_buf > 1)
+        d = tar_pos[..., 0:2] - rigid_body_pos[..., 0, 0:2]
+        tar_fail = torch.sum(d * d, dim=-1) > fail_dist * fail_dist
+        failed = torch.logical_or(has_fallen, tar_fail)
+        if disable_collision:
+            failed = torch.zeros_like(failed)
+        terminated = torch.where(failed, torch.ones_like(reset_buf), terminated)
+    reset = torch.where(progress_buf >= max_episode_length - 1, torch.ones_like(reset_buf), terminated)
+    return reset, terminated
+
+
+def quat_apply(a, b):
+    """isaacgym.torch_utils.quat_apply (3P, oracle/shim): b + w t + xyz x t with t = 2 xyz x b."""
+    xyz = a[..., :3]
+    t = torch.cross(xyz, b, dim=-1) * 2
+    return b + a[..., 3:] * t + torch.cross(xyz, t, dim=-1)
+
+
+def sample_heights(heightsamples, points, horizontal_scale, vertical_scale):
+    """Terrain.world_points_to_map + sample_height_points without groups: integer cell (truncation), clip, min of the cell and its
+    diagonal neighbour, scaled.  heightsamples: (rows, cols) int16; points (B, P, 3)."""
+    p = (points / horizontal_scale).long()
+    px = torch.clip(p[:, :, 0].reshape(-1), 0, heightsamples.shape[0] - 2)
+    py = torch.clip(p[:, :, 1].reshape(-1), 0, heightsamples.shape[1] - 2)
+    h = torch.min(heightsamples[px, py], heightsamples[px + 1, py + 1])
+    return (h * vertical_scale).view(points.shape[0], -1)
+
+
+def terrain_heights(heightsamples, sensor_states, height_points, horizontal_scale, vertical_scale, upright=True):
+    """get_heights: the sensor grid rotated by the HEADING of the sensor body (head or root) and moved to it."""
+    q = _base_rot(sensor_states[:, 3:7], upright)
+    h = R.heading_q(q)
+    n, p = sensor_states.shape[0], height_points.shape[0]
+    pts = quat_apply(h.unsqueeze(1).expand(n, p, 4).reshape(-1, 4), height_points.unsqueeze(0).expand(n, p, 3).reshape(-1, 3)).view(n, p, 3)
+    pts = pts + sensor_states[:, :3].unsqueeze(1)
+    return sample_heights(heightsamples, pts, horizontal_scale, vertical_scale)
+
+
+def terrain_center_heights(heightsamples, root_states, center_points, horizontal_scale, vertical_scale, upright=True):
+    """get_center_heights: the 3 x 3 grid under the root, rotated by the root's YAW-ONLY quaternion (quat_apply_yaw)."""
+    q = _base_rot(root_states[:, 3:7], upright).clone()
+    q[:, :2] = 0.0
+    q = q / q.norm(p=2, dim=-1).clamp(min=1e-9).unsqueeze(-1)
+    n, p = root_states.shape[0], center_points.shape[0]
+    pts = quat_apply(q.unsqueeze(1).expand(n, p, 4).reshape(-1, 4), center_points.unsqueeze(0).expand(n, p, 3).reshape(-1, 3)).view(n, p, 3)
+    pts = pts + root_states[:, :3].unsqueeze(1)
+    return sample_heights(heightsamples, pts, horizontal_scale, vertical_scale)
+
+
+def terrain_task_obs(root_states, sensor_states, traj_samples, heightsamples, height_points, center_points, horizontal_scale=0.1,
+                     vertical_scale=0.005, upright=True, use_center_height=True, height_meas_scale=5.0):
+    obs = traj_location_observations(root_states, traj_samples, upright)
+    measured = terrain_heights(heightsamples, sensor_states, height_points, horizontal_scale, vertical_scale, upright)
+    if use_center_height:
+        center = terrain_center_heights(heightsamples, root_states, center_points, horizontal_scale, vertical_scale, upright).mean(dim=-1, keepdim=True)
+        heights = torch.clip(center - measured, -3, 3.) * height_meas_scale
+    else:
+        heights = torch.clip(root_states[:, 2:3] - measured, -3, 3.) * height_meas_scale
+    return torch.cat([obs, heights], dim=1)

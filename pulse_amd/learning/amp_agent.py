@@ -391,7 +391,8 @@ class AMPAgent(CommonAgent):
         g = ws["g"]
         E, t = net.embedding_size, self.horizon_length
         use_ar1, use_regu = bool(getattr(task, "use_ar1_prior", False)), bool(getattr(task, "use_vae_prior_regu", False))
-        prog = kin_dict["progress_buf"].reshape(-1).contiguous() if use_ar1 else None
+        # (the experience buffer stores kin_dict as floats: progress values are small integers, exact either way)
+        prog = kin_dict["progress_buf"].reshape(-1).to(torch.int64).contiguous() if use_ar1 else None
         if self._kin_partials is None:
             self._kin_partials = torch.zeros(256, 8, device=self.ppo_device)
         gt = gt_action if gt_action.stride(-1) == 1 else gt_action.contiguous()

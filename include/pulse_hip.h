@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 14
+#define PULSE_ABI_VERSION 15
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -398,6 +398,52 @@ typedef struct pulse_pd_sim_args {
 } pulse_pd_sim_args;
 int pulse_sizeof_pd_sim_args(void);
 int pulse_pd_sim_step(const pulse_pd_sim_args* args, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
+ * 2a''. Trajectory following over a height field (HumanoidTraj / HumanoidPedestrianTerrain, the README's terrain-traversal command):
+ *     task observation = ten trajectory samples in the heading frame (compute_location_observations,
+ *     humanoid_pedestrian_terrain.py:1587-1616) + the height map under a 32 x 32 sensor grid (get_heights / get_center_heights /
+ *     Terrain.sample_height_points, :690-772, 1191-1270; clip and scale of _compute_task_obs :414-427), location (+ power) reward
+ *     (:871-890, 1619-1646), and both variants of compute_humanoid_reset (:1476-1531, humanoid_traj.py:256-300).  One 256-thread
+ *     workgroup per env.  ``what`` uses the PULSE_TASK_* bits.
+ * ------------------------------------------------------------------------- */
+typedef struct pulse_traj_step_args {
+    uint32_t what; int32_t num_envs;
+    const int64_t* env_ids; int32_t num_ids; const uint8_t* env_mask;
+    const float* rb; int64_t rb_env_stride; int32_t num_bodies;
+    int32_t upright_start;                       /* 0: remove_base_rot before every heading */
+    const int64_t* progress; float dt;           /* time = progress * dt */
+    /* TrajGenerator state: verts (num_envs, num_verts, 3); traj_dur = num_verts * (episode_dur / (num_verts - 1)) */
+    const float* verts; int32_t num_verts; float traj_dur;
+    int32_t num_samples; float sample_timestep;  /* numTrajSamples (10), trajSampleTimestep (0.5) */
+    /* height sensor: grid points (num_height_points, 2) in the sensor body's heading frame; sensor_body = Head (terrain_obs_root) or 0.
+       heightsamples NULL = terrainType 'plane' (zero heights); num_height_points 0 = no terrain observation (HumanoidTraj). */
+    const int16_t* heightsamples; int32_t map_rows, map_cols; float horizontal_scale, vertical_scale;
+    const float* height_points; int32_t num_height_points; int32_t sensor_body;
+    const float* center_points; int32_t num_center_points; int32_t use_center_height; float height_meas_scale;
+    /* reward */
+    const float* dof_force; const float* dof_vel; int32_t num_dof; float power_coef; int32_t power_reward; int32_t fuzzy_target;
+    /* reset */
+    const float* contact_forces; const int32_t* contact_body_ids; int32_t num_contact_ids; const float* termination_heights;
+    float max_episode_length, fail_dist; int32_t enable_early_termination, terrain_reset, disable_collision;
+    /* outputs */
+    float* obs; int64_t obs_stride; int32_t obs_offset;
+    float* rew; float* rew_raw;                  /* rew_raw (num_envs, 2) = [location reward, power reward] or NULL */
+    int64_t* reset; int64_t* terminate;
+} pulse_traj_step_args;
+int pulse_sizeof_traj_step_args(void);
+int pulse_traj_step(const pulse_traj_step_args* args, pulse_stream_t s);
+
+/* TrajGenerator.reset (phc/utils/traj_generator.py:60-123) for the masked envs; the uniform draws are supplied in the reference's order.
+   dtheta_scale = dtheta_max * seg_dt, dspeed_scale = accel_max * seg_dt, seg_dt = episode_dur / (num_verts - 1). */
+typedef struct pulse_traj_gen_args {
+    int32_t num_envs, num_verts; const uint8_t* env_mask;
+    const float* rb; int64_t rb_env_stride;      /* trajectory starts at the root's xy */
+    const float* u_dtheta; const float* u_sharp; const uint8_t* sharp_mask; const float* u_heading; const float* u_dspeed; const float* u_speed0;
+    float dtheta_scale, dspeed_scale, seg_dt, speed_min, speed_max;
+    float* verts;
+} pulse_traj_gen_args;
+int pulse_traj_generate(const pulse_traj_gen_args* args, pulse_stream_t s);
 
 /* ------------------------------------------------------------------------- *
  * 3. GAE: CommonAgent.discount_values + returns, phc/learning/common_agent.py:493-505,

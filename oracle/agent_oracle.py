@@ -400,6 +400,48 @@ class OracleNetZ(nn.Module):
         return self.value(self.critic_mlp(torch.cat([self_obs, self.critic_z_mlp(obs)], dim=-1)))
 
 
+class OracleNetSept(nn.Module):
+    """AMPSeptBuilder.Network (phc/learning/amp_network_sept_builder.py:19-165), the terrain-task policy (learning/pulse_z_terrain.yaml): ONE
+    task MLP (the constructor builds it twice into the same attribute, :33-36) over the task observation, shared by actor and critic,
+    whose MLPs read cat(self_obs, task_out)."""
+
+    def __init__(self, self_obs_size=358, task_obs_size=1044, actions_num=32, units=(2048, 1024, 512), task_units=(512, 256), sigma_val=-1.0):
+        super().__init__()
+        self.self_obs_size, self.task_obs_size = self_obs_size, task_obs_size
+
+        def mlp(i, us):
+            layers = []
+            for u in us:
+                layers += [nn.Linear(i, u), nn.SiLU()]
+                i = u
+            return nn.Sequential(*layers)
+        cat = self_obs_size + task_units[-1]
+        self.actor_mlp = mlp(cat, units)
+        self.critic_mlp = mlp(cat, units)
+        self.value = nn.Linear(units[-1], 1)
+        self.mu = nn.Linear(units[-1], actions_num)
+        self.sigma = nn.Parameter(torch.full((actions_num,), float(sigma_val)), requires_grad=False)
+        self._task_mlp = mlp(task_obs_size, task_units)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.bias)
+
+    def state_dict_ref(self):
+        return {"a2c_network." + k: v.detach().clone() for k, v in self.state_dict().items()}
+
+    def _cat(self, obs):
+        s, t = self.self_obs_size, self.task_obs_size
+        assert obs.shape[-1] == s + t
+        return torch.cat([obs[:, :s], self._task_mlp(obs[:, s:s + t])], dim=-1)
+
+    def eval_actor(self, obs):
+        mu = self.mu(self.actor_mlp(self._cat(obs)))
+        return mu, mu * 0.0 + self.sigma
+
+    def eval_critic(self, obs):
+        return self.value(self.critic_mlp(self._cat(obs)))
+
+
 def kl_multi(qm, qv, pm, pv):
     """phc/learning/loss_functions.py:3-10 (pinned: tests/golden/rms.npz kl_multi)."""
     return (0.5 * (pv - qv + qv.exp() / pv.exp() + (qm - pm).pow(2) / pv.exp() - 1)).sum(-1)

@@ -397,14 +397,6 @@ def gen_tasks(n=61):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "tasks.npz"), **_np(out))
 
 
-def synthetic_height_field(rows=260, cols=300, seed=5):
-    """A height field with slopes, steps and noise in Isaac Gym's storage format (int16 samples, vertical scale 0.005 m)."""
-    g = torch.Generator().manual_seed(seed)
-    x, y = torch.meshgrid(torch.arange(rows).float(), torch.arange(cols).float(), indexing="ij")
-    h = 0.6 * torch.sin(x / 23.0) * torch.cos(y / 31.0) + 0.15 * torch.floor(x / 40.0) + 0.05 * torch.randn(rows, cols, generator=g)
-    return torch.round(h / 0.005).to(torch.int16)
-
-
 def gen_terrain(n=37):
     """HumanoidTraj / HumanoidPedestrianTerrain (terrain traversal): the reference's TrajGenerator (same seed -> same trajectories), its
     TorchScript functions and the get_heights / get_center_heights / sample_height_points methods executed on a stub object."""
@@ -429,7 +421,7 @@ def gen_terrain(n=37):
     samples = T["HumanoidTraj._fetch_traj_samples"](stub)
     times = progress * dt
     tar_pos = tg.calc_pos(torch.arange(n), times)
-    hs = synthetic_height_field()
+    hs = syn.synthetic_height_field()
     sensor_res, ext = 32, 2.0
     yy = torch.tensor(np.linspace(-ext, ext, sensor_res))
     xx = torch.tensor(np.linspace(-ext, ext, sensor_res))

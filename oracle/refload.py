@@ -154,6 +154,7 @@ AMP_AGENT_METHODS = ["_disc_loss", "_disc_loss_neg", "_disc_loss_pos", "_compute
                      "calc_gradients", "_preproc_obs", "play_steps"]
 AMP_NET_METHODS = ["eval_disc", "get_disc_logit_weights", "get_disc_weights"]
 AMPZ_NET_METHODS = ["form_embedding", "compute_prior", "reparameterize", "eval_actor", "eval_critic"]
+AMPSEPT_NET_METHODS = ["eval_task", "eval_actor", "eval_critic"]
 
 
 def learning_methods():
@@ -175,7 +176,8 @@ def learning_methods():
     out = {}
     for key, fname, cls, names in (("agent", "amp_agent.py", "AMPAgent", AMP_AGENT_METHODS),
                                    ("amp_net", "amp_network_builder.py", "AMPBuilder.Network", AMP_NET_METHODS),
-                                   ("ampz_net", "amp_network_z_builder.py", "AMPZBuilder.Network", AMPZ_NET_METHODS)):
+                                   ("ampz_net", "amp_network_z_builder.py", "AMPZBuilder.Network", AMPZ_NET_METHODS),
+                                   ("ampsept_net", "amp_network_sept_builder.py", "AMPSeptBuilder.Network", AMPSEPT_NET_METHODS)):
         srcs = _extract(os.path.join(base, fname), names, methods_of=cls)
         if key == "agent":                                   # inherited from CommonAgent
             srcs.update(_extract(os.path.join(base, "common_agent.py"), ["_actor_loss", "_critic_loss", "bound_loss", "get_action_values", "_eval_critic",

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -120,6 +120,30 @@ class PdSimArgs(Structure):
                 ("kp", c_float), ("kd", c_float), ("dt", c_float), ("action_scale", c_float), ("lever", c_float), ("substeps", c_int32),
                 ("err", c_void_p), ("err_vel", c_void_p), ("rb", c_void_p), ("dof_pos", c_void_p), ("dof_vel", c_void_p), ("dof_force", c_void_p),
                 ("reset_mask", c_void_p)]
+
+
+class TrajStepArgs(Structure):
+    _fields_ = [("what", c_uint32), ("num_envs", c_int32), ("env_ids", c_void_p), ("num_ids", c_int32), ("env_mask", c_void_p),
+                ("rb", c_void_p), ("rb_env_stride", c_int64), ("num_bodies", c_int32), ("upright_start", c_int32),
+                ("progress", c_void_p), ("dt", c_float),
+                ("verts", c_void_p), ("num_verts", c_int32), ("traj_dur", c_float), ("num_samples", c_int32), ("sample_timestep", c_float),
+                ("heightsamples", c_void_p), ("map_rows", c_int32), ("map_cols", c_int32), ("horizontal_scale", c_float), ("vertical_scale", c_float),
+                ("height_points", c_void_p), ("num_height_points", c_int32), ("sensor_body", c_int32),
+                ("center_points", c_void_p), ("num_center_points", c_int32), ("use_center_height", c_int32), ("height_meas_scale", c_float),
+                ("dof_force", c_void_p), ("dof_vel", c_void_p), ("num_dof", c_int32), ("power_coef", c_float), ("power_reward", c_int32),
+                ("fuzzy_target", c_int32),
+                ("contact_forces", c_void_p), ("contact_body_ids", c_void_p), ("num_contact_ids", c_int32), ("termination_heights", c_void_p),
+                ("max_episode_length", c_float), ("fail_dist", c_float), ("enable_early_termination", c_int32), ("terrain_reset", c_int32),
+                ("disable_collision", c_int32),
+                ("obs", c_void_p), ("obs_stride", c_int64), ("obs_offset", c_int32), ("rew", c_void_p), ("rew_raw", c_void_p),
+                ("reset", c_void_p), ("terminate", c_void_p)]
+
+
+class TrajGenArgs(Structure):
+    _fields_ = [("num_envs", c_int32), ("num_verts", c_int32), ("env_mask", c_void_p), ("rb", c_void_p), ("rb_env_stride", c_int64),
+                ("u_dtheta", c_void_p), ("u_sharp", c_void_p), ("sharp_mask", c_void_p), ("u_heading", c_void_p), ("u_dspeed", c_void_p),
+                ("u_speed0", c_void_p), ("dtheta_scale", c_float), ("dspeed_scale", c_float), ("seg_dt", c_float), ("speed_min", c_float),
+                ("speed_max", c_float), ("verts", c_void_p)]
 
 
 class VaeEmbedArgs(Structure):
@@ -232,6 +256,9 @@ SIGNATURES = {
     "pulse_sizeof_gemm_desc": (c_int, []),
     "pulse_gemm_f32": (c_int, [POINTER(GemmDesc), P]),
     "pulse_gemm_x3p": (c_int, [POINTER(GemmX3pDesc), P]),
+    "pulse_traj_step": (c_int, [POINTER(TrajStepArgs), P]),
+    "pulse_sizeof_traj_step_args": (c_int, []),
+    "pulse_traj_generate": (c_int, [POINTER(TrajGenArgs), P]),
     "pulse_vae_embed": (c_int, [POINTER(VaeEmbedArgs), P]),
     "pulse_vae_kin_loss": (c_int, [POINTER(VaeKinArgs), P]),
     "pulse_vae_head_backward": (c_int, [POINTER(VaeHeadBwdArgs), P]),

@@ -48,6 +48,19 @@ NETWORK_Z_READER = {      # phc/data/cfg/learning/pulse_z_task.yaml:10-44 (netwo
     "mlp": {"units": [2048, 1024, 512], "activation": "silu", "d2rl": False, "initializer": {"name": "default"}},
 }
 
+NETWORK_SEPT = {          # phc/data/cfg/learning/pulse_z_terrain.yaml:12-51 (network: amp_sept)
+    "name": "amp_sept", "separate": True,
+    "space": {"continuous": {"mu_activation": "None", "sigma_activation": "None", "mu_init": {"name": "default"},
+                             "sigma_init": {"name": "const_initializer", "val": -1.0}, "fixed_sigma": True, "learn_sigma": False}},
+    "mlp": {"units": [2048, 1024, 512], "activation": "silu", "d2rl": False, "initializer": {"name": "default"}},
+    "task_mlp": {"units": [512, 256], "activation": "silu", "d2rl": False, "initializer": {"name": "default"}},
+}
+
+ENV_TERRAIN_Z = {"local_root_obs": True, "root_height_obs": True, "enableEarlyTermination": True, "episode_length": 300, "enableTaskObs": True,
+                 "numTrajSamples": 10, "trajSampleTimestep": 0.5, "speedMin": 0.0, "speedMax": 3.0, "accelMax": 2.0, "sharpTurnProb": 0.02,
+                 "terrain_obs": True, "terrain_obs_type": "square", "terrain_obs_root": "head", "use_center_height": True, "power_reward": False,
+                 "terrain": {"terrainType": "trimesh"}, "embedding_size": 32, "z_type": "vae"}   # phc/data/cfg/env/env_pulse_terrain.yaml
+
 ENV_SPEED_Z = {"local_root_obs": True, "root_height_obs": True, "enableEarlyTermination": True, "episode_length": 300, "enableTaskObs": True,
                "tarSpeedMin": 0.0, "tarSpeedMax": 5.0, "speedChangeStepsMin": 100, "speedChangeStepsMax": 200, "power_reward": True,
                "embedding_size": 32, "z_type": "vae"}     # phc/data/cfg/env/env_pulse_amp.yaml (HumanoidSpeedZ)
@@ -74,6 +87,10 @@ CONFIGS = {
     "speed_z": {"num_envs": 4096, "horizon_length": 32, "minibatch_size": 16384, "network": "amp_z_reader", "env": "speed_z", "agent": "amp"},
     "speed_z_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_z_reader", "env": "speed_z", "agent": "amp",
                       "units": [256, 128]},
+    # terrain traversal on a frozen PULSE decoder: HumanoidPedestrianTerrainZ, policy = amp_sept (learning=pulse_z_terrain; env_pulse_terrain.yaml: 1536 envs)
+    "terrain_z": {"num_envs": 1536, "horizon_length": 32, "minibatch_size": 16384, "network": "amp_sept", "env": "terrain_z", "agent": "amp"},
+    "terrain_z_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_sept", "env": "terrain_z", "agent": "amp",
+                        "units": [256, 128]},
     # small shapes of the same graphs for tests
     "cfg3_small": {"num_envs": 64, "horizon_length": 16, "minibatch_size": 256, "network": "amp_z", "env": "vae", "agent": "amp",
                    "extra": {"use_seq_rl": True}},
@@ -85,6 +102,10 @@ def agent_config(name, **overrides):
     c = CONFIGS[name]
     if c.get("network") == "amp_z":
         net = copy.deepcopy(NETWORK_Z)
+    elif c.get("network") == "amp_sept":
+        net = copy.deepcopy(NETWORK_SEPT)
+        if "units" in c:
+            net["mlp"]["units"] = list(c["units"])
     elif c.get("network") == "amp_z_reader":
         net = copy.deepcopy(NETWORK_Z_READER)
         if "units" in c:
@@ -104,15 +125,17 @@ def make_env(num_envs, horizon, device, seed=1234, rank=0, rollout=None, env_kin
     """``reference``: 'recorded' = pre-recorded rigid-body / reference frames (RecordedRollout, what the CPU oracle agent replays);
     'motion_lib' = reference motion queried from the HBM-resident MotionLib every step, physics stand-in tracking it."""
     from .env.humanoid_im import HumanoidIm, VecTaskPythonWrapper
-    if env_kind in ("speed_z", "reach_z", "strike_z"):
+    if env_kind in ("speed_z", "reach_z", "strike_z", "terrain_z"):
         # HumanoidSpeedZ & co: synthetic task physics, the frozen decoder initialised from a (random-init) PULSE checkpoint
         import torch
         from .env import humanoid_tasks as HT
         from .learning.network_z import AMPZNetwork
-        env_cfg = dict(ENV_SPEED_Z)
+        env_cfg = dict(ENV_TERRAIN_Z if env_kind == "terrain_z" else ENV_SPEED_Z)
         env_cfg.update(env_overrides or {})
-        sim = HT.SyntheticTaskSim(num_envs, horizon + 1, device, seed=seed, rank=rank)
-        cls = {"speed_z": HT.HumanoidSpeedZ, "reach_z": HT.HumanoidReachZ, "strike_z": HT.HumanoidStrikeZ}[env_kind]
+        # the terrain task's humanoids walk inside the synthetic height field (cells of 0.1 m): start them near its middle
+        sim = HT.SyntheticTaskSim(num_envs, horizon + 1, device, seed=seed, rank=rank, xy_offset=(13.0, 15.0) if env_kind == "terrain_z" else (0.0, 0.0))
+        cls = {"speed_z": HT.HumanoidSpeedZ, "reach_z": HT.HumanoidReachZ, "strike_z": HT.HumanoidStrikeZ,
+               "terrain_z": HT.HumanoidPedestrianTerrainZ}[env_kind]
         task = cls({"env": env_cfg}, sim, device=device)
         znet = AMPZNetwork(NETWORK_Z, actions_num=69, self_obs_size=task.get_self_obs_size(), task_obs_size=576,
                            task_obs_size_detail={"embedding_size": 32, "z_type": "vae", "use_vae_prior": True, "use_vae_clamped_prior": True,

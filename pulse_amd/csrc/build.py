@@ -37,6 +37,7 @@ SOURCES = [
     ("env_step.hip", NO_CONTRACT),
     ("amp_obs.hip", NO_CONTRACT),
     ("task_step.hip", NO_CONTRACT),
+    ("traj_step.hip", NO_CONTRACT),
     ("motion_state.hip", NO_CONTRACT),
     ("rollout_ops.hip", NO_CONTRACT),
     ("gae.hip", NO_CONTRACT),

@@ -45,7 +45,7 @@ class HumanoidTask:
         self._dof_size = syn.NUM_DOF
         lib = ops._lib.load()
         self._self_obs_size = lib.pulse_self_obs_width(self.num_bodies, int(self._root_height_obs))
-        self._task_obs_size = lib.pulse_task_obs_size({"speed": 1, "reach": 2, "strike": 3}[self.TASK]) if self._enable_task_obs else 0
+        self._task_obs_size = self._task_obs_width(env) if self._enable_task_obs else 0
         self.num_obs = self._self_obs_size + self._task_obs_size
         self.num_actions = self._dof_size
         self.obs_pitch = (self.num_obs + 31) // 32 * 32
@@ -53,7 +53,7 @@ class HumanoidTask:
         self._obs_store = torch.zeros(n, self.obs_pitch, device=dev)
         self.obs_buf = self._obs_store[:, :self.num_obs]
         self.rew_buf = torch.zeros(n, device=dev)
-        self.reward_raw = torch.zeros(n, 2 if self.power_reward else 1, device=dev)
+        self.reward_raw = torch.zeros(n, self._reward_raw_width(), device=dev)
         self.reset_buf = torch.ones(n, dtype=torch.int64, device=dev)
         self.progress_buf = torch.zeros(n, dtype=torch.int64, device=dev)
         self._terminate_buf = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -70,6 +70,12 @@ class HumanoidTask:
         self.z_type = env.get("z_type", None)
 
     # ---- sizes
+    def _task_obs_width(self, env):
+        return ops._lib.load().pulse_task_obs_size({"speed": 1, "reach": 2, "strike": 3}[self.TASK])
+
+    def _reward_raw_width(self):
+        return 2 if self.power_reward else 1
+
     def get_obs_size(self):
         return self.num_obs
 
@@ -255,6 +261,101 @@ class HumanoidStrike(HumanoidTask):
         return {"tar_states": self._target_states, "tar_contact_forces": self.sim.target_contact_forces, "strike_body_ids": self._strike_body_ids}
 
 
+class HumanoidTraj(HumanoidTask):
+    """HumanoidTraj (phc/env/tasks/humanoid_traj.py:22-211): follow a random 2-D trajectory (TrajGenerator, phc/utils/traj_generator.py);
+    task observation = numTrajSamples (10) future trajectory points in the heading frame, reward exp(-2 |root - target|^2), reset when
+    fallen or more than fail_dist (4 m) off the trajectory.  One launch of pulse_traj_step per phase; trajectories are regenerated for the
+    envs being reset by pulse_traj_generate from six uniform draws taken in the reference's order."""
+    TASK = "traj"
+    TERRAIN_OBS = False
+
+    def __init__(self, cfg, sim, device="cuda:0"):
+        env = cfg.get("env", cfg)
+        self._num_traj_samples = int(env.get("numTrajSamples", 10))
+        self._traj_sample_timestep = float(env.get("trajSampleTimestep", 0.5))
+        self.terrain_obs = bool(env.get("terrain_obs", self.TERRAIN_OBS))
+        self._height_points = self._center_points = self._heightsamples = None
+        if self.terrain_obs:
+            if env.get("terrain_obs_type", "square") != "square":
+                raise NotImplementedError("terrain_obs_type 'square' (env_pulse_terrain.yaml) is built; 'fov' / 'square_fov' are viewer-era variants")
+            self._height_points = syn.square_height_points(float(env.get("sensor_extent", 2)), int(env.get("sensor_res", 32))).to(device)
+        super().__init__(cfg, sim, device)
+        dev = self.device
+        self._speed_min, self._speed_max = float(env.get("speedMin", 0.0)), float(env.get("speedMax", 3.0))
+        self._accel_max, self._sharp_turn_prob = float(env.get("accelMax", 2.0)), float(env.get("sharpTurnProb", 0.02))
+        self._fail_dist = 4.0                                                            # humanoid_traj.py:30
+        self._num_verts, self._dtheta_max = 101, 2.0                                     # _build_traj_generator (:105-113)
+        self._episode_dur = self.max_episode_length * self.dt
+        self._traj_verts = torch.zeros(self.num_envs, self._num_verts, 3, device=dev)
+        self.fuzzy_target = bool(env.get("fuzzy_target", False))
+        self._sensor_body = 0
+        if self.terrain_obs:
+            self._center_points = syn.center_height_points().to(dev)
+            self._use_center_height = bool(env.get("use_center_height", False))
+            self._sensor_body = syn.SMPL_BODY_NAMES.index("Head") if env.get("terrain_obs_root", "head") == "head" else 0
+            terrain_type = env.get("terrain", {}).get("terrainType", "trimesh")
+            if terrain_type == "none":
+                raise NameError("Can't measure height with terrain type 'none'")            # get_heights (:744-745)
+            if terrain_type != "plane":
+                hs = getattr(sim, "heightsamples", None)
+                self._heightsamples = (hs if hs is not None else syn.synthetic_height_field()).to(dev).contiguous()
+            self._horizontal_scale, self._vertical_scale, self.height_meas_scale = 0.1, 0.005, 5.0    # Terrain.__init__ (:1121-1122), :69
+
+    def _task_obs_width(self, env):
+        w = 2 * self._num_traj_samples                                                   # get_task_obs_size (:253-270)
+        if self._height_points is not None:
+            w += self._height_points.shape[0]
+        return w
+
+    def _reward_raw_width(self):
+        return 2                                                                         # [location reward, power reward] (:890)
+
+    def get_task_obs_size_detail(self):
+        d = {"traj": 2 * self._num_traj_samples}                                         # get_task_obs_size_detail (:273-290)
+        if self.terrain_obs:
+            d["heightmap"] = self._height_points.shape[0]
+        return d
+
+    def _task_due(self):
+        return None
+
+    def _update_task(self):
+        return                                                                           # trajectories only change at episode reset
+
+    def _reset_task(self, mask):
+        """HumanoidTraj._reset_task (:145-150) -> TrajGenerator.reset for the masked envs."""
+        n, v = self.num_envs, self._num_verts
+        u_dtheta, u_sharp = self._rand(n, v - 1), self._rand(n, v - 1)
+        sharp_mask = torch.bernoulli(torch.full((n, v - 1), self._sharp_turn_prob, device=self.device), generator=self._task_gen) == 1.0
+        u_heading, u_dspeed, u_speed0 = self._rand(n), self._rand(n, v - 1), self._rand(n)
+        ops.traj_generate(self.sim.rigid_body_state, self._traj_verts, u_dtheta, u_sharp, sharp_mask, u_heading, u_dspeed, u_speed0,
+                          episode_dur=self._episode_dur, dtheta_max=self._dtheta_max, speed_min=self._speed_min, speed_max=self._speed_max,
+                          accel_max=self._accel_max, env_mask=mask)
+
+    def _task_step(self, what, env_mask=None):
+        terrain = {}
+        if self.terrain_obs:
+            terrain = dict(heightsamples=self._heightsamples, horizontal_scale=self._horizontal_scale, vertical_scale=self._vertical_scale,
+                           height_points=self._height_points, sensor_body=self._sensor_body, center_points=self._center_points,
+                           use_center_height=self._use_center_height, height_meas_scale=self.height_meas_scale)
+        return ops.traj_step(self.sim.rigid_body_state, self._traj_verts, self.progress_buf, what=what, dt=self.dt, episode_dur=self._episode_dur,
+                             num_samples=self._num_traj_samples, sample_timestep=self._traj_sample_timestep, upright=self._has_upright_start,
+                             dof_force=self.sim.dof_force, dof_vel=self.sim.dof_vel, power_coef=self.power_coefficient, power_reward=self.power_reward,
+                             fuzzy_target=self.fuzzy_target, contact_forces=self.sim.contact_forces, contact_body_ids=self._contact_body_ids,
+                             termination_heights=self._termination_heights, max_episode_length=float(self.max_episode_length),
+                             fail_dist=self._fail_dist, enable_early_termination=self._enable_early_termination, terrain_reset=self.terrain_obs,
+                             obs=self._obs_store, obs_offset=self._self_obs_size, rew=self.rew_buf, rew_raw=self.reward_raw, reset=self.reset_buf,
+                             terminate=self._terminate_buf, env_mask=env_mask, **terrain)
+
+
+class HumanoidPedestrianTerrain(HumanoidTraj):
+    """HumanoidPedestrianTerrain (phc/env/tasks/humanoid_pedestrian_terrain.py:31-890; env_pulse_terrain.yaml): the trajectory task over a height
+    field -- the task observation gains the 32 x 32 height map under the head (:384-440), a fall is a summed non-foot contact force above
+    50 N (:1476-1531), the reward keeps a power term (:871-890).  The terrain itself (isaacgym.terrain_utils, PhysX tri-mesh) is a synthetic
+    height field here; crowds (``_divide_group``, the 'people' point-net input of amp_sept) are not built -- no shipped config enables them."""
+    TERRAIN_OBS = True
+
+
 class _ZMixin(HumanoidZ):
     """HumanoidSpeedZ / ReachZ / StrikeZ (humanoid_speed.py:290-304 ...): the action is the 32-d latent of a frozen PULSE decoder."""
 
@@ -289,11 +390,19 @@ class HumanoidStrikeZ(_ZMixin, HumanoidStrike):
         self._init_z(cfg)
 
 
+class HumanoidPedestrianTerrainZ(_ZMixin, HumanoidPedestrianTerrain):
+    """humanoid_pedestrian_terrain.py:957-972: the terrain task driven through a frozen PULSE decoder (learning=pulse_z_terrain)."""
+
+    def __init__(self, cfg, sim, device="cuda:0"):
+        super().__init__(cfg, sim, device)
+        self._init_z(cfg)
+
+
 class SyntheticTaskSim:
     """Physics stand-in for the downstream tasks: a bank of recorded frames (rigid bodies with a drifting root, sparse contact
     forces, a target object) replayed one per control step.  Actions are accepted and ignored, exactly like RecordedSim."""
 
-    def __init__(self, num_envs, frames, device, seed=1234, rank=0, fall_rate=0.01):
+    def __init__(self, num_envs, frames, device, seed=1234, rank=0, fall_rate=0.01, xy_offset=(0.0, 0.0)):
         g = syn.make_generator(seed + 31, rank)
         n, j, f = num_envs, syn.NUM_BODIES, frames
         self.num_envs, self.frames, self.frame = n, f, 0
@@ -301,6 +410,8 @@ class SyntheticTaskSim:
         drift = torch.cumsum(0.05 * torch.randn(f, n, 1, 3, generator=g), dim=0)
         drift[..., 2] = 0
         rb[..., 0:3] += drift
+        rb[..., 0] += xy_offset[0]                                                             # e.g. into the interior of a height field
+        rb[..., 1] += xy_offset[1]
         contact = torch.zeros(f, n, j, 3)
         fell = torch.rand(f, n, generator=g) < fall_rate
         contact[..., 9, 2] = fell.float() * 200.0                                          # torso contact
@@ -334,4 +445,6 @@ class SyntheticTaskSim:
 
 
 TASKS = {"HumanoidSpeed": HumanoidSpeed, "HumanoidReach": HumanoidReach, "HumanoidStrike": HumanoidStrike,
-         "HumanoidSpeedZ": HumanoidSpeedZ, "HumanoidReachZ": HumanoidReachZ, "HumanoidStrikeZ": HumanoidStrikeZ}
+         "HumanoidSpeedZ": HumanoidSpeedZ, "HumanoidReachZ": HumanoidReachZ, "HumanoidStrikeZ": HumanoidStrikeZ,
+         "HumanoidTraj": HumanoidTraj, "HumanoidPedestrianTerrain": HumanoidPedestrianTerrain,
+         "HumanoidPedestrianTerrainZ": HumanoidPedestrianTerrainZ}

@@ -173,6 +173,12 @@ class CommonAgent:
             return AMPZModel(params, actions_num=net_config["actions_num"], self_obs_size=task.get_self_obs_size(),
                              task_obs_size=task.get_task_obs_size(), task_obs_size_detail=task.get_task_obs_size_detail(),
                              device=self.ppo_device, split_k=int(self.config.get("split_k", 8)), generator=self.noise_generator)
+        if params.get("name", "amp") == "amp_sept":
+            from .network_sept import AMPSeptModel
+            task = self.vec_env.env.task
+            return AMPSeptModel(params, actions_num=net_config["actions_num"], self_obs_size=task.get_self_obs_size(),
+                                task_obs_size=task.get_task_obs_size(), task_obs_size_detail=task.get_task_obs_size_detail(),
+                                device=self.ppo_device, split_k=int(self.config.get("split_k", 8)))
         if params.get("name", "amp") == "amp_z_reader":
             # AMPZReaderBuilder.Network (amp_network_z_reader_builder.py:21-57) IS AMPBuilder.Network -- the plain actor / critic MLP
             # whose 32-d "action" is the latent a frozen PULSE decoder turns into joint targets inside env.step -- unless

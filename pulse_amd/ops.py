@@ -647,3 +647,123 @@ def discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values, gamma, tau
     _lib.check(_lib.load().pulse_gae(_ptr(r), _ptr(v), _ptr(nv), _ptr(d), t, n, st, sn, float(gamma), gt,
                                      _ptr(advs), _ptr(rets), _stream()), "pulse_gae")
     return (advs, rets) if return_returns else advs
+
+
+# --------------------------------------------------------------------------- #
+# trajectory following over a height field (HumanoidTraj / HumanoidPedestrianTerrain)
+# --------------------------------------------------------------------------- #
+def traj_generate(rb, verts, u_dtheta, u_sharp, sharp_mask, u_heading, u_dspeed, u_speed0, *, episode_dur, dtheta_max=2.0, speed_min=0.0,
+                  speed_max=3.0, accel_max=2.0, env_mask=None):
+    """TrajGenerator.reset (phc/utils/traj_generator.py:60-123) for the masked envs from uniform draws in the reference's order.
+    ``verts`` (N, num_verts, 3) is updated in place; trajectories start at each env's root xy."""
+    from ._lib import TrajGenArgs
+    rb, verts = _dev(rb, "rb"), _dev(verts, "verts")
+    n, nv = verts.shape[0], verts.shape[1]
+    if not verts.is_contiguous() or verts.shape[2] != 3:
+        raise ValueError("verts: contiguous (N, num_verts, 3) expected")
+    seg_dt = episode_dur / (nv - 1)
+    a = TrajGenArgs()
+    keep = []
+
+    def P(t, name, shape, dtype=torch.float32):
+        t = _c(t, name, dtype)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+        keep.append(t)
+        return t.data_ptr()
+    a.num_envs, a.num_verts = n, nv
+    if env_mask is not None:
+        a.env_mask = P(env_mask.view(torch.uint8) if env_mask.dtype == torch.bool else env_mask, "env_mask", (n,), torch.uint8)
+    a.rb, a.rb_env_stride = rb.data_ptr(), rb.stride(0)
+    a.u_dtheta, a.u_sharp, a.u_dspeed = P(u_dtheta, "u_dtheta", (n, nv - 1)), P(u_sharp, "u_sharp", (n, nv - 1)), P(u_dspeed, "u_dspeed", (n, nv - 1))
+    a.sharp_mask = P(sharp_mask.view(torch.uint8) if sharp_mask.dtype == torch.bool else sharp_mask, "sharp_mask", (n, nv - 1), torch.uint8)
+    a.u_heading, a.u_speed0 = P(u_heading, "u_heading", (n,)), P(u_speed0, "u_speed0", (n,))
+    a.dtheta_scale, a.dspeed_scale, a.seg_dt = float(dtheta_max * seg_dt), float(accel_max * seg_dt), float(seg_dt)
+    a.speed_min, a.speed_max = float(speed_min), float(speed_max)
+    a.verts = verts.data_ptr()
+    _lib.check(_lib.load().pulse_traj_generate(ctypes.byref(a), _stream()), "pulse_traj_generate")
+    return verts
+
+
+def traj_step(rb, verts, progress, *, what, dt, episode_dur, num_samples=10, sample_timestep=0.5, upright=True, heightsamples=None,
+              horizontal_scale=0.1, vertical_scale=0.005, height_points=None, sensor_body=0, center_points=None, use_center_height=True,
+              height_meas_scale=5.0, dof_force=None, dof_vel=None, power_coef=0.0005, power_reward=False, fuzzy_target=False, contact_forces=None,
+              contact_body_ids=None, termination_heights=None, max_episode_length=300.0, fail_dist=4.0, enable_early_termination=True,
+              terrain_reset=True, disable_collision=False, obs=None, obs_offset=0, rew=None, rew_raw=None, reset=None, terminate=None,
+              env_ids=None, env_mask=None):
+    """One launch of pulse_traj_step (include/pulse_hip.h 2a''): task observation [10 trajectory samples x 2 | height map], location (+ power)
+    reward, reset / terminate.  ``height_points`` None = no terrain observation (HumanoidTraj); ``heightsamples`` None with height points =
+    terrainType 'plane'.  Returns dict(obs, rew, rew_raw, reset, terminate) of what was asked."""
+    from ._lib import TASK_OBS, TASK_RESET, TASK_REWARD, TrajStepArgs
+    rb = _dev(rb, "rb")
+    n, j = rb.shape[0], rb.shape[1]
+    dev = rb.device
+    a = TrajStepArgs()
+    keep = []
+
+    def P(t, name, dtype=torch.float32):
+        if t is None:
+            return None
+        t = _c(t, name, dtype)
+        keep.append(t)
+        return t.data_ptr()
+    a.what, a.num_envs = what, n
+    if env_ids is not None:
+        env_ids = _c(env_ids, "env_ids", torch.int64)
+        keep.append(env_ids)
+        a.env_ids, a.num_ids = env_ids.data_ptr(), env_ids.numel()
+    if env_mask is not None:
+        a.env_mask = P(env_mask.view(torch.uint8) if env_mask.dtype == torch.bool else env_mask, "env_mask", torch.uint8)
+    a.rb, a.rb_env_stride, a.num_bodies, a.upright_start = rb.data_ptr(), rb.stride(0), j, int(bool(upright))
+    a.progress, a.dt = P(progress, "progress", torch.int64), float(dt)
+    verts = _dev(verts, "verts")
+    if verts.shape[0] != n or verts.dim() != 3 or verts.shape[2] != 3 or not verts.is_contiguous():
+        raise ValueError("verts: contiguous (N, num_verts, 3) expected")
+    nv = verts.shape[1]
+    a.verts, a.num_verts, a.traj_dur = verts.data_ptr(), nv, float(nv * (episode_dur / (nv - 1)))
+    a.num_samples, a.sample_timestep = int(num_samples), float(sample_timestep)
+    nh = 0
+    if height_points is not None:
+        nh = height_points.shape[0]
+        a.height_points, a.num_height_points, a.sensor_body = P(height_points, "height_points"), nh, int(sensor_body)
+        if heightsamples is not None:
+            if heightsamples.dtype != torch.int16 or heightsamples.dim() != 2 or not heightsamples.is_contiguous() or not heightsamples.is_cuda:
+                raise TypeError("heightsamples: contiguous (rows, cols) int16 CUDA tensor expected")
+            keep.append(heightsamples)
+            a.heightsamples, a.map_rows, a.map_cols = heightsamples.data_ptr(), heightsamples.shape[0], heightsamples.shape[1]
+        a.horizontal_scale, a.vertical_scale = float(horizontal_scale), float(vertical_scale)
+        if center_points is not None:
+            a.center_points, a.num_center_points = P(center_points, "center_points"), center_points.shape[0]
+        a.use_center_height, a.height_meas_scale = int(bool(use_center_height)), float(height_meas_scale)
+    a.dof_force, a.dof_vel = P(dof_force, "dof_force"), P(dof_vel, "dof_vel")
+    a.num_dof = dof_force.shape[-1] if dof_force is not None else 0
+    a.power_coef, a.power_reward, a.fuzzy_target = float(power_coef), int(bool(power_reward)), int(bool(fuzzy_target))
+    if contact_body_ids is not None:
+        t = _ids32(contact_body_ids, dev)
+        keep.append(t)
+        a.contact_body_ids, a.num_contact_ids = t.data_ptr(), t.numel()
+    a.contact_forces, a.termination_heights = P(contact_forces, "contact_forces"), P(termination_heights, "termination_heights")
+    a.max_episode_length, a.fail_dist = float(max_episode_length), float(fail_dist)
+    a.enable_early_termination, a.terrain_reset, a.disable_collision = int(bool(enable_early_termination)), int(bool(terrain_reset)), int(bool(disable_collision))
+    out = {}
+    if what & TASK_OBS:
+        w = 2 * int(num_samples) + nh
+        if obs is None:
+            obs = torch.zeros(n, (obs_offset + w + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        _dev(obs, "obs")
+        a.obs, a.obs_stride, a.obs_offset = obs.data_ptr(), obs.stride(0), int(obs_offset)
+        out["obs"] = obs
+    if what & TASK_REWARD:
+        rew = torch.empty(n, dtype=torch.float32, device=dev) if rew is None else _dev(rew, "rew")
+        rew_raw = torch.empty(n, 2, dtype=torch.float32, device=dev) if rew_raw is None else _dev(rew_raw, "rew_raw")
+        if not rew_raw.is_contiguous() or rew_raw.shape[-1] != 2:
+            raise ValueError("rew_raw: contiguous (N, 2) expected")
+        a.rew, a.rew_raw = rew.data_ptr(), rew_raw.data_ptr()
+        out["rew"], out["rew_raw"] = rew, rew_raw
+    if what & TASK_RESET:
+        reset = torch.empty(n, dtype=torch.int64, device=dev) if reset is None else _dev(reset, "reset", torch.int64)
+        terminate = torch.empty(n, dtype=torch.int64, device=dev) if terminate is None else _dev(terminate, "terminate", torch.int64)
+        a.reset, a.terminate = reset.data_ptr(), terminate.data_ptr()
+        out["reset"], out["terminate"] = reset, terminate
+    _lib.check(_lib.load().pulse_traj_step(ctypes.byref(a), _stream()), "pulse_traj_step")
+    return out

@@ -102,6 +102,6 @@ def build_alg_runner(algo_observer=None):
     runner.algo_factory.register_builder("im_amp", lambda **kw: im_amp.IMAmpAgent(**kw))
     runner.player_factory.register_builder("im_amp", lambda **kw: players.IMAMPPlayerContinuous(**kw))
     # the network names of the reference's network_factory: resolved inside the agents' _build_model
-    for name in ("amp", "amp_z", "amp_z_reader"):
+    for name in ("amp", "amp_z", "amp_z_reader", "amp_sept"):
         runner.model_builder.network_factory.register_builder(name, lambda **kw: None)
     return runner

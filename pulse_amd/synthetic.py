@@ -230,3 +230,29 @@ def pd_sim_tables():
     b = torch.arange(NUM_BODIES, dtype=torch.float32)
     u = torch.stack([torch.cos(1.3 * b), torch.sin(1.3 * b) * torch.cos(0.9 * b + 0.4), torch.sin(1.3 * b) * torch.sin(0.9 * b + 0.4)], dim=-1)
     return sag, u / u.norm(dim=-1, keepdim=True)
+
+
+def synthetic_height_field(rows=260, cols=300, seed=5):
+    """A height field with slopes, steps and noise in Isaac Gym's storage format (int16 samples, vertical scale 0.005 m, cells of 0.1 m):
+    the stand-in for Terrain.heightsamples (phc/env/tasks/humanoid_pedestrian_terrain.py:1114-1160 builds it with isaacgym.terrain_utils,
+    a closed third-party package)."""
+    g = torch.Generator().manual_seed(seed)
+    x, y = torch.meshgrid(torch.arange(rows).float(), torch.arange(cols).float(), indexing="ij")
+    h = 0.6 * torch.sin(x / 23.0) * torch.cos(y / 31.0) + 0.15 * torch.floor(x / 40.0) + 0.05 * torch.randn(rows, cols, generator=g)
+    return torch.round(h / 0.005).to(torch.int16)
+
+
+def square_height_points(extent=2.0, res=32):
+    """init_square_height_points (humanoid_pedestrian_terrain.py:608-625): res x res grid over [-extent, extent]^2, x-major -> (res^2, 2)."""
+    import numpy as np
+    x = torch.tensor(np.linspace(-extent, extent, res))
+    gx, gy = torch.meshgrid(x, x.clone(), indexing="ij")
+    return torch.stack([gx.flatten(), gy.flatten()], dim=1).float()
+
+
+def center_height_points():
+    """init_center_height_points (:591-606): x in linspace(-0.1, 0.1, 3), y in linspace(-0.2, 0.2, 3) -> (9, 2)."""
+    import numpy as np
+    x, y = torch.tensor(np.linspace(-0.1, 0.1, 3)), torch.tensor(np.linspace(-0.2, 0.2, 3))
+    gx, gy = torch.meshgrid(x, y, indexing="ij")
+    return torch.stack([gx.flatten(), gy.flatten()], dim=1).float()

@@ -287,3 +287,25 @@ def test_whole_play_steps_matches_reference_method():
     assert torch.equal(orc.tensor_dict["next_values"], tensors["next_values"])
     assert ref["dones"].sum() > 0 and ref["played_frames"] == n * t
     assert torch.equal(ref["disc_rewards"].reshape(-1), AO.oracle_disc_rewards(disc, arms, AO.swap_and_flatten01(amp_frames), 2.0).reshape(-1))
+
+
+def test_amp_sept_network_matches_reference_methods():
+    """AMPSeptBuilder.Network.eval_task / eval_actor / eval_critic (amp_network_sept_builder.py:43-123) executed on the oracle's modules: one
+    shared task MLP feeds both the actor and the critic."""
+    torch.manual_seed(4)
+    orc = AO.OracleNetSept(self_obs_size=30, task_obs_size=52, actions_num=8, units=(40, 24), task_units=(28, 16))
+    m = refload.learning_methods()
+    ref = copy.deepcopy(orc)
+    _bind(ref, m["ampsept_net"])
+    for k, v in dict(actor_cnn=nn.Sequential(), task_obs_size_detail={"traj": 20, "heightmap": 32}, is_discrete=False, is_multi_discrete=False,
+                     is_continuous=True, mu_act=nn.Identity(), sigma_act=nn.Identity(), value_act=nn.Identity(),
+                     space_config={"fixed_sigma": True}).items():
+        setattr(ref, k, v)
+    obs = torch.randn(19, 82)
+    mu_r, sig_r = ref.eval_actor({"obs": obs})
+    mu_o, sig_o = orc.eval_actor(obs)
+    assert torch.equal(mu_o, mu_r) and torch.equal(sig_o, sig_r)
+    assert torch.equal(orc.eval_critic(obs), ref.eval_critic({"obs": obs}))
+    # shared task MLP: a loss on the value alone still reaches the task MLP both nets use
+    orc.eval_critic(obs).sum().backward()
+    assert orc._task_mlp[0].weight.grad.abs().sum() > 0 and orc.actor_mlp[0].weight.grad is None

@@ -248,6 +248,8 @@ def main():
         agent.train_epoch()
     log(f"rank {rank}: timing {a.steps} steps")
     prof = kernels.PROFILER
+    dist.time_exposure = world > 1                                # event-bracket every wait for gradient buckets (device-side exposure)
+    dist.exposed_wait_ms()                                        # (drop what the warm-up recorded)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -272,7 +274,9 @@ def main():
         "metric": "env-steps/sec through PPO update", "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "bf16" if cfg.get("mixed_precision") else "f32", "data": "synthetic",
-        "config": {"workload": f"{a.config}: {num_envs} SMPL-humanoid envs/GPU x horizon {T}, imitation obs/reward/reset + PPO "
+        # BASELINE.json configs[3] ("32768 envs sharded 8-way ...") is this workload at 8 ranks: name it when the run is that shape
+        "config": {"workload": ("cfg4 (cfg2 sharded over %d GPUs, %d envs in total): " % (world, num_envs * world) if (a.config == "cfg2" and world > 1) else "") +
+                               f"{a.config}: {num_envs} SMPL-humanoid envs/GPU x horizon {T}, imitation obs/reward/reset + PPO "
                                f"(actor+critic MLP {cfg['network']['mlp']['units']}, minibatch {cfg['minibatch_size']} x {cfg['mini_epochs']} mini-epochs)",
                    "num_envs_per_gpu": num_envs, "horizon": T, "global_batch": T * num_envs * world, "parallelism": f"dp{world}",
                    "reference_motion": "HBM-resident motion library (1024 clips), queried every step" if a.reference == "motion_lib"
@@ -281,9 +285,13 @@ def main():
     }
     if world > 1:
         st = dist.stats()
-        out["allreduce"] = {"backend": st["backend"], "ranks": world, "calls_per_step": st["calls"] / max(1, a.steps + a.warmup),
+        exp_ms, exp_n = dist.exposed_wait_ms()
+        out["allreduce"] = {"backend": st["backend"], "ranks": world, "backend_world_size": dist.backend_world_size(),
+                            "calls_per_step": st["calls"] / max(1, a.steps + a.warmup),
                             "mbytes_per_call": st["bytes"] / max(1, st["calls"]) / 1e6,
-                            "ms_per_step_host_enqueue": 1e3 * st["seconds"] / max(1, a.steps + a.warmup)}
+                            "ms_per_step_host_enqueue": 1e3 * st["seconds"] / max(1, a.steps + a.warmup),
+                            # device-side: how long the optimiser's stream actually waited for gradient buckets (what the overlap did not hide)
+                            "ms_per_step_exposed_wait_device": exp_ms / max(1, a.steps), "waits_timed": exp_n}
     if not a.no_roofline:
         s = prof.summary()
 

@@ -851,9 +851,6 @@ struct StagerX {
         const float a = v[S][2 * k], b = v[S][2 * k + 1];
         const unsigned q0 = pack_rn(a, b);
         p0[k] = q0;
-#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 1)
-        p1[k] = fbits(a); p2[k] = fbits(b); return;
-#endif
         const float ra = a - bitsf(q0 << 16), rb = b - bitsf(q0 & 0xffff0000u);
         const unsigned q1 = pack_rn(ra, rb);
         p1[k] = q1;
@@ -862,9 +859,6 @@ struct StagerX {
     }
     __device__ __forceinline__ void write_plane(int st, int pl) {
         extern __shared__ __attribute__((aligned(16))) char smem_c[];
-#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 2)
-        if (pl > 0 && !(p1[0] == 0x12345678u && p2[1] == 0x9abcdef0u)) return;
-#endif
         *reinterpret_cast<u32x4*>(smem_c + st + lds + pl * X_PLANE) = pl == 0 ? p0 : pl == 1 ? p1 : p2;
     }
     __device__ __forceinline__ void write(int st) { write_plane(st, 0); write_plane(st, 1); write_plane(st, 2); }
@@ -999,37 +993,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int p = q * SPM; p < (q + 1) * SPM; ++p)
             if constexpr (MODE != 2) {
-#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 16)
-                if (g.K == 12345 || MODE == 1)        // timing only: steady tiles keep re-reading the first tiles' planes (no split, no stores)
-#endif
-                {
                 if (p < 4) sa.template split_pair<O>(p);
                 else if (p < 8) sb.template split_pair<O>(p - 4);
                 if (p >= 4 && p < 7) sa.write_plane(OTH, p - 4);          // one 16-byte store per gap: the store path takes ~13 cycles each
                 if (p >= 8 && p < 11) sb.write_plane(OTH, p - 8);
-                }
                 if constexpr (MODE == 0) {
-#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 8)
-                    if (p == 11 && t + 3 < nkt && g.K == 12345) {
-#else
                     if (p == 11 && t + 3 < nkt) {
-#endif
-#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 32)
-                        sa.template load<O>(rsA, 0); sb.template load<O>(rsB, 0);                         // timing only: every tile re-reads k-tile 0 (always cached)
-#elif defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 64)
-                        sa.template load<O>(rsA, (t + 3) * 2 * kstepA); sb.template load<O>(rsB, (t + 3) * 2 * kstepB);   // timing only: every other k-tile (each 128-B line touched once)
-#else
                         sa.template load<O>(rsA, (t + 3) * kstepA); sb.template load<O>(rsB, (t + 3) * kstepB);
-#endif
                     }
                 }
                 if (p == X3_BARRIER_GAP) {                                // a few MFMAs after the last store: its lgkmcnt wait is short
                     __builtin_amdgcn_sched_barrier(0);
                     __syncthreads();
                 }
-#if defined(PULSE_GEMM_EXP) && (PULSE_GEMM_EXP & 4)
-                if (g.K == 12345)
-#endif
                 {
                     // 12 fragment reads in the gaps after the barrier; A1 may be refilled after MFMA 15, B1 after MFMA 19
                     constexpr int R0 = X3_BARRIER_GAP + 1;

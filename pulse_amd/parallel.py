@@ -30,6 +30,7 @@ class DistContext:
         self._own_group = False
         self._stat = {"calls": 0, "bytes": 0, "seconds": 0.0}
         self._pending = []
+        self.time_exposure, self._exposure_events = False, []
         if not self.enabled:
             return
         self.rank = int(os.environ.get("RANK", "0"))
@@ -102,10 +103,32 @@ class DistContext:
         return out
 
     def wait_gradients(self):
-        """Make the current stream wait for every gradient bucket in flight."""
+        """Make the current stream wait for every gradient bucket in flight.  With ``time_exposure`` on (bench.py --gpus N) the wait is
+        bracketed by two events on the compute stream: their distance is the part of the all-reduce the overlap did NOT hide (device
+        time, read back once after the timed region)."""
+        if not self._pending:
+            return
+        ev = None
+        if self.time_exposure and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._pending:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self._exposure_events.append(ev)
         self._pending = []
+
+    def exposed_wait_ms(self):
+        """Sum of the device-side waits recorded by wait_gradients (call after a synchronize)."""
+        ms = sum(a.elapsed_time(b) for a, b in self._exposure_events)
+        n = len(self._exposure_events)
+        self._exposure_events = []
+        return ms, n
+
+    def backend_world_size(self):
+        """The rank count as the BACKEND sees it (an RCCL communicator that came up with fewer ranks than WORLD_SIZE would show here)."""
+        return dist.get_world_size() if (self.enabled and dist.is_initialized()) else 1
 
     def stats(self):
         d = dict(self._stat)

@@ -249,8 +249,15 @@ def _rank_worker(rank, world, port, outdir, overlap=False):
     for i in range(3):
         agent.train_actor_critic(agent.dataset[i])
     agent._end_loss_ring()
+    # the per-epoch exchange of CommonAgent.train (common_agent.py:126-127, 224-247): running statistics averaged, frames summed, KL mean
+    rms = agent.running_mean_std
+    stat_pre = {"mean": rms.running_mean.detach().clone().cpu(), "var": rms.running_var.detach().clone().cpu()}
+    frames = agent.dist.sync_stats(agent._stat_modules(), agent.batch_size)
+    kl_mean = agent.dist.average_value(th.tensor([0.25 + rank], device="cuda:0"), "ep_kls")
+    stat_post = {"mean": rms.running_mean.detach().clone().cpu(), "var": rms.running_var.detach().clone().cpu(), "frames": frames,
+                 "kl": float(kl_mean.item()), "batch": agent.batch_size}
     th.cuda.synchronize()
-    th.save({"before": flat_before.cpu(), "after_setup_rank0_view": None, "pre": pre, "post": post, "flat": agent.model.flat.cpu(),
+    th.save({"before": flat_before.cpu(), "stat_pre": stat_pre, "stat_post": stat_post, "after_setup_rank0_view": None, "pre": pre, "post": post, "flat": agent.model.flat.cpu(),
              "obs_sum": float(agent.experience_buffer.tensor_dict["obses"].double().sum()),
              "sums": {k: float(v.double().sum()) for k, v in agent.experience_buffer.tensor_dict.items() if v.is_floating_point()},
              "adv_sum": float(agent.dataset.values_dict["advantages"].double().sum())}, os.path.join(outdir, f"rank{rank}_{int(overlap)}.pt"))
@@ -294,6 +301,15 @@ def test_two_ranks_share_gpu_gradient_mean_and_identical_parameters(dev):
         assert torch.equal(r0["post"][s], r0["pre"][s] + r1["pre"][s]), f"step {s}: reduced gradient is not the sum of the scaled shards"
     assert torch.equal(r0["flat"], r1["flat"]), "parameters diverged across ranks"
     assert not torch.equal(r0["flat"], r0["before"])
+    # agent-level sync_stats / average_value: both ranks end with the MEAN of the two ranks' observation statistics, the summed frame
+    # count and the mean KL
+    for a_, b_ in ((r0, r1), (o0, o1)):
+        assert not torch.equal(a_["stat_pre"]["mean"], b_["stat_pre"]["mean"])            # the shards saw different observations
+        for k in ("mean", "var"):
+            want = (a_["stat_pre"][k] + b_["stat_pre"][k]) / 2
+            assert torch.equal(a_["stat_post"][k], b_["stat_post"][k]) and torch.allclose(a_["stat_post"][k], want, rtol=1e-12, atol=0)
+        assert a_["stat_post"]["frames"] == b_["stat_post"]["frames"] == 2 * a_["stat_post"]["batch"]
+        assert abs(a_["stat_post"]["kl"] - 0.75) < 1e-6 and abs(b_["stat_post"]["kl"] - 0.75) < 1e-6
     # cross-launch comparison: the overlapped job reproduces the blocking job bit for bit (rollout, advantages, reduced gradients, parameters)
     for r, o in ((r0, o0), (r1, o1)):
         assert r["sums"] == o["sums"] and r["adv_sum"] == o["adv_sum"], "rollout differs between two launches of the same job"

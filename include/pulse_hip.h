@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 15
+#define PULSE_ABI_VERSION 16
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -523,7 +523,7 @@ int pulse_gemm_set_debug_buffer(long long* device_buffer);
 typedef struct pulse_gemm_x3p_desc {
     const void* A; int64_t a_plane_stride; int32_t lda;   /* planes of A(m, k); bf16 elements */
     const void* B; int64_t b_plane_stride; int32_t ldb;   /* planes of B(n, k) */
-    int32_t a_layout, b_layout;                           /* PULSE_GEMM_*_CONTIG (this build: both reduction-contiguous) */
+    int32_t a_layout, b_layout;                           /* PULSE_GEMM_*_CONTIG (three planes: both reduction-contiguous) */
     float* C; int32_t ldc;                                /* optional fp32 output */
     void* Cp; int64_t c_plane_stride; int32_t ldcp;       /* optional: the output's own planes (columns [N, roundup8(N)) zero-filled) */
     float* C2; int32_t ldc2;                              /* optional pre-activation output (EPI_BIAS_ACT + SILU) */
@@ -534,11 +534,18 @@ typedef struct pulse_gemm_x3p_desc {
     int32_t split_k; int64_t split_stride;
     int32_t activation, epilogue;                         /* PULSE_ACT_*, PULSE_EPI_* */
     float* rowsum; int64_t stride_rowsum;
+    int32_t planes;                                       /* 3 (or 0): fp32-grade, three planes per operand.  1: the operands are plain bf16
+                                                             matrices (plane strides ignored), products accumulate in fp32, results leave
+                                                             rounded to bf16 (bf16 autocast semantics; split-K slabs stay fp32), Cp is one
+                                                             bf16 matrix.  [red][out] operands (a/b_layout OUT_CONTIG) are read through the
+                                                             LDS transposing load and exist in this mode only. */
+    int32_t aux_is_bf16;                                  /* aux points at a bf16 matrix (ldaux / stride_aux in bf16 elements) */
 } pulse_gemm_x3p_desc;
 int pulse_sizeof_gemm_x3p_desc(void);
 int pulse_gemm_x3p(const pulse_gemm_x3p_desc* desc, pulse_stream_t s);
 /* fp32 (rows x cols, pitch ld_in floats) -> planes of rows_out x cols_out with pitch ld_out (multiple of 8; columns [cols_out, ld_out)
- * zero-filled).  transpose != 0: out(r, c) = in(c, r).  row_idx (optional, no transpose): out row r = in row row_idx[r]. */
+ * zero-filled).  transpose != 0: out(r, c) = in(c, r).  row_idx (optional, no transpose): out row r = in row row_idx[r].
+ * plane_stride 0: write plane 0 only, i.e. the matrix rounded to bf16 (the single-plane mode's operand format). */
 int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t cols_out, void* out, int64_t plane_stride, int32_t ld_out,
                        int32_t transpose, const int64_t* row_idx, pulse_stream_t s);
 

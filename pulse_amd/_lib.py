@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -181,7 +181,7 @@ class GemmX3pDesc(Structure):
                 ("stride_a", c_int64), ("stride_b", c_int64), ("stride_c", c_int64), ("stride_cp", c_int64), ("stride_c2", c_int64),
                 ("stride_bias", c_int64), ("stride_aux", c_int64),
                 ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
-                ("rowsum", c_void_p), ("stride_rowsum", c_int64)]
+                ("rowsum", c_void_p), ("stride_rowsum", c_int64), ("planes", c_int32), ("aux_is_bf16", c_int32)]
 
 
 class GemmDesc(Structure):

@@ -21,6 +21,12 @@
 // once.  [red][out] operand tile, per plane: [32 k rows][out pieces of 16 B], piece p of row m at slot p ^ ((m & 3) << 2): the four
 // rows x four pieces a half-wave's transposing read touches are 16 different bank groups.
 // Two stages of (3 A planes + 3 B planes) = 144 KB (256-row tile), one workgroup per CU, two waves per SIMD; one barrier per k-tile.
+//
+// Single-plane mode (NPL = 1, "b16"): the operands ARE bf16 matrices (bf16 autocast training, BASELINE.json configs[4]; the reference's
+// autocast sites are phc/learning/amp_agent.py:671 and common_agent.py:426,461) -- activations and gradients live in HBM as bf16, half
+// the bytes of the fp32-storage bf16 kernel in gemm_f32.hip, which is bound by exactly that traffic.  Same pipeline: the three plane
+// slots of a stage hold three CONSECUTIVE 32-deep k-tiles of the one plane, a k step is the three diagonal products (12 MFMAs) instead
+// of the six cross terms, and k-tiles past the reduction's end are skipped (their slots hold stale bytes nobody multiplies).
 #include <type_traits>
 #include "common.h"
 
@@ -45,7 +51,7 @@ struct XpArgs {
     const unsigned short* A; const unsigned short* B;
     long long pa, pb;                  // plane strides (elements)
     int lda, ldb;                      // pitches (elements)
-    float* C; float* C2; unsigned short* Cp; const float* bias; const float* aux;
+    float* C; float* C2; unsigned short* Cp; const float* bias; const float* aux; const unsigned short* aux16;
     long long pc;                      // plane stride of Cp (elements)
     int ldc, ldc2, ldcp, ldaux;
     int M, N, K;
@@ -86,17 +92,24 @@ __device__ __forceinline__ bf16x8 xp_lds128(int addr) {
 }
 // [red][out] fragment: 8 consecutive k of one out = two transposing 8-byte reads (k rows 0-3 and 4-7 of the lane's k-chunk)
 __device__ __forceinline__ bf16x8 xp_lds_tr(int addr_lo, int addr_hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char xp_smem[];
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xp_smem + addr_lo));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xp_smem + addr_hi));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return __builtin_bit_cast(bf16x8, v);
+#else
+    // host pass of the single-source compile: the gfx950-only builtin does not exist there, and a kernel template whose instantiation
+    // reaches it is silently not emitted (its launch stub goes missing at link time)
+    return bf16x8{};
+#endif
 }
 
 // AKC / BKC: operand stored [out][k] (reduction-contiguous); otherwise [k][out].
-template <bool AKC, bool BKC, int WMW>
+template <bool AKC, bool BKC, int WMW, int NPL>
 __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
+    static_assert(NPL == 1 || NPL == 3, "three planes (fp32-grade) or one (bf16 operands)");
     using G = XpGeom<WMW>;
     constexpr int BM = G::BM, NW = G::NW;
     extern __shared__ __attribute__((aligned(16))) char xp_smem[];
@@ -119,15 +132,16 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
     const int kbeg = sp * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int klen = kend - kbeg;
-    const int nkt = (klen + PK - 1) / PK;
-    const int kpad = nkt * PK;                                   // the planes are zero-padded to a multiple of 32 in k
+    const int nkt32 = (klen + PK - 1) / PK;                      // 32-deep k-tiles of this split
+    const int kpad = nkt32 * PK;                                 // the planes are zero-padded to a multiple of 32 in k
+    const int nkt = NPL == 3 ? nkt32 : (nkt32 + 2) / 3;          // pipeline stages: one k-tile of three planes, or three k-tiles of one
 
     // ---- buffer resources: one per plane and operand, based at this workgroup's tile origin, with the true extent (rows / outs past
     // the operand read as zero and write zeros into LDS; they only feed outputs that are never stored)
     const int extA = min(BM, g.M - m0), extB = min(PBN, g.N - n0);
-    __amdgpu_buffer_rsrc_t rsA[3], rsB[3];
+    __amdgpu_buffer_rsrc_t rsA[3], rsB[3];                          // (a template-dependent extent here makes the host pass drop the kernel's stub)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NPL; ++p) {
         const unsigned short* a = g.A + bz * g.sA + p * g.pa + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
         const unsigned short* b = g.B + bz * g.sB + p * g.pb + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
         const unsigned ra = (unsigned)(AKC ? ((extA - 1) * g.lda + kpad) : ((klen - 1) * g.lda + ((extA + 7) & ~7))) * 2u;
@@ -135,31 +149,36 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
         rsA[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a), 0, klen > 0 ? ra : 0u, P_RSRC);
         rsB[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(b), 0, klen > 0 ? rb : 0u, P_RSRC);
     }
-    // per-lane DMA source offsets (bytes, constant); the k-tile / row-block advance is the scalar offset.
-    //   KC: one instruction = 16 rows x 4 chunks: lane L -> row L >> 2, slot L & 3 holding chunk (L & 3) ^ ((L >> 4) & 3)
-    //   MC: one instruction = 4 k rows x 16 pieces (128 outs): lane L -> k row L >> 4, slot L & 15 holding piece (L & 15) ^ (((L >> 4) & 3) << 2)
-    static_assert(AKC && BKC, "[red][out] operands (transposing LDS reads) are the next step; this build handles reduction-contiguous operands");
-    const int voA = ((lane >> 2) * g.lda + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2;
-    const int voB = ((lane >> 2) * g.ldb + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2;
-    constexpr int ktA = PK * 2, ktB = PK * 2;                                              // bytes per k-tile
-    // DMA of k-tile t into the stage at byte offset stage_off: (3 BM / 16 + 3 * 128 / 16) wave instructions of 16 rows x 64 B, dealt
-    // round-robin to the waves: unit j of this wave is instruction i = wave + j NW (plane and operand compile-time, row block wave + const)
+    // per-lane DMA source offsets (bytes, constant); the k-tile / row-block advance is the scalar offset.  One wave instruction fills
+    // 1024 consecutive LDS bytes (lane L: bytes 16 L ..), "row block" rb of a sub-tile:
+    //   KC: 16 rows x 4 chunks: lane L -> row 16 rb + (L >> 2), slot L & 3 holding chunk (L & 3) ^ ((L >> 4) & 3)
+    //   MC: 4 k rows x 16 pieces of one 128-out block: block rb >> 3, k rows 4 (rb & 7) + (L >> 4), slot L & 15 holding piece
+    //       (L & 15) ^ ((L >> 4) << 2)
+    const int voA = AKC ? ((lane >> 2) * g.lda + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2
+                        : ((lane >> 4) * g.lda + (((lane & 15) ^ ((lane >> 4) << 2)) << 3)) * 2;
+    const int voB = BKC ? ((lane >> 2) * g.ldb + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2
+                        : ((lane >> 4) * g.ldb + (((lane & 15) ^ ((lane >> 4) << 2)) << 3)) * 2;
+    const int ktA = AKC ? PK * 2 : PK * g.lda * 2, ktB = BKC ? PK * 2 : PK * g.ldb * 2;   // bytes per 32-deep k-tile
+    // DMA of stage t into the stage buffer at byte offset stage_off: (3 BM / 16 + 3 * 128 / 16) wave instructions, dealt round-robin to
+    // the waves: unit j of this wave is instruction i = wave + j NW (sub-tile and operand compile-time, row block wave + const)
     constexpr int DMA_PER_WAVE = (3 * BM / 16 + 3 * PBN / 16) / NW;
     auto issue_unit = [&](int stage_off, int t, int j) {
         constexpr int PA = BM / 16, PB = PBN / 16, NA = 3 * PA;
         static_assert(PA % NW == 0 && (PB % NW == 0), "row blocks per plane must be a multiple of the wave count");
         const int i0 = j * NW;
         if (i0 < NA) {
-            const int plane = i0 / PA;
+            const int sub = i0 / PA;
             const int rb = wave + (i0 % PA);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA[plane], (lds_void_t*)(xp_smem + stage_off + plane * G::A_PLANE + rb * 1024), 16, voA,
-                                                     t * ktA + rb * 16 * g.lda * 2, 0, 0);
+            const int kt = NPL == 3 ? t : 3 * t + sub;
+            const int so = AKC ? kt * ktA + rb * 16 * g.lda * 2 : kt * ktA + (rb & 7) * 4 * g.lda * 2 + (rb >> 3) * 256;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA[NPL == 3 ? sub : 0], (lds_void_t*)(xp_smem + stage_off + sub * G::A_PLANE + rb * 1024), 16, voA, so, 0, 0);
         } else {
             const int ii0 = i0 - NA;
-            const int plane = ii0 / PB;
+            const int sub = ii0 / PB;
             const int rb = wave + (ii0 % PB);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[plane], (lds_void_t*)(xp_smem + stage_off + G::A_IMG + plane * G::B_PLANE + rb * 1024), 16, voB,
-                                                     t * ktB + rb * 16 * g.ldb * 2, 0, 0);
+            const int kt = NPL == 3 ? t : 3 * t + sub;
+            const int so = BKC ? kt * ktB + rb * 16 * g.ldb * 2 : kt * ktB + (rb & 7) * 4 * g.ldb * 2 + (rb >> 3) * 256;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[NPL == 3 ? sub : 0], (lds_void_t*)(xp_smem + stage_off + G::A_IMG + sub * G::B_PLANE + rb * 1024), 16, voB, so, 0, 0);
         }
     };
     auto issue_tile = [&](int stage_off, int t) {
@@ -167,19 +186,33 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
         for (int j = 0; j < DMA_PER_WAVE; ++j) issue_unit(stage_off, t, j);
     };
 
-    // ---- fragment read addresses (bytes, per lane; the plane and the stage are immediates / added constants)
+    // ---- fragment read addresses (bytes, per lane; the sub-tile and the stage are immediates / added constants)
     //   KC: lane (l31, half) of k-step ks reads row (tile row + l31), chunk 2 ks + half -> slot (2 ks + half) ^ ((l31 >> 2) & 3)
-    //   MC: 16-lane group gq = lane >> 4: outs 16 (gq & 1) .. + 15 of the 32-wide tile, k rows 8 (gq >> 1) + {0..3 | 4..7} of the k-step;
-    //       lane 4 j + q of the group addresses k row j, 8-byte piece q of those 16 outs
+    //   MC: 16-lane group gq = lane >> 4 covers outs 16 (gq & 1) .. + 15 of the 32-wide MFMA tile and k rows 8 (gq >> 1) .. + 7 of the
+    //       k-step; lane 4 j + q of the group addresses k row j (second read: j + 4), 8-byte piece q of those 16 outs, and receives the
+    //       four k values of out (lane & 15) (ds_read_b64_tr_b16; tools/tr_probe.cpp)
     int frA[2][2], frB[2][2];                                       // [mfma tile][k-step]
     {
         const int sw = (l31 >> 2) & 3;
+        const int gq = lane >> 4, jj = (lane >> 2) & 3, qq = lane & 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                frA[i][ks] = ((wm * 64 + i * 32 + l31) * 4 + ((2 * ks + half) ^ sw)) * 16;
-                frB[i][ks] = G::A_IMG + ((wn * 64 + i * 32 + l31) * 4 + ((2 * ks + half) ^ sw)) * 16;
+                if constexpr (AKC) {
+                    frA[i][ks] = ((wm * 64 + i * 32 + l31) * 4 + ((2 * ks + half) ^ sw)) * 16;
+                } else {
+                    const int o = wm * 64 + i * 32 + 16 * (gq & 1);               // first out of this group inside the tile
+                    const int piece = ((o & 127) >> 3) + (qq >> 1);
+                    frA[i][ks] = (o >> 7) * 8192 + (ks * 16 + 8 * (gq >> 1) + jj) * 256 + ((piece ^ (jj << 2)) << 4) + (qq & 1) * 8;
+                }
+                if constexpr (BKC) {
+                    frB[i][ks] = G::A_IMG + ((wn * 64 + i * 32 + l31) * 4 + ((2 * ks + half) ^ sw)) * 16;
+                } else {
+                    const int o = wn * 64 + i * 32 + 16 * (gq & 1);
+                    const int piece = (o >> 3) + (qq >> 1);
+                    frB[i][ks] = G::A_IMG + (ks * 16 + 8 * (gq >> 1) + jj) * 256 + ((piece ^ (jj << 2)) << 4) + (qq & 1) * 8;
+                }
             }
     }
 
@@ -198,34 +231,48 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
             for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
     }
 
-    // fragments: [set][plane][mfma tile]
+    // fragments: [set][sub-tile][mfma tile]
     bf16x8 fa[2][3][2], fb[2][3][2];
-    // read unit u (0..11) of k-step ks of the stage at byte offset st into set S: A planes 2, 0, 1 / B planes 0, 2, 1 in consumption order
+    auto rdA = [&](int addr) { if constexpr (AKC) return xp_lds128(addr); else return xp_lds_tr(addr, addr + 1024); };
+    auto rdB = [&](int addr) { if constexpr (BKC) return xp_lds128(addr); else return xp_lds_tr(addr, addr + 1024); };
+    // read unit u (0..11) of k-step ks of the stage at byte offset st into set S, in consumption order:
+    //   three planes: term sequence (2,0) (0,2) (1,1) (1,0) (0,1) (0,0) -> A2 A2' B0 B0' | B2 B2' A0 A0' | A1 A1' B1 B1'
+    //   one plane:    sub-tile 0, 1, 2 -> A A' B B' each
     auto frag_unit = [&](auto set_tag, int u, int st, int ks) {
         constexpr int S = decltype(set_tag)::value;
-        // consumption order of the term sequence (2,0) (0,2) (1,1) (1,0) (0,1) (0,0): A2 A2' B0 B0' | B2 B2' A0 A0' | A1 A1' B1 B1'
         const int grp = u >> 2, w = u & 3, i = w & 1;
-        const bool isA = grp == 1 ? (w >= 2) : (w < 2);
-        const int pl = isA ? (grp == 0 ? 2 : grp == 1 ? 0 : 1) : (grp == 0 ? 0 : grp == 1 ? 2 : 1);
-        if (isA) fa[S][pl][i] = xp_lds128(st + pl * G::A_PLANE + frA[i][ks]);
-        else fb[S][pl][i] = xp_lds128(st + pl * G::B_PLANE + frB[i][ks]);
+        bool isA; int pl;
+        if constexpr (NPL == 3) {
+            isA = grp == 1 ? (w >= 2) : (w < 2);
+            pl = isA ? (grp == 0 ? 2 : grp == 1 ? 0 : 1) : (grp == 0 ? 0 : grp == 1 ? 2 : 1);
+        } else {
+            isA = w < 2; pl = grp;
+        }
+        if (isA) fa[S][pl][i] = rdA(st + pl * G::A_PLANE + frA[i][ks]);
+        else fb[S][pl][i] = rdB(st + pl * G::B_PLANE + frB[i][ks]);
     };
-    // 24 MFMAs of one k-step on set S; after MFMA q the side work slot(q) runs
-    auto kstep = [&](auto set_tag, auto&& slot) {
+    // MFMAs of one k-step on set S (24 cross terms, or 12 diagonal ones of which those of k-tiles past the end are skipped: ``live`` =
+    // k-tiles of this stage that exist, wave-uniform); after MFMA q the side work slot(q) runs
+    constexpr int NQ = NPL == 3 ? 24 : 12;
+    auto kstep = [&](auto set_tag, int live, auto&& slot) {
         constexpr int S = decltype(set_tag)::value;
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int term = q >> 2, i = (q >> 1) & 1, j = q & 1;
-            const int pa_ = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
-            const int pb_ = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][pa_][i], fb[S][pb_][j], acc[i][j], 0, 0, 0);
+            if constexpr (NPL == 3) {
+                const int pa_ = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
+                const int pb_ = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][pa_][i], fb[S][pb_][j], acc[i][j], 0, 0, 0);
+            } else {
+                if (term < live) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][term][i], fb[S][term][j], acc[i][j], 0, 0, 0);
+            }
             slot(q);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
-    // ---- prologue: tiles 0 and 1 on their way, tile 0 landed, first fragments read
+    // ---- prologue: stages 0 and 1 on their way, stage 0 landed, first fragments read
     if (nkt > 0) issue_tile(0, 0);
     if (nkt > 1) issue_tile(G::STAGE, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -237,21 +284,23 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
         for (int u = 0; u < 12; ++u) frag_unit(I0{}, u, 0, 0);
     }
 
-    // Behind k-step 1's first MFMAs the first fragments of tile t + 1 are read (unconditionally: past the last tile they fetch stale LDS
-    // bytes nobody uses); behind its later ones the DMA of tile t + 2 is issued, one instruction per MFMA gap, into the stage this tile
-    // has just released (wave-uniform condition: the last two tiles issue none).
+    // Behind k-step 1's first MFMAs the first fragments of stage t + 1 are read (unconditionally: past the last stage they fetch stale LDS
+    // bytes nobody uses); behind its MFMAs too (three planes: the later ones) the DMA of stage t + 2 is issued, one instruction per MFMA
+    // gap, into the buffer this stage has just released (wave-uniform condition: the last two stages issue none).
     auto tile = [&](auto stage_tag, int t) {
         constexpr int CUR = decltype(stage_tag)::value * G::STAGE, OTH = G::STAGE - CUR;
         const bool more2 = t + 2 < nkt;
+        const int live = NPL == 3 ? 3 : min(3, nkt32 - 3 * t);
         // k-step 0 on set 0; the 12 fragment reads of k-step 1 behind its first MFMAs
-        kstep(I0{}, [&](int q) { if (q < 12) frag_unit(I1{}, q, CUR, 1); });
-        // every wave has read what it needs of this stage (its reads are issued; lgkmcnt(0) completes them); tile t + 1 has landed
+        kstep(I0{}, live, [&](int q) { if (q < 12) frag_unit(I1{}, q, CUR, 1); });
+        // every wave has read what it needs of this stage (its reads are issued; lgkmcnt(0) completes them); stage t + 1 has landed
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        kstep(I1{}, [&](int q) {
+        kstep(I1{}, live, [&](int q) {
             if (q < 12) frag_unit(I0{}, q, OTH, 0);
-            else if (q - 12 < DMA_PER_WAVE) { if (more2) issue_unit(CUR, t + 2, q - 12); }
+            constexpr int D0 = NPL == 3 ? 12 : 0;
+            if (q >= D0 && q - D0 < DMA_PER_WAVE) { if (more2) issue_unit(CUR, t + 2, q - D0); }
         });
     };
     for (int t = 0; t < nkt; t += 2) {
@@ -276,6 +325,7 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
         float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
         unsigned short* Cp = g.Cp ? g.Cp + bz * g.sCp : nullptr;
         const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+        const unsigned short* aux16 = g.aux16 ? g.aux16 + bz * g.sAux : nullptr;
         const int c8 = (tid & 15) * 8;
         const int col = n0 + c8;
         constexpr int RPI = G::NT / 16;                             // rows per iteration
@@ -288,6 +338,14 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4);
                 float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if constexpr (NPL == 1) {
+                    // a bf16 autocast Linear hands bf16 to the next op: the product leaves rounded, the activation / mask acts on that
+                    // (split-K slabs are partial sums and stay fp32)
+                    if (g.splitk == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = (float)(__bf16)o[k];
+                    }
+                }
                 if (g.epi == 0) {
                     if (g.act == 1) {
 #pragma unroll
@@ -295,19 +353,25 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
                     } else if (g.act == 2) {
                         if (C2) {
                             float* p2 = C2 + (long long)row * g.ldc2 + col;
-                            if (full) { *reinterpret_cast<f32x4*>(p2) = v0; *reinterpret_cast<f32x4*>(p2 + 4) = v1; }
+                            if (full) { *reinterpret_cast<f32x4*>(p2) = (f32x4){o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(p2 + 4) = (f32x4){o[4], o[5], o[6], o[7]}; }
                             else for (int k = 0; k < 8 && col + k < g.N; ++k) p2[k] = o[k];
                         }
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
                     }
                 } else {
-                    const float* pa = aux + (long long)row * g.ldaux + col;
                     float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    if (full) {
-                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(pa), t1 = *reinterpret_cast<const f32x4*>(pa + 4);
-                        a8[0] = t0.x; a8[1] = t0.y; a8[2] = t0.z; a8[3] = t0.w; a8[4] = t1.x; a8[5] = t1.y; a8[6] = t1.z; a8[7] = t1.w;
-                    } else for (int k = 0; k < 8 && col + k < g.N; ++k) a8[k] = pa[k];
+                    if (aux16) {                                    // bf16-stored activations (rows hold roundup8(N) columns)
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(aux16 + (long long)row * g.ldaux + col);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { a8[2 * k] = xp_bitsf(t[k] << 16); a8[2 * k + 1] = xp_bitsf(t[k] & 0xffff0000u); }
+                    } else {
+                        const float* pa = aux + (long long)row * g.ldaux + col;
+                        if (full) {
+                            const f32x4 t0 = *reinterpret_cast<const f32x4*>(pa), t1 = *reinterpret_cast<const f32x4*>(pa + 4);
+                            a8[0] = t0.x; a8[1] = t0.y; a8[2] = t0.z; a8[3] = t0.w; a8[4] = t1.x; a8[5] = t1.y; a8[6] = t1.z; a8[7] = t1.w;
+                        } else for (int k = 0; k < 8 && col + k < g.N; ++k) a8[k] = pa[k];
+                    }
                     if (g.epi == 1) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = a8[k] > 0.f ? o[k] : 0.f;
@@ -332,14 +396,17 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float a = col + 2 * k < g.N ? o[2 * k] : 0.f, b = col + 2 * k + 1 < g.N ? o[2 * k + 1] : 0.f;
-                        unsigned x0, x1, x2;
-                        xp_split_pair(a, b, x0, x1, x2);
+                        unsigned x0, x1 = 0u, x2 = 0u;
+                        if constexpr (NPL == 3) xp_split_pair(a, b, x0, x1, x2);
+                        else x0 = xp_pack_rn(a, b);
                         q0[k] = x0; q1[k] = x1; q2[k] = x2;
                     }
                     unsigned short* pp = Cp + (long long)row * g.ldcp + col;
                     *reinterpret_cast<u32x4*>(pp) = q0;
-                    *reinterpret_cast<u32x4*>(pp + g.pc) = q1;
-                    *reinterpret_cast<u32x4*>(pp + 2 * g.pc) = q2;
+                    if constexpr (NPL == 3) {
+                        *reinterpret_cast<u32x4*>(pp + g.pc) = q1;
+                        *reinterpret_cast<u32x4*>(pp + 2 * g.pc) = q2;
+                    }
                 }
             }
         }
@@ -378,8 +445,10 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
         }
         unsigned short* o = out + (long long)r * ld_out + c0;
         *reinterpret_cast<u32x4*>(o) = q0;
-        *reinterpret_cast<u32x4*>(o + plane_stride) = q1;
-        *reinterpret_cast<u32x4*>(o + 2 * plane_stride) = q2;
+        if (plane_stride) {                                         // plane_stride 0: a plain bf16 matrix (plane 0 only)
+            *reinterpret_cast<u32x4*>(o + plane_stride) = q1;
+            *reinterpret_cast<u32x4*>(o + 2 * plane_stride) = q2;
+        }
     }
 }
 
@@ -396,8 +465,8 @@ int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t
     PULSE_REQUIRE(rows_out >= 0 && cols_out >= 0, "pulse_split_planes: negative size");
     if (rows_out == 0) return PULSE_OK;
     PULSE_REQUIRE(in && out, "pulse_split_planes: null pointer");
-    PULSE_REQUIRE(ld_out % 8 == 0 && ld_out >= cols_out && plane_stride >= (int64_t)rows_out * ld_out && plane_stride % 8 == 0,
-                  "pulse_split_planes: ld_out must be a multiple of 8 covering cols_out, plane_stride a multiple of 8 covering the plane");
+    PULSE_REQUIRE(ld_out % 8 == 0 && ld_out >= cols_out && (plane_stride == 0 || plane_stride >= (int64_t)rows_out * ld_out) && plane_stride % 8 == 0,
+                  "pulse_split_planes: ld_out must be a multiple of 8 covering cols_out, plane_stride a multiple of 8 covering the plane (or 0: one plane)");
     PULSE_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "pulse_split_planes: out must be 16-byte aligned");
     const int vec_in = !transpose && (ld_in % 4) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;      // 16-byte loads when the rows allow them
     PULSE_REQUIRE(!(transpose && row_idx), "pulse_split_planes: row_idx with transpose is not supported");
@@ -415,8 +484,11 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     if (d->M == 0 || d->N == 0 || d->batch == 0) return PULSE_OK;
     PULSE_REQUIRE(d->A && d->B && (d->C || d->Cp), "pulse_gemm_x3p: null operand / no output");
     PULSE_REQUIRE(d->batch >= 1 && d->split_k >= 1, "pulse_gemm_x3p: batch / split_k must be >= 1");
+    PULSE_REQUIRE(d->planes == 0 || d->planes == 1 || d->planes == 3, "pulse_gemm_x3p: planes must be 3 (fp32-grade; 0 means 3) or 1 (bf16 operands)");
+    const int npl = d->planes == 1 ? 1 : 3;
     const bool akc = d->a_layout == PULSE_GEMM_RED_CONTIG, bkc = d->b_layout == PULSE_GEMM_RED_CONTIG;
     PULSE_REQUIRE(akc == bkc || (akc && !bkc), "pulse_gemm_x3p: layout combination (A out-contiguous, B reduction-contiguous) unsupported");
+    PULSE_REQUIRE((akc && bkc) || npl == 1, "pulse_gemm_x3p: [red][out] operands are built for the single-plane (bf16) mode only");
     PULSE_REQUIRE((d->lda % 8) == 0 && (d->ldb % 8) == 0 && (d->a_plane_stride % 8) == 0 && (d->b_plane_stride % 8) == 0 &&
                   (d->stride_a % 8) == 0 && (d->stride_b % 8) == 0, "pulse_gemm_x3p: operand pitches / strides must be multiples of 8 elements");
     PULSE_REQUIRE((reinterpret_cast<uintptr_t>(d->A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->B) & 15) == 0, "pulse_gemm_x3p: A / B must be 16-byte aligned");
@@ -433,23 +505,30 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     PULSE_REQUIRE(!d->Cp || d->split_k == 1, "pulse_gemm_x3p: split-K slabs carry no planes");
     PULSE_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2 && d->activation >= 0 && d->activation <= 2, "pulse_gemm_x3p: bad epilogue / activation");
     PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr, "pulse_gemm_x3p: gradient epilogue needs aux");
-    PULSE_REQUIRE(!d->aux || ((reinterpret_cast<uintptr_t>(d->aux) & 15) == 0 && (d->ldaux % 4) == 0 && (d->stride_aux % 4) == 0), "pulse_gemm_x3p: aux rows must be 16-byte aligned");
+    if (d->aux_is_bf16) {
+        PULSE_REQUIRE(!d->aux || ((reinterpret_cast<uintptr_t>(d->aux) & 15) == 0 && (d->ldaux % 8) == 0 && (d->stride_aux % 8) == 0 && d->ldaux >= ((d->N + 7) & ~7)),
+                      "pulse_gemm_x3p: bf16 aux rows must be 16-byte aligned and hold roundup8(N) columns");
+    } else {
+        PULSE_REQUIRE(!d->aux || ((reinterpret_cast<uintptr_t>(d->aux) & 15) == 0 && (d->ldaux % 4) == 0 && (d->stride_aux % 4) == 0), "pulse_gemm_x3p: aux rows must be 16-byte aligned");
+    }
     PULSE_REQUIRE(!d->C2 || ((reinterpret_cast<uintptr_t>(d->C2) & 15) == 0 && (d->ldc2 % 4) == 0 && (d->stride_c2 % 4) == 0), "pulse_gemm_x3p: C2 rows must be 16-byte aligned");
     PULSE_REQUIRE(d->split_k == 1 || (d->epilogue == 0 && d->activation == 0 && d->bias == nullptr), "pulse_gemm_x3p: split-K slabs carry no epilogue");
     PULSE_REQUIRE(d->rowsum == nullptr, "pulse_gemm_x3p: rowsum is not implemented in this build");
-    PULSE_REQUIRE(akc && bkc, "pulse_gemm_x3p: [red][out] operands are not enabled in this build");
 
     XpArgs g;
     g.A = reinterpret_cast<const unsigned short*>(d->A); g.B = reinterpret_cast<const unsigned short*>(d->B);
     g.pa = d->a_plane_stride; g.pb = d->b_plane_stride; g.lda = d->lda; g.ldb = d->ldb;
-    g.C = d->C; g.C2 = d->C2; g.Cp = reinterpret_cast<unsigned short*>(d->Cp); g.bias = d->bias; g.aux = d->aux;
+    g.C = d->C; g.C2 = d->C2; g.Cp = reinterpret_cast<unsigned short*>(d->Cp); g.bias = d->bias;
+    g.aux = d->aux_is_bf16 ? nullptr : d->aux;
+    g.aux16 = d->aux_is_bf16 ? reinterpret_cast<const unsigned short*>(d->aux) : nullptr;
     g.pc = d->c_plane_stride; g.ldc = d->ldc; g.ldc2 = d->ldc2; g.ldcp = d->ldcp; g.ldaux = d->ldaux;
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.sA = d->stride_a; g.sB = d->stride_b; g.sC = d->stride_c; g.sC2 = d->stride_c2; g.sCp = d->stride_cp; g.sBias = d->stride_bias; g.sAux = d->stride_aux;
     g.batch = d->batch; g.splitk = d->split_k;
+    const int kq = npl == 1 ? 3 * PK : PK;                           // split-K chunks are whole pipeline stages
     int kchunk = (d->K + d->split_k - 1) / d->split_k;
-    kchunk = ((kchunk + PK - 1) / PK) * PK;
-    g.kchunk = kchunk > 0 ? kchunk : PK;
+    kchunk = ((kchunk + kq - 1) / kq) * kq;
+    g.kchunk = kchunk > 0 ? kchunk : kq;
     g.sSplit = d->split_stride;
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
@@ -459,26 +538,32 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     g.tiles_m = big ? (d->M + 255) / 256 : (d->M + 127) / 128;
     g.tiles_n = (d->N + PBN - 1) / PBN;
     PULSE_REQUIRE((long long)d->lda * 300 < (1LL << 29) && (long long)d->ldb * 300 < (1LL << 29), "pulse_gemm_x3p: pitch too large for 32-bit tile-relative offsets");
+    // [red][out] operands advance lda elements per k row: the whole k extent of a split must stay inside the 32-bit scalar offset
+    PULSE_REQUIRE(akc || (long long)g.kchunk * d->lda * 2 < (1LL << 31), "pulse_gemm_x3p: split the reduction further (k extent x pitch exceeds 2 GiB)");
+    PULSE_REQUIRE(bkc || (long long)g.kchunk * d->ldb * 2 < (1LL << 31), "pulse_gemm_x3p: split the reduction further (k extent x pitch exceeds 2 GiB)");
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
-    static bool attr_done[2] = {false, false};
     hipError_t e = hipSuccess;
-    if (big) {
-        constexpr int lds = XpGeom<4>::LDS;
-        if (!attr_done[0]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<true, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_x3p: LDS attribute: %s", hipGetErrorString(e));
-            attr_done[0] = true;
-        }
-        hipLaunchKernelGGL((gemm_x3p_kernel<true, true, 4>), grid, dim3(512), lds, as_stream(s), g);
+#define PULSE_XP_LAUNCH(AK, BK_, W, NP, SLOT)                                                                                                   \
+    do {                                                                                                                                        \
+        constexpr int lds = XpGeom<W>::LDS;                                                                                                     \
+        static bool done = false;                                                                                                               \
+        if (!done) {                                                                                                                            \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<AK, BK_, W, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_x3p: LDS attribute: %s", hipGetErrorString(e));                     \
+            done = true;                                                                                                                        \
+        }                                                                                                                                       \
+        hipLaunchKernelGGL((gemm_x3p_kernel<AK, BK_, W, NP>), grid, dim3(128 * W), lds, as_stream(s), g);                                       \
+    } while (0)
+    if (npl == 3) {
+        if (big) PULSE_XP_LAUNCH(true, true, 4, 3, 0); else PULSE_XP_LAUNCH(true, true, 2, 3, 1);
+    } else if (akc && bkc) {
+        if (big) PULSE_XP_LAUNCH(true, true, 4, 1, 2); else PULSE_XP_LAUNCH(true, true, 2, 1, 3);
+    } else if (akc) {
+        if (big) PULSE_XP_LAUNCH(true, false, 4, 1, 4); else PULSE_XP_LAUNCH(true, false, 2, 1, 5);
     } else {
-        constexpr int lds = XpGeom<2>::LDS;
-        if (!attr_done[1]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_x3p: LDS attribute: %s", hipGetErrorString(e));
-            attr_done[1] = true;
-        }
-        hipLaunchKernelGGL((gemm_x3p_kernel<true, true, 2>), grid, dim3(256), lds, as_stream(s), g);
+        if (big) PULSE_XP_LAUNCH(false, false, 4, 1, 6); else PULSE_XP_LAUNCH(false, false, 2, 1, 7);
     }
+#undef PULSE_XP_LAUNCH
     return check_launch("pulse_gemm_x3p");
 }
 }

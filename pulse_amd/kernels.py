@@ -250,34 +250,79 @@ def join_planes(p):
     return (f[0].double() + f[1].double() + f[2].double()).float()
 
 
+def alloc_b16(rows, cols, device):
+    """(rows, pitch) int16 (bf16 bit patterns), zero-initialised: a single-plane operand / output of gemm_x3p(planes=1)."""
+    return torch.zeros(rows, planes_pitch(cols), dtype=torch.int16, device=device)
+
+
+def to_b16(x, out=None, *, rows=None, cols=None, transpose=False, row_idx=None, x_off=0, ld_in=None, out_off=0):
+    """fp32 matrix -> the same matrix rounded to bf16 (round to nearest even), pad columns zero-filled.  Geometry arguments as split_planes."""
+    _chk(x, "x")
+    if ld_in is None:
+        if x.dim() != 2 or x.stride(1) != 1:
+            raise ValueError("to_b16: 2-D tensor with contiguous rows expected (or explicit geometry)")
+        ld_in = x.stride(0)
+        r_in, c_in = x.shape
+        rows_out, cols_out = (c_in, r_in) if transpose else (r_in, c_in)
+        if row_idx is not None:
+            rows_out = row_idx.numel()
+    else:
+        rows_out, cols_out = rows, cols
+    if out is None:
+        out = alloc_b16(rows_out, cols_out, x.device)
+    if out.dtype != torch.int16 or out.dim() != 2 or out.stride(1) != 1 or not out.is_cuda:
+        raise TypeError("to_b16: out must be a (rows, pitch) int16 CUDA tensor")
+    _chk(row_idx, "row_idx", torch.int64)
+    _lib.check(_lib.load().pulse_split_planes(x.data_ptr() + 4 * x_off, ld_in, rows_out, cols_out, out.data_ptr() + 2 * out_off, 0,
+                                              out.stride(0), 1 if transpose else 0, _p(row_idx), _stream()), "pulse_split_planes")
+    return out
+
+
+def from_b16(p):
+    """The fp32 values of a bf16 bit-pattern tensor."""
+    return (p.to(torch.int32) << 16).view(torch.float32)
+
+
 def make_gemm_x3p_desc(A, B, *, M, N, K, C=None, Cp=None, bias=None, activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None,
                        ldc2=0, ldc=0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_cp=0, stride_c2=0, stride_bias=0, stride_aux=0,
-                       a_off=0, b_off=0, c_off=0, cp_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None):
-    """A / B / Cp are planes tensors (3, rows, pitch) int16; *_off are element offsets inside a plane.  Returns (descriptor, algorithmic
-    FLOPs, tag) like make_gemm_desc."""
-    for t, nm in ((A, "A"), (B, "B"), (Cp, "Cp")):
-        if t is not None and (t.dtype != torch.int16 or t.dim() != 3 or t.shape[0] != 3 or t.stride(2) != 1 or not t.is_cuda):
-            raise TypeError(f"gemm_x3p: {nm} must be a (3, rows, pitch) int16 CUDA planes tensor")
+                       a_off=0, b_off=0, c_off=0, cp_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None, planes=3,
+                       a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, split_k=1, split_stride=0, lda=None, ldb=None, ldcp=None):
+    """planes=3: A / B / Cp are planes tensors (3, rows, pitch) int16.  planes=1 (bf16 operands): (rows, pitch) int16 matrices (or flat
+    int16 buffers with lda / ldb / ldcp given), aux may be one too (ReLU-mask / SiLU-derivative epilogues reading bf16 activations).
+    *_off are element offsets.  Returns (descriptor, algorithmic FLOPs, tag) like make_gemm_desc."""
+    nd = 3 if planes == 3 else 2
+    for t, nm, ld in ((A, "A", lda), (B, "B", ldb), (Cp, "Cp", ldcp)):
+        if t is None:
+            continue
+        flat_ok = planes == 1 and ld is not None and t.dim() == 1
+        if t.dtype != torch.int16 or not t.is_cuda or not (flat_ok or (t.dim() == nd and t.stride(nd - 1) == 1 and (planes == 1 or t.shape[0] == 3))):
+            raise TypeError(f"gemm_x3p: {nm} must be a {'(3, rows, pitch)' if planes == 3 else '(rows, pitch)'} int16 CUDA tensor")
     d = _lib.GemmX3pDesc()
-    d.A, d.a_plane_stride, d.lda = A.data_ptr() + 2 * a_off, A.stride(0), A.stride(1)
-    d.B, d.b_plane_stride, d.ldb = B.data_ptr() + 2 * b_off, B.stride(0), B.stride(1)
-    d.a_layout = d.b_layout = GEMM_RED_CONTIG
+    d.planes = planes
+    d.A, d.a_plane_stride, d.lda = A.data_ptr() + 2 * a_off, (A.stride(0) if planes == 3 else 0), (lda if lda is not None else A.stride(nd - 2))
+    d.B, d.b_plane_stride, d.ldb = B.data_ptr() + 2 * b_off, (B.stride(0) if planes == 3 else 0), (ldb if ldb is not None else B.stride(nd - 2))
+    d.a_layout, d.b_layout = a_layout, b_layout
     if C is not None:
         _chk(C, "C")
         d.C, d.ldc = C.data_ptr() + 4 * c_off, ldc
     if Cp is not None:
-        d.Cp, d.c_plane_stride, d.ldcp = Cp.data_ptr() + 2 * cp_off, Cp.stride(0), Cp.stride(1)
+        d.Cp, d.c_plane_stride, d.ldcp = Cp.data_ptr() + 2 * cp_off, (Cp.stride(0) if planes == 3 else 0), (ldcp if ldcp is not None else Cp.stride(nd - 2))
     d.C2 = (C2.data_ptr() + 4 * c2_off) if C2 is not None else None
     d.ldc2 = ldc2
     d.bias = (bias.data_ptr() + 4 * bias_off) if bias is not None else None
-    d.aux = (aux.data_ptr() + 4 * aux_off) if aux is not None else None
+    if aux is not None and aux.dtype == torch.int16:
+        d.aux, d.aux_is_bf16 = aux.data_ptr() + 2 * aux_off, 1
+    else:
+        d.aux = (aux.data_ptr() + 4 * aux_off) if aux is not None else None
     d.ldaux = ldaux
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.stride_a, d.stride_b, d.stride_c, d.stride_cp, d.stride_c2 = stride_a, stride_b, stride_c, stride_cp, stride_c2
     d.stride_bias, d.stride_aux = stride_bias, stride_aux
-    d.split_k, d.split_stride, d.activation, d.epilogue = 1, 0, activation, epilogue
+    d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
     flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
-    return d, flops, "x3p_fwd"
+    kc_a, kc_b = a_layout == GEMM_RED_CONTIG, b_layout == GEMM_RED_CONTIG
+    tag = ("x3p_" if planes == 3 else "b16_") + ("fwd" if kc_a and kc_b else "dx" if kc_a else "dw")
+    return d, flops, tag
 
 
 def launch_gemm_x3p(d, flops=0.0, tag="x3p_fwd", stream=None):

@@ -312,6 +312,11 @@ def main():
             if r32 is not None:
                 r32["arithmetic"] = ("fp32 in / fp32 out; operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 per 16-deep k step, "
                                      "fp32 accumulation; peak = dense bf16 MFMA peak / 6; the fp32 MFMA's own ceiling is %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS)
+                # not part of the contract's frac: what the fully issued pipe sustains on random operands with nothing to feed (it is clocked to
+                # 1.72 GHz by operand toggling alone), measured once with tools/mfma_ceiling_probe.cpp -> profiles/r03_mfma_ceiling.txt
+                r32["pipe_only_ceiling"] = {"tflops": 1758.3 / 6, "frac_of_it": r32["achieved"] / (1758.3 / 6),
+                                            "source": "profiles/r03_mfma_ceiling.txt (register-resident MFMA chains, random bf16 operands: 1758.3 TFLOP/s at 1.72 GHz; "
+                                                      "2474.5 at 2.39 GHz on all-zero operands)"}
         r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")
         if r16 is not None:
             # mixed precision: the training GEMMs run on the bf16 MFMA (judged against its 2.5 PFLOP/s dense peak; with fp32 operand

@@ -594,6 +594,9 @@ typedef struct pulse_vae_head_bwd_args {
     float* dpheads; int64_t dpheads_stride;     /* out (rows, 2E), optional */
 } pulse_vae_head_bwd_args;
 int pulse_vae_head_backward(const pulse_vae_head_bwd_args* args, pulse_stream_t s);
+int pulse_sizeof_vae_embed_args(void);
+int pulse_sizeof_vae_kin_args(void);
+int pulse_sizeof_vae_head_bwd_args(void);
 
 /* out[i] = scale * sum_s slabs[s*slab_stride + i]  (deterministic split-K / partial-sum reduction) */
 int pulse_reduce_slabs(const float* slabs, int32_t num_slabs, int64_t slab_stride, int64_t count, float* out,

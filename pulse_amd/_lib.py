@@ -262,6 +262,9 @@ SIGNATURES = {
     "pulse_vae_embed": (c_int, [POINTER(VaeEmbedArgs), P]),
     "pulse_vae_kin_loss": (c_int, [POINTER(VaeKinArgs), P]),
     "pulse_vae_head_backward": (c_int, [POINTER(VaeHeadBwdArgs), P]),
+    "pulse_sizeof_vae_embed_args": (c_int, []),
+    "pulse_sizeof_vae_kin_args": (c_int, []),
+    "pulse_sizeof_vae_head_bwd_args": (c_int, []),
     "pulse_sizeof_gemm_x3p_desc": (c_int, []),
     "pulse_split_planes": (c_int, [P, c_int64, c_int32, c_int32, P, c_int64, c_int32, c_int32, P, P]),
     "pulse_reduce_slabs": (c_int, [P, c_int32, c_int64, c_int64, P, c_float, P]),

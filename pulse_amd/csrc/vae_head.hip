@@ -176,6 +176,10 @@ using namespace pulse;
 
 extern "C" {
 
+int pulse_sizeof_vae_embed_args(void) { return (int)sizeof(pulse_vae_embed_args); }
+int pulse_sizeof_vae_kin_args(void) { return (int)sizeof(pulse_vae_kin_args); }
+int pulse_sizeof_vae_head_bwd_args(void) { return (int)sizeof(pulse_vae_head_bwd_args); }
+
 int pulse_vae_embed(const pulse_vae_embed_args* args, pulse_stream_t s) {
     PULSE_REQUIRE(args != nullptr, "pulse_vae_embed: null args");
     const pulse_vae_embed_args& a = *args;

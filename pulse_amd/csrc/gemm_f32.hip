@@ -773,8 +773,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs g) {
 // same fp64-referenced tolerances as the fp32 MFMA kernel; the exactness, linearity and tile-position-independence properties hold bit
 // for bit).  Non-finite inputs give NaN (inf - inf in the split).
 //
-// Tile 128 x 128 x 16, 4 waves, each 2 x 2 MFMA tiles.  LDS image per operand and stage: 3 planes x [2 k-chunks of 8][136 slots][16 B]
-// (slot = out ^ ((out >> 3) & 7); 136 keeps the 2-lanes-per-row store pattern conflict-free), two stages.  Per thread and k-tile:
+// Tile 128 x 128 x 16, 4 waves, each 2 x 2 MFMA tiles.  LDS image per operand and stage: 3 planes x [2 k-chunks of 8][132 slots][16 B]
+// (slot = out ^ ((out >> 3) & 7); a ds_write_b128 is serviced in groups of 8 consecutive lanes over 32 banks, i.e. 4 rows x 2 k-chunks: the chunk stride
+// 132 = 4 mod 8 puts the two chunks of a row in different halves of the 128-byte bank window), two stages.  Per thread and k-tile:
 // 8 elements of A and 8 of B are split (about 44 VALU each, spread over the first MFMAs of the tile), 6 ds_write_b128, 12
 // ds_read_b128 (next tile's fragments, second register set), 24 MFMAs.  Global loads: reduction-contiguous operands 2 x 16 B per
 // thread (two lanes per row), [red][out] operands 8 dwords per thread (lane = out: no register transpose).  The buffer resources
@@ -783,14 +784,17 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(const GemmArgs g) {
 // tile that stages the last k-tile, and rows / outs beyond the extent only feed outputs that are never stored.
 // =====================================================================================================================
 constexpr int XK = 16;
-constexpr int X_CSTRIDE = 136;                       // 16-byte slots per 8-k chunk block
-constexpr int X_PLANE = 2 * X_CSTRIDE * 16;          // 4,352 B
-constexpr int X_IMG = 3 * X_PLANE;                   // 13,056 B per operand
-constexpr int X_STAGE = 2 * X_IMG;                   // 26,112 B
+#ifndef X3_CSTRIDE
+#define X3_CSTRIDE 132
+#endif
+constexpr int X_CSTRIDE = X3_CSTRIDE;               // 16-byte slots per 8-k chunk block (see the store-pattern note above)
+constexpr int X_PLANE = 2 * X_CSTRIDE * 16;          // 4,224 B
+constexpr int X_IMG = 3 * X_PLANE;                   // 12,672 B per operand
+constexpr int X_STAGE = 2 * X_IMG;                   // 25,344 B
 #ifndef X3_BARRIER_GAP
 #define X3_BARRIER_GAP 13
 #endif
-constexpr int X_LDS = BM * CP * 4;                   // 65,536 B: the epilogue transpose (>= 2 stages = 52,224 B) -> two workgroups per CU
+constexpr int X_LDS = BM * CP * 4;                   // 65,536 B: the epilogue transpose (>= 2 stages = 50,688 B) -> two workgroups per CU
 
 __device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ float bitsf(unsigned v) { return __builtin_bit_cast(float, v); }

@@ -99,6 +99,37 @@ t = timeit(rec)
 report("rollout_record_kernel (one workgroup)", n * 46, t, f"{n} envs")
 t = timeit(task.sim.simulate_and_refresh)
 report("kinematic_sim_kernel (physics stand-in)", n * (24 * 13 * 12 + 69 * 4 * 8), t, f"{n} envs")
+# ---- round 3: terrain / trajectory step (height-map gather), PULSE VAE head kernels, downstream-task step
+from pulse_amd._lib import TASK_OBS, TASK_REWARD, TASK_RESET  # noqa: E402
+try:
+    agent_t, _ = configs.make_agent("terrain_z", device=dev, seed=1, num_envs_override=4096)
+    agent_t.init_tensors()
+    agent_t.obs = agent_t.env_reset()
+    tt = agent_t.vec_env.env.task
+    nt = tt.num_envs
+    nh = tt.get_task_obs_size_detail()["heightmap"]
+    t = timeit(lambda: tt._task_step(TASK_OBS | TASK_REWARD | TASK_RESET))
+    # per env: bodies 1 248 + dof force / vel 552 + trajectory vertices 101 x 12 + three int16 cells per height point, task obs (20 + nh) x 4, reward 12, flags 16, progress 8
+    report("traj_step_kernel (trajectory samples + height map + reward + reset)", nt * (1248 + 552 + 101 * 12 + nh * 6 + (20 + nh) * 4 + 12 + 16 + 8), t, f"{nt} envs, {nh} height points")
+except Exception as e:                                           # keep the older rows if a config cannot be built
+    print("terrain_z skipped:", e)
+E, A, S_ = 32, 69, 358
+rows_v = 16384
+heads, pheads = torch.randn(rows_v, 2 * E, device=dev), torch.randn(rows_v, 2 * E, device=dev)
+eps, xin = torch.randn(rows_v, E, device=dev), torch.randn(rows_v, 960, device=dev)
+ain, cin = torch.zeros(rows_v, 392, device=dev), torch.zeros(rows_v, 392, device=dev)
+t = timeit(lambda: K.vae_embed(heads, xin, ain, rows=rows_v, embedding_size=E, self_obs_size=S_, z_col=360, eps=eps, cin=cin, clamp=True, clamp_max=2.0))
+report("vae_embed_kernel (re-parameterise + decoder / critic input rows)", rows_v * (2 * E * 4 + E * 4 + S_ * 4 + (S_ + E) * 4 + S_ * 4), t, f"{rows_v} rows")
+pred, gt, dmu = torch.randn(rows_v, 72, device=dev), torch.randn(rows_v, 72, device=dev), torch.zeros(rows_v, 72, device=dev)
+prog = (torch.arange(rows_v, device=dev) % 32).to(torch.int64)
+part = torch.zeros(256, 8, device=dev)
+t = timeit(lambda: K.vae_kin_loss(pred, gt, heads, pheads, prog, dmu, part, rows=rows_v, num_actions=A, embedding_size=E, horizon=32, clamp=True, clamp_max=2.0,
+                                  use_ar1=True, use_regu=True))
+report("vae_kin_loss_kernel (RMSE + KL vs learned prior + AR(1) + regulariser)", rows_v * (2 * A * 4 + 4 * E * 4 + 8 + A * 4), t, f"{rows_v} rows")
+dz, dzh, dph = torch.randn(rows_v, E, device=dev), torch.zeros(rows_v, 2 * E, device=dev), torch.zeros(rows_v, 2 * E, device=dev)
+t = timeit(lambda: K.vae_head_backward(heads, dzh, rows=rows_v, embedding_size=E, horizon=32, pheads=pheads, dpheads=dph, eps=eps, dz=dz, progress=prog, clamp=True,
+                                       clamp_max=2.0, c_kl=1e-4, c_ar1=1e-5, c_regu=1e-7))
+report("vae_head_backward_kernel", rows_v * (4 * E * 4 + 2 * E * 4 + 8 + 4 * E * 4), t, f"{rows_v} rows")
 print("| kernel | units per launch | algorithmic MB per launch | us per launch | GB/s | frac of 8 TB/s |")
 print("|---|---|---|---|---|---|")
 print("\n".join(rows))

@@ -304,3 +304,45 @@ def test_amp_obs_vs_golden(golden, dev):
     ops.build_amp_observations_smpl(rb, dp, dv, key, out=out, env_ids=ids)
     close(out[ids], g.np("amp_obs_full")[ids.cpu().numpy()])
     assert (out[0] == -1).all()
+
+
+def _yaw_translate(rb, ref_now, ref_next, yaw, shift):
+    """The same scene seen from a frame rotated by ``yaw`` (per env) about z and shifted in the ground plane."""
+    c, s = torch.cos(yaw), torch.sin(yaw)
+
+    def rot_v(v):                                                           # (n, J, 3)
+        return torch.stack([c[:, None] * v[..., 0] - s[:, None] * v[..., 1], s[:, None] * v[..., 0] + c[:, None] * v[..., 1], v[..., 2]], -1)
+
+    def rot_q(q):                                                           # qz (x) q, xyzw, qz = (0, 0, sin(yaw/2), cos(yaw/2))
+        hz, hw = torch.sin(yaw / 2)[:, None], torch.cos(yaw / 2)[:, None]
+        x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+        return torch.stack([hw * x - hz * y, hw * y + hz * x, hw * z + hz * w, hw * w - hz * z], -1)
+    rb2 = rb.clone()
+    rb2[..., 0:3] = rot_v(rb[..., 0:3]) + shift[:, None, :]
+    rb2[..., 3:7] = rot_q(rb[..., 3:7])
+    rb2[..., 7:10], rb2[..., 10:13] = rot_v(rb[..., 7:10]), rot_v(rb[..., 10:13])
+    tr = lambda r: {"pos": rot_v(r["pos"]) + shift[:, None, :], "rot": rot_q(r["rot"]), "vel": rot_v(r["vel"]), "ang": rot_v(r["ang"])}
+    return rb2, tr(ref_now), tr(ref_next)
+
+
+def test_fused_step_is_invariant_under_yaw_and_ground_translation_at_full_size(dev):
+    """Size-independent property at BASELINE.json's configs[1] width: every observation block is expressed in the root's heading frame
+    relative to the root (humanoid.py:1675-1731, humanoid_im.py:1328-1378), the reward and the termination test depend on differences
+    only (humanoid_im.py:1543-1628) -- so turning each env's whole scene (simulated bodies AND reference frames) about the vertical and
+    moving it over the ground must leave observations and rewards unchanged to rounding and the reset / terminate flags bit for bit."""
+    n = 4096
+    d = syn.env_step_inputs(syn.make_generator(4242), n)
+    g = torch.Generator().manual_seed(77)
+    yaw = (torch.rand(n, generator=g, dtype=torch.float64) * 2 - 1) * 3.1
+    shift = torch.cat([torch.randn(n, 2, generator=g, dtype=torch.float64) * 3.0, torch.zeros(n, 1, dtype=torch.float64)], -1)
+    dd = lambda r: {k: v.double() for k, v in r.items()}
+    rb2, rn2, rx2 = _yaw_translate(d["rb"].double(), dd(d["ref_now"]), dd(d["ref_next"]), yaw, shift)     # transformed in fp64, rounded once
+    d2 = dict(d, rb=rb2.float(), ref_now={k: v.float() for k, v in rn2.items()}, ref_next={k: v.float() for k, v in rx2.items()})
+    a, b = _run_full(d, dev), _run_full(d2, dev)
+    # inputs differ by one fp32 rounding of O(10) coordinates (~1e-6 absolute), amplified by the reward's exp(-100 x) at most ~1e-4 relative
+    assert (a["obs"] - b["obs"]).abs().max().item() <= 2e-4
+    assert (a["rew"] - b["rew"]).abs().max().item() <= 2e-4 and (a["rew_raw"] - b["rew_raw"]).abs().max().item() <= 2e-4
+    # the termination threshold is a strict compare on distances: identical except for envs within rounding of the 0.25 m threshold
+    differ = (a["terminate"] != b["terminate"]) | (a["reset"] != b["reset"])
+    assert int(differ.sum()) <= 2
+    assert a["obs"].abs().max().item() > 0.5                                 # (not trivially equal zeros)

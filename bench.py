@@ -308,7 +308,7 @@ def main():
                     "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in sel.items()}}
         r32 = roof(("fwd", "dx", "dw"), MFMA_F32_PEAK_TFLOPS, "gemm_f32_kernel")
         if r32 is None:
-            r32 = roof(("x3_fwd", "x3_dx", "x3_dw"), MFMA_X3_PEAK_TFLOPS, "gemm_x3_kernel")
+            r32 = roof(("x3_fwd", "x3_dx", "x3_dw", "x3p_fwd"), MFMA_X3_PEAK_TFLOPS, "gemm_x3_kernel")
             if r32 is not None:
                 r32["arithmetic"] = ("fp32 in / fp32 out; operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 per 16-deep k step, "
                                      "fp32 accumulation; peak = dense bf16 MFMA peak / 6; the fp32 MFMA's own ceiling is %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS)

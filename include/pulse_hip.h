@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 16
+#define PULSE_ABI_VERSION 17
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -620,6 +620,13 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
                         const double* mean, const double* var, float eps, float clip, int32_t mode,
                         float* y, int64_t y_stride, int32_t y_cols,
                         double* moment_partials, int32_t num_blocks, pulse_stream_t s);
+/* The same normalise pass (mode 0, wide-row form: 64 <= cols, 16-byte aligned rows) also writing the THREE bf16 planes of y (section 4b's
+ * operand format; planes[p * plane_stride + row * planes_ld + col], y_cols a multiple of 32, columns [cols, y_cols) zero) -- the
+ * layer-1 input of pulse_gemm_x3p split by its producer (same call site: RunningMeanStd.forward in _preproc_obs, common_agent.py:257-261). */
+int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols,
+                               const double* mean, const double* var, float eps, float clip,
+                               float* y, int64_t y_stride, int32_t y_cols, double* moment_partials, int32_t num_blocks,
+                               void* planes, int64_t plane_stride, int64_t planes_ld, pulse_stream_t s);
 /* _update_mean_var_count_from_moments, running_mean_std.py:56-67 (unbiased batch variance).
  * count_old is tracked by the host (it only ever grows by the batch size). */
 int pulse_rms_update(double* mean, double* var, double* count_out, const double* moment_partials, int32_t num_blocks,

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -270,6 +270,7 @@ SIGNATURES = {
     "pulse_reduce_slabs": (c_int, [P, c_int32, c_int64, c_int64, P, c_float, P]),
     "pulse_colsum_partial": (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, c_int64, P]),
     "pulse_rms_normalize": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, c_int32, P, c_int64, c_int32, P, c_int32, P]),
+    "pulse_rms_normalize_planes": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, P, c_int64, c_int32, P, c_int32, P, c_int64, c_int64, P]),
     "pulse_rms_update": (c_int, [P, P, P, P, c_int32, c_int32, c_double, c_double, P]),
     "pulse_policy_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int32, c_int32, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
     "pulse_sizeof_ppo_loss_args": (c_int, []),

@@ -73,18 +73,10 @@ struct XpGeom {
     static constexpr int LDS = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
 };
 
-__device__ __forceinline__ unsigned xp_pack_rn(float lo, float hi) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
-}
-__device__ __forceinline__ float xp_bitsf(unsigned v) { return __builtin_bit_cast(float, v); }
-// the three planes' packed dwords of an element pair (same rounding as StagerX::split_pair in gemm_f32.hip)
-__device__ __forceinline__ void xp_split_pair(float a, float b, unsigned& q0, unsigned& q1, unsigned& q2) {
-    q0 = xp_pack_rn(a, b);
-    const float ra = a - xp_bitsf(q0 << 16), rb = b - xp_bitsf(q0 & 0xffff0000u);
-    q1 = xp_pack_rn(ra, rb);
-    const float sa = ra - xp_bitsf(q1 << 16), sb = rb - xp_bitsf(q1 & 0xffff0000u);
-    q2 = xp_pack_rn(sa, sb);
-}
+__device__ __forceinline__ unsigned xp_pack_rn(float lo, float hi) { return split_pack_rn(lo, hi); }
+__device__ __forceinline__ float xp_bitsf(unsigned v) { return split_bitsf(v); }
+// the three planes' packed dwords of an element pair (same rounding as StagerX::split_pair in gemm_f32.hip; common.h)
+__device__ __forceinline__ void xp_split_pair(float a, float b, unsigned& q0, unsigned& q1, unsigned& q2) { split_pair3(a, b, q0, q1, q2); }
 
 __device__ __forceinline__ bf16x8 xp_lds128(int addr) {
     extern __shared__ __attribute__((aligned(16))) char xp_smem[];

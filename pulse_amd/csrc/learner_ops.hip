@@ -89,11 +89,15 @@ constexpr int kRmsVecGroups = 3;   // 256 threads x 4 columns x 3 groups = 3072 
 constexpr int kRmsRowsPerPass = 64;
 constexpr int kRmsRowsInFlight = 4;
 
+// PLANES: besides y, the three bf16 planes of every output element (common.h: split_pair3) go to planes[p * plane_stride + row * planes_ld + col]
+// -- the layer-1 operand of the planar GEMM (gemm_x3p.hip) written by its producer instead of a separate split pass.
+template <bool PLANES>
 __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,
                                                                 const double* __restrict__ mean, const double* __restrict__ var,
                                                                 float eps, float clip, int mode, float* __restrict__ y,
-                                                                long long y_stride, int y_cols, double* __restrict__ partials) {
+                                                                long long y_stride, int y_cols, double* __restrict__ partials,
+                                                                unsigned short* __restrict__ planes, long long plane_stride, long long planes_ld) {
     const int tid = threadIdx.x;
     const int nblk = gridDim.x;
     const int per = (rows + nblk - 1) / nblk;
@@ -152,6 +156,15 @@ __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __
                             }
                         }
                         *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+                        if constexpr (PLANES) {
+                            unsigned a0, a1, a2, b0, b1, b2;
+                            split_pair3(o[0], o[1], a0, a1, a2);
+                            split_pair3(o[2], o[3], b0, b1, b2);
+                            unsigned short* pr = planes + (long long)(rb + q + h) * planes_ld + c;
+                            *reinterpret_cast<uint2*>(pr) = make_uint2(a0, b0);
+                            *reinterpret_cast<uint2*>(pr + plane_stride) = make_uint2(a1, b1);
+                            *reinterpret_cast<uint2*>(pr + 2 * plane_stride) = make_uint2(a2, b2);
+                        }
                     }
                 }
             }
@@ -527,8 +540,9 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
                         (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                         x_stride >= ((cols + 3) & ~3);
     if (vec_ok)
-        hipLaunchKernelGGL(rms_normalize_vec4_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
+        hipLaunchKernelGGL(rms_normalize_vec4_kernel<false>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials,
+                           (unsigned short*)nullptr, 0LL, 0LL);
     else if (cols >= 64)
         hipLaunchKernelGGL(rms_normalize_wide_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
@@ -536,6 +550,27 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
         hipLaunchKernelGGL(rms_normalize_narrow_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
     return check_launch("pulse_rms_normalize");
+}
+
+int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols, const double* mean,
+                               const double* var, float eps, float clip, float* y, int64_t y_stride, int32_t y_cols, double* moment_partials,
+                               int32_t num_blocks, void* planes, int64_t plane_stride, int64_t planes_ld, pulse_stream_t s) {
+    PULSE_REQUIRE(rows >= 0 && cols >= 0, "pulse_rms_normalize_planes: negative size");
+    if (rows == 0 || cols == 0) return PULSE_OK;
+    PULSE_REQUIRE(x && y && mean && var && planes, "pulse_rms_normalize_planes: null pointer");
+    PULSE_REQUIRE(num_blocks >= 1, "pulse_rms_normalize_planes: num_blocks < 1");
+    PULSE_REQUIRE(y_cols >= cols && y_stride >= y_cols && x_stride >= cols, "pulse_rms_normalize_planes: bad pitches");
+    PULSE_REQUIRE(cols >= 64 && cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (y_stride % 4) == 0 && (y_cols % 4) == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && x_stride >= ((cols + 3) & ~3),
+                  "pulse_rms_normalize_planes: needs the wide-row form (64 <= cols <= %d, 16-byte aligned rows)", 256 * 4 * kRmsVecGroups);
+    // the planes cover the same y_cols columns as y (columns [cols, y_cols) are written as zeros: the GEMM's k padding)
+    PULSE_REQUIRE((y_cols % 32) == 0 && planes_ld >= y_cols && (planes_ld % 8) == 0 && (plane_stride % 8) == 0 && plane_stride >= (int64_t)rows * planes_ld &&
+                  (reinterpret_cast<uintptr_t>(planes) & 15) == 0,
+                  "pulse_rms_normalize_planes: y_cols must be a multiple of 32 (zero-padded k extent), planes rows 16-byte aligned and covering it");
+    hipLaunchKernelGGL(rms_normalize_vec4_kernel<true>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+                       (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
+                       reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
+    return check_launch("pulse_rms_normalize_planes");
 }
 
 int pulse_rms_update(double* mean, double* var, double* count_out, const double* moment_partials, int32_t num_blocks, int32_t cols,

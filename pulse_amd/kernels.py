@@ -154,11 +154,16 @@ class Plan:
     def call(self, name, *args):
         self.ops.append((1, getattr(_lib.load(), name), args, name))
 
+    def gemm_x3p(self, A, B, **kw):
+        self.ops.append((2,) + make_gemm_x3p_desc(A, B, **kw))
+
     def run(self, start=0, stop=None):
         st = _stream()
         for op in self.ops[start:stop]:
             if op[0] == 0:
                 launch_gemm(op[1], op[2], op[3], st)
+            elif op[0] == 2:
+                launch_gemm_x3p(op[1], op[2], op[3], st)
             else:
                 _lib.check(op[1](*op[2], st), op[3])
 
@@ -364,9 +369,19 @@ def colsum_partial(x, m, n, ld, num_chunks, partial, ld_partial, x_off=0, partia
 
 
 def rms_normalize(x, mean, var, *, rows, cols, x_stride, y, y_stride, y_cols=None, row_idx=None, eps=1e-5, clip=5.0,
-                  unnorm=False, moment_partials=None, num_blocks=None):
+                  unnorm=False, moment_partials=None, num_blocks=None, planes=None):
+    """``planes``: a (3, rows, pitch) int16 planes tensor that also receives the exact three-way bf16 split of y (layer-1 operand of gemm_x3p)."""
     if num_blocks is None:
         num_blocks = max(1, min(512, rows // 16)) if moment_partials is None else moment_partials.shape[0]
+    if planes is not None:
+        if unnorm:
+            raise ValueError("rms_normalize: planes go with the normalising direction only")
+        if planes.dtype != torch.int16 or planes.dim() != 3 or planes.shape[0] != 3 or planes.stride(2) != 1 or planes.shape[1] < rows or not planes.is_cuda:
+            raise TypeError("rms_normalize: planes must be a (3, >= rows, pitch) int16 CUDA tensor")
+        _lib.check(_lib.load().pulse_rms_normalize_planes(_p(x), x_stride, _p(row_idx), rows, cols, _p(mean), _p(var), eps, clip, _p(y), y_stride,
+                                                          cols if y_cols is None else y_cols, _p(moment_partials), num_blocks, planes.data_ptr(),
+                                                          planes.stride(0), planes.stride(1), _stream()), "pulse_rms_normalize_planes")
+        return
     _lib.check(_lib.load().pulse_rms_normalize(_p(x), x_stride, _p(row_idx), rows, cols, _p(mean), _p(var), eps, clip,
                                                1 if unnorm else 0, _p(y), y_stride, cols if y_cols is None else y_cols,
                                                _p(moment_partials), num_blocks, _stream()), "pulse_rms_normalize")

@@ -263,7 +263,10 @@ class CommonAgent:
 
     def _preproc_obs(self, obs_batch, ws, rows, row_idx=None):
         """running_mean_std(obs) written into the network's GEMM-ready input buffer."""
-        self.running_mean_std.forward(obs_batch, row_idx=row_idx, out=ws["x"], out_cols=self.model.in_pitch)
+        xp = ws.get("xp")                      # a model whose layer 1 runs on the planar GEMM: the normaliser also writes the operand's planes
+        self.running_mean_std.forward(obs_batch, row_idx=row_idx, out=ws["x"], out_cols=self.model.in_pitch, planes=xp)
+        if xp is not None:
+            ws["xp_fresh"] = True
         return ws["x"]
 
     def get_action_values(self, obs, slot=None):
@@ -484,10 +487,13 @@ class CommonAgent:
         net = self.model
         ws = net.workspace(mb, train=True)
         norm, live = self._obs_normalizer_for_update()
+        xp = ws.get("xp")         # layer 1 on the planar GEMM: the normaliser also writes the operand's planes (see _preproc_obs)
         if live is not None:      # AMPAgent: output from the frozen copy, live statistics still updated (one pass)
-            live.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch, norm_with=norm)
+            live.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch, norm_with=norm, planes=xp)
         else:
-            norm.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch)
+            norm.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch, planes=xp)
+        if xp is not None:
+            ws["xp_fresh"] = True
         net.forward(ws, mb)
         ap = net.a_pitch
         K.ppo_loss(mu=ws["mu"], mu_stride=ws["mu"].stride(0), value=ws["val"], value_stride=ws["val"].stride(0), logstd=net.sigma,

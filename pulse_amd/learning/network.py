@@ -22,6 +22,8 @@ MI355X-first layout (what differs from a stack of nn.Linear):
 """
 import math
 
+import os
+
 import torch
 
 from .. import kernels as K
@@ -64,6 +66,12 @@ class A2CNetwork:
         self.sigma = torch.zeros(self.actions_num, dtype=torch.float32, device=self.device)   # log-std, non-learned
         self._slabs = None
         self._ws = {}
+        # PULSE_L1_PLANAR=1: layer-1 forward on the planar GEMM (gemm_x3p.hip; same six-product arithmetic), its input planes written by the
+        # normaliser.  OFF by default -- measured in situ on cfg2 (A/B in one gpurun call): the GEMM itself gains 11 % (196.6 vs
+        # 176.1 TFLOP/s on the layer-1 forward), the 6 bytes of planes per element the normaliser writes beside its fp32 output and the weight
+        # re-split cost more: 79.7 vs 78.8 ms per epoch.
+        self.l1_planar = os.environ.get("PULSE_L1_PLANAR", "0") == "1" and K.F32_MODE == "x3"
+        self._w1p = None
         self.training = True
         self.mixed_precision = False      # True: the TRAINING forward / backward run on the bf16 MFMA (amp_agent.py:671 autocast); inference stays fp32
         self.reset_parameters()
@@ -212,6 +220,15 @@ class A2CNetwork:
             ws["z"] = [e(m, 2 * uu) for uu in u]
         ws["plan_fwd"] = self._plan_forward(ws, m, 0, 2)
         ws["plan_critic"] = self._plan_forward(ws, m, 1, 1)
+        if self.l1_planar:
+            # layer 1 on the planar GEMM (gemm_x3p.hip): the normaliser writes the three bf16 planes of its output next to the fp32 copy
+            # (ws['xp']; the caller raises ws['xp_fresh'] when it did), the weight planes are re-split in front of every pass
+            ws["xp"] = K.alloc_planes(m, self.in_dim, dev)
+            ws["xp_fresh"] = False
+            if self._w1p is None:
+                self._w1p = K.alloc_planes(2 * u[0], self.in_dim, dev)
+            ws["plan_fwd_planar"] = self._plan_forward(ws, m, 0, 2, planar=True)
+            ws["plan_critic_planar"] = self._plan_forward(ws, m, 1, 1, planar=True)
         if train:
             ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, bf16=True) if self.mixed_precision else ws["plan_fwd"]
             ws["dh"] = [e(m, 2 * uu) for uu in u]
@@ -228,14 +245,23 @@ class A2CNetwork:
         self._ws[key] = ws
         return ws
 
-    def _plan_forward(self, ws, m, n0, cnt, bf16=False):
+    def _plan_forward(self, ws, m, n0, cnt, bf16=False, planar=False):
         """nets n0 .. n0+cnt-1 (0 = actor, 1 = critic)."""
         u, f = self.units, self.flat
         pre = ws.get("z")
         p = K.Plan(bf16=bf16)
         for l, uu in enumerate(u):
             k = self.in_w[l]
-            if l == 0:   # both nets read the same input: one GEMM of N = cnt*u1
+            if l == 0 and planar:
+                wp, xp = self._w1p, ws["xp"]
+                # W1 of both nets is one contiguous (2 u1, in_pitch) matrix of the flat buffer: its planes are refreshed here, so no writer of
+                # the parameters (optimiser step, checkpoint load, broadcast, a test poking the flat buffer) can leave them stale
+                p.call("pulse_split_planes", f.data_ptr() + 4 * (self.w_off[0] + n0 * uu * k), k, cnt * uu, self.in_dim,
+                       wp.data_ptr() + 2 * n0 * uu * wp.stride(1), wp.stride(0), wp.stride(1), 0, None)
+                p.gemm_x3p(xp, wp, M=m, N=cnt * uu, K=self.in_dim, C=ws["h"][0], ldc=2 * uu, bias=f, activation=self.act,
+                           b_off=n0 * uu * wp.stride(1), bias_off=self.b_off[0] + n0 * uu, c_off=n0 * uu,
+                           C2=pre[0] if pre else None, ldc2=2 * uu, c2_off=n0 * uu)
+            elif l == 0:   # both nets read the same input: one GEMM of N = cnt*u1
                 p.gemm(ws["x"], f, ws["h"][0], M=m, N=cnt * uu, K=k, lda=k, ldb=k, ldc=2 * uu, bias=f, activation=self.act,
                        algo_k=self.in_dim, b_off=self.w_off[0] + n0 * uu * k, bias_off=self.b_off[0] + n0 * uu, c_off=n0 * uu,
                        C2=pre[0] if pre else None, ldc2=2 * uu, c2_off=n0 * uu)
@@ -254,11 +280,22 @@ class A2CNetwork:
 
     def forward(self, ws, m):
         """Actor + critic forward on the normalised input in ws['x'] -> ws['heads'] (mu | value)."""
+        if self._take_planes(ws):
+            ws["plan_fwd_planar"].run()
+            return
         (ws["plan_fwd_train"] if (self.training and "plan_fwd_train" in ws) else ws["plan_fwd"]).run()
+
+    def _take_planes(self, ws):
+        """True once per normaliser pass that also wrote ws['xp'] (the caller raised ws['xp_fresh']); anyone who fills ws['x'] by other
+        means gets the in-kernel-split path.  The bf16 training passes (mixed_precision) do not use the planes."""
+        fresh = ws.get("xp_fresh", False)
+        if fresh:
+            ws["xp_fresh"] = False
+        return fresh and not (self.training and self.mixed_precision)
 
     def eval_critic(self, ws, m):
         """Critic only (CommonAgent._eval_critic, common_agent.py:551-562) -> ws['val']."""
-        ws["plan_critic"].run()
+        (ws["plan_critic_planar"] if self._take_planes(ws) else ws["plan_critic"]).run()
 
     # ------------------------------------------------------------------ backward
     def _plan_backward(self, ws, m):

@@ -124,3 +124,69 @@ def test_x3p_batched(dev):
     for zb in range(2):
         want = a[:, zb * k:(zb + 1) * k].double() @ b[zb * n:(zb + 1) * n].double().t() + bias[zb * n:(zb + 1) * n].double()
         assert (c[:, zb * n:(zb + 1) * n].double() - want).abs().max().item() <= 3e-6 * want.abs().max().item()
+
+
+def test_normaliser_writes_the_exact_planes_of_its_output(dev):
+    """pulse_rms_normalize_planes: y as before, plus the three bf16 planes of y (pad columns zero) -- bit for bit what pulse_split_planes
+    makes of y, with and without the row gather and the moment partials."""
+    g = torch.Generator().manual_seed(5)
+    rows, cols, pitch = 300, 934, 960
+    x = (torch.randn(1000, 936, generator=g) * 3 + 1).to(dev)
+    mean = (torch.randn(cols, generator=g, dtype=torch.float64)).to(dev)
+    var = (torch.rand(cols, generator=g, dtype=torch.float64) + 0.1).to(dev)
+    idx = torch.randperm(1000, generator=g)[:rows].to(dev)
+    for row_idx, part in ((None, None), (idx, torch.zeros(16, 2, cols, dtype=torch.float64, device=dev))):
+        y0 = torch.full((rows, pitch), float("nan"), device=dev)
+        K.rms_normalize(x, mean, var, rows=rows, cols=cols, x_stride=936, y=y0, y_stride=pitch, y_cols=pitch, row_idx=row_idx, moment_partials=part)
+        p0 = part.clone() if part is not None else None
+        y1 = torch.full((rows, pitch), float("nan"), device=dev)
+        planes = torch.full((3, rows, pitch), 0x7fc0, dtype=torch.int16, device=dev)
+        K.rms_normalize(x, mean, var, rows=rows, cols=cols, x_stride=936, y=y1, y_stride=pitch, y_cols=pitch, row_idx=row_idx, moment_partials=part, planes=planes)
+        assert torch.equal(y0, y1)
+        assert torch.equal(planes, K.split_planes(y1))
+        assert torch.equal(K.join_planes(planes), y1)
+        if part is not None:
+            assert torch.equal(part, p0)
+
+
+def test_actor_critic_layer1_on_the_planar_kernel(dev, monkeypatch):
+    """A2CNetwork with layer 1 on the planar GEMM (PULSE_L1_PLANAR=1; the normaliser supplies the planes) against the same network on the
+    in-kernel-split kernel: same arithmetic, different accumulation grouping -- fp32-grade agreement; a caller who fills ws['x'] itself
+    falls back."""
+    from pulse_amd import configs as C
+    if K.F32_MODE != "x3":
+        pytest.skip("the planar kernel computes the x3 arithmetic (PULSE_GEMM_F32=mfma32 is set)")
+    monkeypatch.setenv("PULSE_L1_PLANAR", "1")
+    torch.manual_seed(3)
+    agent, _ = C.make_agent("cfg1", device="cuda:0", seed=11)
+    net = agent.model
+    assert net.l1_planar
+    agent.init_tensors()
+    obs = agent.env_reset()["obs"]
+    n = agent.num_actors
+    ws = net.workspace(n, train=False)
+    net.eval()
+    agent._preproc_obs(obs, ws, n)
+    assert ws["xp_fresh"] and torch.equal(K.join_planes(ws["xp"])[:, :net.in_pitch], ws["x"])
+    net.forward(ws, n)
+    assert not ws["xp_fresh"]                                           # consumed
+    planar = ws["heads"].clone()
+    h_planar = ws["h"][0].clone()
+    net.forward(ws, n)                                                  # no fresh planes: the in-kernel-split path on the same ws['x']
+    staged = ws["heads"].clone()
+    scale = ws["h"][0].abs().max().item()
+    assert (h_planar - ws["h"][0]).abs().max().item() <= 4e-6 * scale + 1e-6
+    assert (planar - staged).abs().max().item() <= 1e-5 * staged.abs().max().item() + 1e-6
+    # the weight planes follow the parameters without anyone being told: poke the flat buffer, run again
+    net.flat.mul_(0.5)
+    agent._preproc_obs(obs, ws, n)
+    net.forward(ws, n)
+    half = ws["heads"].clone()
+    net.forward(ws, n)
+    assert (half - ws["heads"]).abs().max().item() <= 1e-5 * ws["heads"].abs().max().item() + 1e-6
+    # critic-only pass
+    agent._preproc_obs(obs, ws, n)
+    net.eval_critic(ws, n)
+    v_planar = ws["val"].clone()
+    net.eval_critic(ws, n)
+    assert (v_planar - ws["val"]).abs().max().item() <= 1e-5 * ws["val"].abs().max().item() + 1e-6

@@ -1,0 +1,47 @@
+"""CPU: the build's guard against packed-fp32 VALU arithmetic (on gfx950 / ROCm 7.2 v_pk_mul_f32 / v_pk_add_f32 returned
+wrong values in the last wave quarter of the fused env step while another process ran MFMA kernels).  The library is compiled with the SLP and
+loop vectorisers off and csrc/build.py disassembles every object; here the detector is shown to see such instructions when they are there,
+and every object of the shipped library is shown to be free of them."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+from pulse_amd.csrc import build as B
+
+SRC = r"""
+#include <hip/hip_runtime.h>
+// four independent fp32 multiply-adds per thread on adjacent values: what the SLP vectoriser turns into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32
+__global__ void probe(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const float4 x = *reinterpret_cast<const float4*>(a + i), y = *reinterpret_cast<const float4*>(b + i);
+    float4 r;
+    r.x = x.x * y.x + x.y; r.y = x.y * y.y + x.z; r.z = x.z * y.z + x.w; r.w = x.w * y.w + x.x;
+    *reinterpret_cast<float4*>(c + i) = r;
+}
+"""
+
+
+def _compile(tmp_path, name, flags):
+    src, obj = tmp_path / f"{name}.hip", tmp_path / f"{name}.o"
+    src.write_text(SRC)
+    r = subprocess.run([B.hipcc(), "-x", "hip", f"--offload-arch={B.ARCH}", "-O3", "-c", str(src), "-o", str(obj)] + flags, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("hipcc cannot cross-compile here: " + r.stderr[-200:])
+    return str(obj)
+
+
+def test_detector_sees_packed_fp32_and_the_flags_remove_it(tmp_path):
+    with_vec = B.packed_f32_instructions(_compile(tmp_path, "vec", []))
+    without = B.packed_f32_instructions(_compile(tmp_path, "novec", list(B.NO_PACKED_F32)))
+    assert with_vec, "the default optimiser no longer packs this pattern: pick another probe, the detector is untested"
+    assert without == []
+
+
+def test_every_object_of_the_library_is_free_of_packed_fp32():
+    objs = sorted(glob.glob(os.path.join(os.path.dirname(B.__file__), "*.o")))
+    if not objs:
+        pytest.skip("objects not built in this checkout (the library was shipped prebuilt)")
+    bad = {os.path.basename(o): B.packed_f32_instructions(o)[:3] for o in objs}
+    assert all(not v for v in bad.values()), {k: v for k, v in bad.items() if v}

@@ -10,7 +10,6 @@ is newer than its object.
 import argparse
 import os
 import subprocess
-import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -21,7 +21,6 @@ import torch
 from .. import ops
 from .. import synthetic as syn
 from .._lib import PULSE_IM_SELF_OBS, TASK_OBS, TASK_RESET, TASK_REWARD
-from .humanoid_im import Box
 from .humanoid_z import HumanoidZ
 
 

@@ -8,8 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_SILU, EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG,
-                   GEMM_RED_CONTIG, GemmDesc, PpoLossArgs)
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, EPI_BIAS_ACT, GEMM_RED_CONTIG, GemmDesc, PpoLossArgs
 from .ops import _dev, _ptr, _stream
 
 ACTIVATIONS = {"None": ACT_NONE, "none": ACT_NONE, None: ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}

@@ -21,7 +21,7 @@ the three layouts of gemm_f32_kernel with the ReLU-mask epilogue; no autograd gr
 import torch
 
 from .. import kernels as K
-from .._lib import ACT_NONE, ACT_RELU, EPI_BIAS_ACT, EPI_RELU_GRAD, GEMM_OUT_CONTIG
+from .._lib import ACT_NONE, ACT_RELU, EPI_RELU_GRAD, GEMM_OUT_CONTIG
 from .graph import Linear, ParamBook, init_linear_, r4
 
 

@@ -27,7 +27,7 @@ import os
 import torch
 
 from .. import kernels as K
-from .._lib import (ACT_NONE, ACT_RELU, ACT_SILU, EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG, GEMM_RED_CONTIG)
+from .._lib import ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG
 
 
 def _r4(x):

@@ -22,7 +22,7 @@ weight carries the same column layout.  ``state_dict`` speaks the reference's na
 import torch
 
 from .. import kernels as K
-from .._lib import ACT_NONE, ACT_SILU, ACT_RELU
+from .._lib import ACT_NONE
 from .graph import Linear, MlpGraph, ParamBook, init_linear_, r4
 
 

@@ -523,7 +523,7 @@ int pulse_gemm_set_debug_buffer(long long* device_buffer);
 typedef struct pulse_gemm_x3p_desc {
     const void* A; int64_t a_plane_stride; int32_t lda;   /* planes of A(m, k); bf16 elements */
     const void* B; int64_t b_plane_stride; int32_t ldb;   /* planes of B(n, k) */
-    int32_t a_layout, b_layout;                           /* PULSE_GEMM_*_CONTIG (three planes: both reduction-contiguous) */
+    int32_t a_layout, b_layout;                           /* PULSE_GEMM_*_CONTIG: (red, red), (red, out) or (out, out) as in section 4 */
     float* C; int32_t ldc;                                /* optional fp32 output */
     void* Cp; int64_t c_plane_stride; int32_t ldcp;       /* optional: the output's own planes (columns [N, roundup8(N)) zero-filled) */
     float* C2; int32_t ldc2;                              /* optional pre-activation output (EPI_BIAS_ACT + SILU) */
@@ -538,7 +538,7 @@ typedef struct pulse_gemm_x3p_desc {
                                                              matrices (plane strides ignored), products accumulate in fp32, results leave
                                                              rounded to bf16 (bf16 autocast semantics; split-K slabs stay fp32), Cp is one
                                                              bf16 matrix.  [red][out] operands (a/b_layout OUT_CONTIG) are read through the
-                                                             LDS transposing load and exist in this mode only. */
+                                                             LDS transposing load in either mode. */
     int32_t aux_is_bf16;                                  /* aux points at a bf16 matrix (ldaux / stride_aux in bf16 elements) */
 } pulse_gemm_x3p_desc;
 int pulse_sizeof_gemm_x3p_desc(void);

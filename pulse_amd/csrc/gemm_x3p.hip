@@ -480,7 +480,6 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     const int npl = d->planes == 1 ? 1 : 3;
     const bool akc = d->a_layout == PULSE_GEMM_RED_CONTIG, bkc = d->b_layout == PULSE_GEMM_RED_CONTIG;
     PULSE_REQUIRE(akc == bkc || (akc && !bkc), "pulse_gemm_x3p: layout combination (A out-contiguous, B reduction-contiguous) unsupported");
-    PULSE_REQUIRE((akc && bkc) || npl == 1, "pulse_gemm_x3p: [red][out] operands are built for the single-plane (bf16) mode only");
     PULSE_REQUIRE((d->lda % 8) == 0 && (d->ldb % 8) == 0 && (d->a_plane_stride % 8) == 0 && (d->b_plane_stride % 8) == 0 &&
                   (d->stride_a % 8) == 0 && (d->stride_b % 8) == 0, "pulse_gemm_x3p: operand pitches / strides must be multiples of 8 elements");
     PULSE_REQUIRE((reinterpret_cast<uintptr_t>(d->A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->B) & 15) == 0, "pulse_gemm_x3p: A / B must be 16-byte aligned");
@@ -546,8 +545,12 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
         }                                                                                                                                       \
         hipLaunchKernelGGL((gemm_x3p_kernel<AK, BK_, W, NP>), grid, dim3(128 * W), lds, as_stream(s), g);                                       \
     } while (0)
-    if (npl == 3) {
+    if (npl == 3 && akc && bkc) {
         if (big) PULSE_XP_LAUNCH(true, true, 4, 3, 0); else PULSE_XP_LAUNCH(true, true, 2, 3, 1);
+    } else if (npl == 3 && akc) {
+        if (big) PULSE_XP_LAUNCH(true, false, 4, 3, 8); else PULSE_XP_LAUNCH(true, false, 2, 3, 9);
+    } else if (npl == 3) {
+        if (big) PULSE_XP_LAUNCH(false, false, 4, 3, 10); else PULSE_XP_LAUNCH(false, false, 2, 3, 11);
     } else if (akc && bkc) {
         if (big) PULSE_XP_LAUNCH(true, true, 4, 1, 2); else PULSE_XP_LAUNCH(true, true, 2, 1, 3);
     } else if (akc) {

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from pulse_amd import kernels as K
-from pulse_amd._lib import ACT_NONE, ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD
+from pulse_amd._lib import ACT_NONE, ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG
 
 pytestmark = pytest.mark.gpu
 
@@ -190,3 +190,31 @@ def test_actor_critic_layer1_on_the_planar_kernel(dev, monkeypatch):
     v_planar = ws["val"].clone()
     net.eval_critic(ws, n)
     assert (v_planar - ws["val"]).abs().max().item() <= 1e-5 * ws["val"].abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("rows,m,n,split", [(96, 256, 128, 1), (1000, 300, 200, 1), (16384, 2048, 934, 8), (4099, 515, 129, 4)])
+def test_x3p_weight_gradient_form_three_planes(dev, rows, m, n, split):
+    """dW(m, n) = sum_r dZ(r, m) X(r, n) over row-major planes (both operands [red][out], transposing LDS reads): fp32-grade."""
+    g = torch.Generator().manual_seed(rows + m)
+    dz, x = torch.randn(rows, m, generator=g).to(dev), torch.randn(rows, n, generator=g).to(dev)
+    ldc = (n + 3) // 4 * 4
+    pstride = (m * ldc + 1023) // 1024 * 1024
+    slabs = torch.full((split, pstride), float("nan"), device=dev)
+    K.gemm_x3p(K.split_planes(dz), K.split_planes(x), M=m, N=n, K=rows, C=slabs, ldc=ldc, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
+               split_k=split, split_stride=pstride)
+    got = slabs[:, :m * ldc].view(split, m, ldc)[:, :, :n].double().sum(0)
+    want = dz.double().t() @ x.double()
+    assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 200, 100), (16384, 1024, 512), (515, 129, 33)])
+def test_x3p_input_gradient_form_three_planes(dev, m, n, k):
+    """C(m, n) = sum_k A(m, k) W(k, n), W a [red][out] operand, ReLU mask from the bf16 plane 0 of the activations."""
+    g = torch.Generator().manual_seed(m + n)
+    a, w, h = torch.randn(m, k, generator=g).to(dev), (torch.randn(k, n, generator=g) * 0.05).to(dev), torch.randn(m, n, generator=g).to(dev)
+    ph = K.split_planes(h)
+    c = torch.empty(m, (n + 3) // 4 * 4, device=dev)
+    K.gemm_x3p(K.split_planes(a), K.split_planes(w), M=m, N=n, K=k, C=c, ldc=c.stride(0), b_layout=GEMM_OUT_CONTIG, epilogue=EPI_RELU_GRAD,
+               aux=ph[0], ldaux=ph.stride(1))
+    want = (a.double() @ w.double()) * (h > 0)                             # sign(h) == sign(bf16(h)) unless h rounds to zero (never here)
+    assert (c[:, :n].double() - want).abs().max().item() <= 2e-6 * want.abs().max().item() + 1e-6

@@ -140,7 +140,9 @@ def test_b16_rejects_bad_geometry(dev):
     c = torch.empty(64, 64, device=dev)
     with pytest.raises(RuntimeError, match="layout combination"):
         K.gemm_x3p(a, b, M=64, N=64, K=64, C=c, ldc=64, planes=1, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_RED_CONTIG)
-    with pytest.raises(RuntimeError, match="single-plane"):
-        K.gemm_x3p(K.alloc_planes(64, 64, dev), K.alloc_planes(64, 64, dev), M=64, N=64, K=64, C=c, ldc=64, b_layout=GEMM_OUT_CONTIG)
+    with pytest.raises(RuntimeError, match="planes must be"):
+        d, flops, tag = K.make_gemm_x3p_desc(a, b, M=64, N=64, K=64, C=c, ldc=64, planes=1)
+        d.planes = 2
+        K.launch_gemm_x3p(d, flops, tag)
     with pytest.raises(RuntimeError, match="split-K"):
         K.gemm_x3p(a, b, M=64, N=64, K=64, C=c, ldc=64, planes=1, split_k=2, split_stride=4096)

@@ -40,17 +40,24 @@ __device__ __forceinline__ V3 traj_pos(const float* verts, int num_verts, float 
     return V3{a * p0[0] + lerp * p1[0], a * p0[1] + lerp * p1[1], a * p0[2] + lerp * p1[2]};
 }
 
-__device__ __forceinline__ float sample_height(const pulse_traj_step_args& a, float wx, float wy) {
-    // world_points_to_map: (points / horizontal_scale).long() truncates toward zero, then clip to [0, size - 2]
+// world_points_to_map: (points / horizontal_scale).long() truncates toward zero, then clip to [0, size - 2]; the two cells get_heights compares
+__device__ __forceinline__ void height_cells(const pulse_traj_step_args& a, float wx, float wy, long long& c1, long long& c2) {
     long long px = (long long)(wx / a.horizontal_scale), py = (long long)(wy / a.horizontal_scale);
     px = px < 0 ? 0 : (px > a.map_rows - 2 ? a.map_rows - 2 : px);
     py = py < 0 ? 0 : (py > a.map_cols - 2 ? a.map_cols - 2 : py);
-    const short h1 = a.heightsamples[px * a.map_cols + py], h2 = a.heightsamples[(px + 1) * a.map_cols + py + 1];
+    c1 = px * a.map_cols + py;
+    c2 = (px + 1) * a.map_cols + py + 1;
+}
+__device__ __forceinline__ float sample_height(const pulse_traj_step_args& a, float wx, float wy) {
+    long long c1, c2;
+    height_cells(a, wx, wy, c1, c2);
+    const short h1 = a.heightsamples[c1], h2 = a.heightsamples[c2];
     return (float)(h1 < h2 ? h1 : h2) * a.vertical_scale;
 }
 
 __global__ void __launch_bounds__(256) traj_step_kernel(const pulse_traj_step_args a) {
     __shared__ float s_center;
+    __shared__ float s_cpt[256];
     __shared__ float s_red[4][4];
     const int count = a.env_ids ? a.num_ids : a.num_envs;
     const int idx = blockIdx.x;
@@ -82,16 +89,21 @@ __global__ void __launch_bounds__(256) traj_step_kernel(const pulse_traj_step_ar
                     ho[p] = fminf(fmaxf(ref - 0.0f, -3.0f), 3.0f) * a.height_meas_scale;
                 }
             } else {
-                if (a.use_center_height && tid == 0) {
-                    // get_center_heights: 3 x 3 grid under the root, rotated by the root's yaw-only quaternion (quat_apply_yaw)
-                    const float n = fmaxf(sqrtf(root_q.z * root_q.z + root_q.w * root_q.w), 1e-9f);
-                    const Q4 qy{0.0f / n, 0.0f / n, root_q.z / n, root_q.w / n};
-                    float sum = 0.0f;
-                    for (int c = 0; c < a.num_center_points; ++c) {
-                        const V3 w = q_apply(qy, V3{a.center_points[2 * c], a.center_points[2 * c + 1], 0.0f});
-                        sum += sample_height(a, w.x + root_p.x, w.y + root_p.y);
+                if (a.use_center_height) {
+                    // get_center_heights: 3 x 3 grid under the root, rotated by the root's yaw-only quaternion (quat_apply_yaw).  One thread per
+                    // point (their dependent gathers overlap), summed by thread 0 in the reference's order
+                    if (tid < a.num_center_points) {
+                        const float n = fmaxf(sqrtf(root_q.z * root_q.z + root_q.w * root_q.w), 1e-9f);
+                        const Q4 qy{0.0f / n, 0.0f / n, root_q.z / n, root_q.w / n};
+                        const V3 w = q_apply(qy, V3{a.center_points[2 * tid], a.center_points[2 * tid + 1], 0.0f});
+                        s_cpt[tid] = sample_height(a, w.x + root_p.x, w.y + root_p.y);
                     }
-                    s_center = sum / (float)a.num_center_points;
+                    __syncthreads();
+                    if (tid == 0) {
+                        float sum = 0.0f;
+                        for (int c = 0; c < a.num_center_points; ++c) sum += s_cpt[c];
+                        s_center = sum / (float)a.num_center_points;
+                    }
                 }
                 __syncthreads();
                 // get_heights: the sensor grid rotated by the HEADING of the sensor body (terrain_obs_root: head) and moved to it
@@ -100,10 +112,26 @@ __global__ void __launch_bounds__(256) traj_step_kernel(const pulse_traj_step_ar
                 if (!a.upright_start) sq = qmul(sq, Q4{-0.5f, -0.5f, -0.5f, 0.5f});
                 const Q4 hq = heading_quat(sq, false);
                 const float ref = a.use_center_height ? s_center : root_p.z;
-                for (int p = tid; p < a.num_height_points; p += 256) {
-                    const V3 w = q_apply(hq, V3{a.height_points[2 * p], a.height_points[2 * p + 1], 0.0f});
-                    const float h = sample_height(a, w.x + sb[0], w.y + sb[1]);
-                    ho[p] = fminf(fmaxf(ref - h, -3.0f), 3.0f) * a.height_meas_scale;
+                // four points per thread and pass, their cell indices first and their eight gathers together: the gathers' latencies overlap
+                for (int p0 = tid; p0 < a.num_height_points; p0 += 1024) {
+                    long long i1[4], i2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int p = min(p0 + 256 * i, a.num_height_points - 1);
+                        const V3 w = q_apply(hq, V3{a.height_points[2 * p], a.height_points[2 * p + 1], 0.0f});
+                        height_cells(a, w.x + sb[0], w.y + sb[1], i1[i], i2[i]);
+                    }
+                    short h1[4], h2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { h1[i] = a.heightsamples[i1[i]]; h2[i] = a.heightsamples[i2[i]]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int p = p0 + 256 * i;
+                        if (p < a.num_height_points) {
+                            const float h = (float)(h1[i] < h2[i] ? h1[i] : h2[i]) * a.vertical_scale;
+                            ho[p] = fminf(fmaxf(ref - h, -3.0f), 3.0f) * a.height_meas_scale;
+                        }
+                    }
                 }
             }
         }
@@ -231,7 +259,8 @@ int pulse_traj_step(const pulse_traj_step_args* args, pulse_stream_t s) {
         if (a.num_height_points > 0) {
             PULSE_REQUIRE(a.height_points && a.sensor_body >= 0 && a.sensor_body < a.num_bodies, "pulse_traj_step: height sensor needs its grid and a body");
             PULSE_REQUIRE(!a.heightsamples || (a.map_rows >= 2 && a.map_cols >= 2 && a.horizontal_scale > 0.f), "pulse_traj_step: bad height field");
-            PULSE_REQUIRE(!a.use_center_height || !a.heightsamples || (a.center_points && a.num_center_points >= 1), "pulse_traj_step: use_center_height needs the centre grid");
+            PULSE_REQUIRE(!a.use_center_height || !a.heightsamples || (a.center_points && a.num_center_points >= 1 && a.num_center_points <= 256),
+                          "pulse_traj_step: use_center_height needs the centre grid (1 .. 256 points)");
         }
     }
     if (a.what & PULSE_TASK_REWARD) {

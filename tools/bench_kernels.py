@@ -99,6 +99,20 @@ t = timeit(rec)
 report("rollout_record_kernel (one workgroup)", n * 46, t, f"{n} envs")
 t = timeit(task.sim.simulate_and_refresh)
 report("kinematic_sim_kernel (physics stand-in)", n * (24 * 13 * 12 + 69 * 4 * 8), t, f"{n} envs")
+# ---- the fused env step over recorded reference frames at 8 x cfg2's width: time per env when every CU has 16 workgroups to run
+# (it scales linearly from 4096 envs: the kernel is bound by its own instruction stream -- ~12 us per wave of two envs --, not by HBM)
+from pulse_amd import synthetic as syn  # noqa: E402
+for n_big in (32768,):                                           # (at 4096 envs this Python wrapper, not the kernel, sets the pace of back-to-back launches)
+    d = syn.env_step_inputs(syn.make_generator(5), n_big)
+    to = lambda x: x.to(dev)
+    rbb = to(d["rb"])
+    rn, rx = {k: to(v) for k, v in d["ref_now"].items()}, {k: to(v) for k, v in d["ref_next"].items()}
+    kw = dict(what=full, ref_now=rn, ref_next=rx, dof_force=to(d["dof_force"]), dof_vel=to(d["dof_vel"]), progress=to(d["progress"]), pass_time=to(d["pass_time"]),
+              track_ids=list(range(24)), reset_ids=syn.RESET_BODY_IDS, term_dist=torch.full((24,), 0.25, device=dev),
+              obs=torch.zeros(n_big, 960, device=dev), obs_cols=960, rew=torch.zeros(n_big, device=dev), rew_raw=torch.zeros(n_big, 5, device=dev),
+              reset=torch.zeros(n_big, dtype=torch.int64, device=dev), terminate=torch.zeros(n_big, dtype=torch.int64, device=dev))
+    t = timeit(lambda: ops.im_step(rbb, **kw))
+    report("im_step_kernel (recorded reference frames, reward+reset+obs)", n_big * 8080, t, f"{n_big} envs (SURVEY 8d: 8 080 B per env-step)")
 # ---- round 3: terrain / trajectory step (height-map gather), PULSE VAE head kernels, downstream-task step
 from pulse_amd._lib import TASK_OBS, TASK_REWARD, TASK_RESET  # noqa: E402
 try:

@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(root, "p*", "**", "*kernel_trace.csv"), recursiv
         dur[key].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 print("# SQ / GRBM counters per kernel launch (mean over launches 2..), rocprofv3 --pmc, MI355X")
 for key in sorted(acc):
-    if "gemm" not in key[0]:
+    if not any(w in key[0] for w in os.environ.get("PMC_KERNEL_FILTER", "gemm").split()):
         continue
     c = {k: sum(v[1:]) / max(1, len(v[1:])) if len(v) > 1 else v[0] for k, v in acc[key].items()}
     d = sorted(dur.get(key, [0.0]))

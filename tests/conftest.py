@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built library (artefacts are git-ignored): build it once (hipcc cross-compiles without a GPU) so the ABI tests
+    and everything behind pulse_amd._lib can load it.  A present library is left alone -- the GPU box runs the one that travelled with the tree."""
+    from pulse_amd import _lib
+    if os.path.exists(_lib.LIB_PATH) or os.environ.get("PULSE_HIP_LIB"):
+        return
+    try:
+        from pulse_amd.csrc import build
+        build.build()
+    except Exception as exc:                                     # the tests that need the library will say so themselves
+        print(f"[conftest] could not build libpulse_hip.so: {exc}")
+
+
 def pytest_collection_modifyitems(config, items):
     if torch.cuda.is_available():
         return

@@ -108,6 +108,7 @@ class HumanoidIm:
         # ---- buffers (base_task.py:98-104)
         n, dev = self.num_envs, self.device
         self._obs_store = torch.zeros(n, self.obs_pitch, device=dev)
+        self._im_launch_cache = {}                      # per phase: the filled pulse_im_step argument struct (ops.im_step cache=)
         self.obs_buf = self._obs_store[:, :self.num_obs]
         self.rew_buf = torch.zeros(n, device=dev)
         self.reward_raw = torch.zeros(n, 5 if self.power_reward else 4, device=dev)
@@ -367,8 +368,10 @@ class HumanoidIm:
         rc = self._recovery_counter_for_step()
         if rc is not None:
             extra["recovery_counter"] = rc
+        # the step and the masked-reset launch repeat with the same buffers every control step: their argument structs are cached per phase
+        cache = self._im_launch_cache.setdefault((what, inc, env_ids is None, env_mask is None), {})
         return ops.im_step(
-            rb, what=what, ref_now=ref_now, ref_next=ref_next, upright=self._has_upright_start,
+            rb, cache=cache, what=what, ref_now=ref_now, ref_next=ref_next, upright=self._has_upright_start,
             enable_early_termination=self._enable_early_termination, self_obs_version=self.self_obs_v, **extra,
             time_steps=self._num_traj_samples, dof_force=self.sim.dof_force, dof_vel=self.sim.dof_vel,
             progress=self.progress_buf, pass_time=self._pass_time, cycle_counter=self._cycle_counter,

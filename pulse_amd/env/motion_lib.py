@@ -125,6 +125,11 @@ class MotionLib:
         return ((phase * motion_len) / curr_fps).long() * curr_fps
 
     # ---- the hot query
+    def launch_signature(self):
+        """Identity of the device tables a cached launch points at (ops._launch_sig)."""
+        return (id(self), self.frames.data_ptr(), self._motion_lengths.data_ptr(), self._motion_dt.data_ptr(), self._motion_num_frames.data_ptr(),
+                self.length_starts.data_ptr(), self._num_motions)
+
     def fill_tables(self, t):
         """Fill a pulse_motion_tables struct (by reference) with this library's device pointers."""
         t.frames, t.frame_stride, t.total_frames, t.num_bodies = self.frames.data_ptr(), self.frame_stride, self.frames.shape[0], self.num_bodies

@@ -198,11 +198,11 @@ _IM_DEBUG_BITS = 0x80000000 if os.environ.get("PULSE_IM_DEBUG_POISON_LDS") == "1
 
 def _launch_sig(o):
     """Cheap identity of a launch's arguments: device pointers of tensors, values of scalars / id lists, recursively through dicts.  Two calls
-    with equal signatures launch the same kernel on the same buffers (shapes and strides are taken to be fixed per buffer address)."""
+    with equal signatures launch the same kernel on the same buffers (a buffer's layout is taken to be fixed by its address and element count)."""
     if o is None:
         return 0
     if isinstance(o, torch.Tensor):
-        return o.data_ptr()
+        return (o.data_ptr(), o.numel())            # (the caching allocator may hand a freed address to a tensor of another size)
     if isinstance(o, dict):
         return tuple((k, _launch_sig(v)) for k, v in o.items())
     if isinstance(o, (list, tuple)):

@@ -346,3 +346,49 @@ def test_fused_step_is_invariant_under_yaw_and_ground_translation_at_full_size(d
     differ = (a["terminate"] != b["terminate"]) | (a["reset"] != b["reset"])
     assert int(differ.sum()) <= 2
     assert a["obs"].abs().max().item() > 0.5                                 # (not trivially equal zeros)
+
+
+def test_im_step_launch_cache_replays_only_identical_launches(dev):
+    """ops.im_step(cache=...): the filled argument struct is replayed while the arguments' signature (device pointers, element counts,
+    scalars) is unchanged; a swapped buffer, another flag or an argument that needed a converted temporary goes through the full path."""
+    n = 300
+    d = syn.env_step_inputs(syn.make_generator(21), n)
+    to = lambda x: x.to(dev)
+    rb = to(d["rb"])
+    rn, rx = {k: to(v) for k, v in d["ref_now"].items()}, {k: to(v) for k, v in d["ref_next"].items()}
+    outs = dict(obs=torch.zeros(n, 960, device=dev), obs_cols=960, rew=torch.zeros(n, device=dev), rew_raw=torch.zeros(n, 5, device=dev),
+                reset=torch.zeros(n, dtype=torch.int64, device=dev), terminate=torch.zeros(n, dtype=torch.int64, device=dev))
+    kw = dict(what=ALL, ref_now=rn, ref_next=rx, dof_force=to(d["dof_force"]), dof_vel=to(d["dof_vel"]), progress=to(d["progress"]), pass_time=to(d["pass_time"]),
+              track_ids=list(range(24)), reset_ids=syn.RESET_BODY_IDS, term_dist=torch.full((24,), 0.25, device=dev), **outs)
+    ref = {k: v.clone() for k, v in ops.im_step(rb, **kw).items()}
+    cache = {}
+    ops.im_step(rb, cache=cache, **kw)
+    assert "args" in cache                                               # caller-owned outputs, nothing converted: cached
+    args0 = cache["args"]
+    # the content of the buffers may change between replays (that is the point): new state, same addresses
+    rb.add_(0.01)
+    want = {k: v.clone() for k, v in ops.im_step(rb.clone(), **kw).items()}
+    got = ops.im_step(rb, cache=cache, **kw)
+    assert cache["args"] is args0                                        # replayed
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert not torch.equal(got["obs"], ref["obs"])
+    # another rigid-body buffer: signature differs, the struct is rebuilt
+    rb2 = rb.clone()
+    ops.im_step(rb2, cache=cache, **kw)
+    assert cache["args"] is not args0
+    # a flag changes
+    args1 = cache["args"]
+    ops.im_step(rb2, cache=cache, **dict(kw, power_reward=False, rew_raw=torch.zeros(n, 4, device=dev)))
+    assert cache["args"] is not args1
+    # outputs allocated by the wrapper: never cached
+    c2 = {}
+    ops.im_step(rb, cache=c2, **{k: v for k, v in kw.items() if k not in outs})
+    assert "args" not in c2
+    # an argument that needs a contiguous temporary: never cached (a replay would read the stale copy)
+    c3 = {}
+    wide = torch.zeros(n, 2, device=dev)
+    wide[:, 0] = 1.0
+    prog_nc = torch.stack([to(d["progress"]), to(d["progress"])], 1)[:, 0]             # stride 2
+    ops.im_step(rb, cache=c3, **dict(kw, progress=prog_nc))
+    assert "args" not in c3

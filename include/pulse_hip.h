@@ -420,7 +420,7 @@ typedef struct pulse_traj_step_args {
        heightsamples NULL = terrainType 'plane' (zero heights); num_height_points 0 = no terrain observation (HumanoidTraj). */
     const int16_t* heightsamples; int32_t map_rows, map_cols; float horizontal_scale, vertical_scale;
     const float* height_points; int32_t num_height_points; int32_t sensor_body;
-    const float* center_points; int32_t num_center_points; int32_t use_center_height; float height_meas_scale;
+    const float* center_points; int32_t num_center_points; int32_t use_center_height; float height_meas_scale;   /* centre grid: 1 .. 256 points */
     /* reward */
     const float* dof_force; const float* dof_vel; int32_t num_dof; float power_coef; int32_t power_reward; int32_t fuzzy_target;
     /* reset */

@@ -419,7 +419,7 @@ class AMPAgent(CommonAgent):
                 task.kld_coefficient = (0.01 - mn) * max((5000 - self.epoch_num) / 2500, 0) + mn
             info["kin_kld_w"] = task.kld_coefficient
         # ---- backward through the GEMM plans; the head-level gradients join at the encoder / prior heads
-        model.book.slabs.zero_()
+        model.book.zero_slab_ranges(model._untouched(ws, ("dec", "enc", "prior")))     # the critic's slabs (PPO pass) must read as zero
         model.backward_actor(ws, kin={"c_kl": kld_w / mb, "c_ar1": (task.ar1_coefficient / n_err) if use_ar1 else 0.0,
                                       "c_regu": (0.005 * 0.001 / (mb * E)) if use_regu else 0.0, "progress": prog, "horizon": t})
         model.backward_prior(ws)

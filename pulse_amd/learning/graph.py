@@ -92,6 +92,14 @@ class ParamBook:
         else:
             v[:, :p.cols] = value
 
+    def zero_slab_ranges(self, ranges):
+        """Zero the gradient slabs of the flat ranges [(lo, hi), ...] (all S slabs): the sub-networks a backward pass does NOT visit, whose
+        slabs still hold another pass's gradients.  The visited ones are overwritten by their weight-gradient GEMMs; zeroing all S x n_flat
+        floats per minibatch instead was 1.3 % of the cfg3 epoch."""
+        for lo, hi in ranges:
+            if hi > lo:
+                self.slabs[:, lo:hi].zero_()
+
     def reduce_grads(self, scale=1.0):
         K.reduce_slabs(self.slabs, self.split_k, self.n_flat, self.n_flat, self.grad, scale=scale)
         return self.grad
@@ -191,6 +199,24 @@ class MlpGraph:
             self.linear(lin, cur, final_dst, dst_col=final_dst_col, grad_ranges=[(0, cur_w, prev_act, prev_aux, 0)], tag=tag)
             lins.append(lin)
         return lins
+
+    def untouched_ranges(self, tags):
+        """Flat parameter ranges (merged, sorted) of the ops whose tag is NOT in ``tags``."""
+        spans = []
+        for op in self.ops:
+            if op["tag"] in tags:
+                continue
+            lin = op["lin"]
+            spans.append((lin.w.off, lin.w.off + lin.w.rows * lin.w.pitch))
+            spans.append((lin.b.off, lin.b.off + lin.b.rows * lin.b.pitch))
+        spans.sort()
+        merged = []
+        for lo, hi in spans:
+            if merged and lo <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], hi))
+            else:
+                merged.append((lo, hi))
+        return merged
 
     # ---- plans -----------------------------------------------------------------------------------------
     def forward_plan(self, tags=None, store_pre=True):

@@ -121,7 +121,13 @@ class AMPZModel:
 
     def backward(self, ws, m, grad_scale=1.0):
         """PPO backward: actor (through the VAE) + critic; weight gradients of untouched sub-nets stay zero."""
-        self.book.slabs.zero_()
+        self.book.zero_slab_ranges(self._untouched(ws, ("dec", "enc", "critic", "critic_z")))      # the prior's slabs (kin pass) must read as zero
         self.backward_actor(ws)
         ws["G"]["bwd_critic"].run()
         return self.book.reduce_grads(grad_scale)
+
+    def _untouched(self, ws, tags):
+        key = ("untouched",) + tuple(tags)
+        if key not in ws:
+            ws[key] = ws["g"].untouched_ranges(set(tags))
+        return ws[key]

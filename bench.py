@@ -194,24 +194,112 @@ def cpu_baseline(cfg_name, seed, sample_steps, n_minibatches, budget_s, referenc
         return {"value": None, "unit": "env-steps/s", "cores": None, "kind": "port", "sample": f"worker exceeded its {budget_s} s budget"}
 
 
+def workload_suffix(cfg):
+    """The parts of a config beyond plain PPO, spelled out in config.workload (BASELINE.json configs[2] / [4])."""
+    parts = []
+    net = cfg["network"]
+    if cfg.get("enable_disc"):
+        parts.append(f"AMP discriminator MLP {net['disc']['units']} on 10-step AMP observations (amp_minibatch {cfg['amp_minibatch_size']}, "
+                     f"demo + replay rings {cfg['amp_obs_demo_buffer_size']} rows, disc reward mixed {cfg['disc_reward_w']}/{cfg['task_reward_w']})")
+    if net.get("name") == "amp_z":
+        parts.append(f"PULSE VAE encoder/decoder policy head (network amp_z, latent 32, task MLP {net['task_mlp']['units']})"
+                     + (", distillation (kin) loss only" if cfg.get("_env_kind") == "vae" else ""))
+    if cfg.get("mixed_precision"):
+        parts.append("mixed_precision: training GEMMs on the bf16 MFMA over fp32 master weights")
+    return (" + " + " + ".join(parts)) if parts else ""
+
+
+def launch_plan(gpus, env):
+    """What a `bench.py --gpus N` process has to do, from its arguments and environment alone (no torch; unit-tested on CPU).
+
+    The reference turns multi-GPU on with one config flag (im.yaml:49 `multi_gpu`, common_agent.py:112-127) and expects one
+    process per GPU to exist already (horovodrun); the driver's command is plain `python bench.py --gpus N`.  So:
+      * WORLD_SIZE set (a launcher started us): it must equal --gpus, otherwise refuse -- never print n_gpus != --gpus;
+      * WORLD_SIZE unset and --gpus 1: run in this process;
+      * WORLD_SIZE unset and --gpus N > 1: this process becomes the launcher of N rank processes (self_launch)."""
+    if gpus < 1:
+        return {"action": "refuse", "why": f"--gpus {gpus}"}
+    ws = env.get("WORLD_SIZE")
+    if ws is None:
+        if gpus == 1:
+            return {"action": "run", "world": 1, "rank": 0, "local_rank": 0}
+        return {"action": "spawn", "world": gpus}
+    world = int(ws)
+    if world != gpus:
+        return {"action": "refuse", "why": f"--gpus {gpus} but WORLD_SIZE={world}: refusing to report a rank count that is not the one asked for"}
+    rank = int(env.get("RANK", "0"))
+    if not 0 <= rank < world:
+        return {"action": "refuse", "why": f"RANK={rank} outside WORLD_SIZE={world}"}
+    return {"action": "run", "world": world, "rank": rank, "local_rank": int(env.get("LOCAL_RANK", str(rank)))}
+
+
+def rank_environment(base_env, rank, world, port):
+    """Environment of rank ``rank`` of a self-launched job: what torch.distributed.run would export (127.0.0.1 rendezvous: the
+    container hostname may not resolve), dmabuf IPC for RCCL, and one OpenMP thread per rank (N ranks share the host)."""
+    env = dict(base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return env
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start one rank process per GPU (same interpreter, same arguments), rank 0's
+    stdout (the ONE JSON line) is this process's stdout, every rank's stderr is forwarded.  Returns the job's exit code: the first
+    non-zero rank code (the other ranks are then terminated -- a dead rank would leave them in a collective forever)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    log(f"self-launch: {gpus} ranks, rendezvous 127.0.0.1:{port}")
+    procs = []
+    for r in range(gpus):
+        procs.append(subprocess.Popen(cmd, env=rank_environment(os.environ, r, gpus, port),
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=None))
+    rc = 0
+    pending = set(range(gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"self-launch: rank {r} exited with {code}; stopping the other ranks")
+                for q in pending:
+                    procs[q].terminate()                          # exact PIDs we started
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     a = parse()
     if a.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker(a.config, 1234, a.cpu_steps, a.cpu_minibatches, a.reference)), flush=True)
         return
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    plan = launch_plan(a.gpus, os.environ)
+    if plan["action"] == "refuse":
+        raise SystemExit("bench.py: " + plan["why"])
+    if plan["action"] == "spawn":
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
+    world, rank, local_rank = plan["world"], plan["rank"], plan["local_rank"]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
+    share = bool(os.environ.get("PULSE_BENCH_SHARE_GPU"))
+    if torch.cuda.is_available() and torch.cuda.device_count() < world and not share:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible "
+                         "(set PULSE_BENCH_SHARE_GPU=1 with PULSE_DIST_BACKEND=gloo for a functional run of the N>1 path on one device)")
     from pulse_amd import _lib, configs, kernels
     from pulse_amd.env.sim import RecordedRollout
     from pulse_amd.parallel import DistContext
     _lib.load()                                                   # fail loudly before anything else if the HIP library is missing
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    if os.environ.get("PULSE_BENCH_SHARE_GPU"):                   # functional test of the N>1 path on a 1-GPU box (with PULSE_DIST_BACKEND=gloo)
+    if share:                                                     # functional test of the N>1 path on a 1-GPU box (with PULSE_DIST_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
@@ -277,16 +365,26 @@ def main():
         # BASELINE.json configs[3] ("32768 envs sharded 8-way ...") is this workload at 8 ranks: name it when the run is that shape
         "config": {"workload": ("cfg4 (cfg2 sharded over %d GPUs, %d envs in total): " % (world, num_envs * world) if (a.config == "cfg2" and world > 1) else "") +
                                f"{a.config}: {num_envs} SMPL-humanoid envs/GPU x horizon {T}, imitation obs/reward/reset + PPO "
-                               f"(actor+critic MLP {cfg['network']['mlp']['units']}, minibatch {cfg['minibatch_size']} x {cfg['mini_epochs']} mini-epochs)",
+                               f"(actor+critic MLP {cfg['network']['mlp']['units']}, minibatch {cfg['minibatch_size']} x {cfg['mini_epochs']} mini-epochs)"
+                               + workload_suffix(cfg),
                    "num_envs_per_gpu": num_envs, "horizon": T, "global_batch": T * num_envs * world, "parallelism": f"dp{world}",
                    "reference_motion": "HBM-resident motion library (1024 clips), queried every step" if a.reference == "motion_lib"
                    else "pre-recorded reference frames"},
         "play_ms_per_step": 1e3 * play / a.steps, "update_ms_per_step": 1e3 * upd / a.steps, "per_step_play_update_ms": per_step,
     }
+    if out["n_gpus"] != a.gpus:
+        raise SystemExit(f"bench.py: ran {out['n_gpus']} rank(s) for --gpus {a.gpus}")
     if world > 1:
+        ids = [None] * world
+        import torch.distributed as tdist
+        tdist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
+                                      "uuid": str(getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "uuid", ""))})
+        if dist.backend_world_size() != world:
+            raise SystemExit(f"bench.py: backend came up with {dist.backend_world_size()} ranks, --gpus {world}")
         st = dist.stats()
         exp_ms, exp_n = dist.exposed_wait_ms()
-        out["allreduce"] = {"backend": st["backend"], "ranks": world, "backend_world_size": dist.backend_world_size(),
+        out["allreduce"] = {"backend": st["backend"], "ranks": world, "backend_world_size": dist.backend_world_size(), "rank_devices": ids,
+                            "devices_shared": share,
                             "calls_per_step": st["calls"] / max(1, a.steps + a.warmup),
                             "mbytes_per_call": st["bytes"] / max(1, st["calls"]) / 1e6,
                             "ms_per_step_host_enqueue": 1e3 * st["seconds"] / max(1, a.steps + a.warmup),

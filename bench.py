@@ -415,7 +415,9 @@ def main():
                 r32["pipe_only_ceiling"] = {"tflops": 1758.3 / 6, "frac_of_it": r32["achieved"] / (1758.3 / 6),
                                             "source": "profiles/r03_mfma_ceiling.txt (register-resident MFMA chains, random bf16 operands: 1758.3 TFLOP/s at 1.72 GHz; "
                                                       "2474.5 at 2.39 GHz on all-zero operands)"}
-        r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")
+        r16 = roof(("b16_fwd", "b16_dx", "b16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_x3p_kernel<.., 1> (bf16 storage)")
+        if r16 is None:
+            r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")
         if r16 is not None:
             # mixed precision: the training GEMMs run on the bf16 MFMA (judged against its 2.5 PFLOP/s dense peak; with fp32 operand
             # storage the kernel is bound by operand traffic); the rollout's fp32 inference GEMMs are reported beside it

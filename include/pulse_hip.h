@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 17
+#define PULSE_ABI_VERSION 18
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -550,6 +550,33 @@ int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t
                        int32_t transpose, const int64_t* row_idx, pulse_stream_t s);
 
 /* ------------------------------------------------------------------------- *
+ * 4d. Glue of the bf16-STORAGE training path (mixed_precision: the reference wraps calc_gradients in autocast, amp_agent.py:671,
+ *     common_agent.py:426,461): activations, gradients and per-step weight copies are bf16 matrices feeding pulse_gemm_x3p(planes = 1).
+ * ------------------------------------------------------------------------- */
+/* out[z][c][r] = bf16(in[z][r][c]) for z < batch: W[out][in] -> W^T[in][out], so an input-gradient GEMM (nn.Linear backward,
+ * network_builder.py:105-124) reads both operands reduction-contiguous.  Columns [rows_in, ld_out) of the output rows are not written
+ * (allocate them zero: they are the k padding of the consumer). */
+int pulse_transpose_to_b16(const float* in, int64_t ld_in, int32_t rows_in, int32_t cols_in, void* out, int64_t ld_out, int32_t batch,
+                           int64_t stride_in, int64_t stride_out, pulse_stream_t s);
+/* pulse_colsum_partial over a bf16 matrix (ld in bf16 elements, multiple of 8): bias-gradient partials, fp32 accumulation.  With
+ * num_chunks = the split-K count and partial = the gradient slabs (ld_partial = the slab stride) the bias gradient rides the slab reduce
+ * the weight gradients need anyway (what pulse_gemm_desc.rowsum does for the fp32-storage kernels). */
+int pulse_colsum_partial_b16(const void* x, int32_t m, int32_t n, int64_t ld, int32_t num_chunks, float* partial, int64_t ld_partial,
+                             pulse_stream_t s);
+/* AMPAgent._disc_loss gradient penalty (amp_agent.py:925-934) on g = dD/dx of the demo rows (rows x cols fp32, pad columns zero):
+ * partials[block] = sum of g^2 over the block's share; out32 / out16 (either may be NULL) = scale * g, the seed of the penalty's backward
+ * pass (scale = 2 disc_grad_penalty disc_coef / (world_size rows)). */
+int pulse_disc_penalty(const float* g, int64_t ldg, int32_t rows, int32_t cols, float scale, float* out32, int64_t ld32, void* out16,
+                       int64_t ld16, float* partials, int32_t num_blocks, pulse_stream_t s);
+/* disc_logit_reg / disc_weight_decay terms (amp_agent.py:919-923, 936-940) over up to four ranges of a flat parameter buffer:
+ * grad[off_r + i] += alpha_r * flat[off_r + i] (grad may be NULL), partials[block * 4 + r] = the block's share of sum flat[range r]^2.
+ * offsets / lengths / alphas are HOST arrays of num_ranges entries. */
+int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int64_t* offsets, const int64_t* lengths, const float* alphas,
+                   float* partials, int32_t num_blocks, pulse_stream_t s);
+/* AMPAgent._calc_disc_rewards (amp_agent.py:1027-1041): out[i * out_stride] = -log(max(1 - sigmoid(logits[i * logit_stride]), 1e-4)) * scale */
+int pulse_disc_reward(const float* logits, int64_t logit_stride, int64_t n, float scale, float* out, int64_t out_stride, pulse_stream_t s);
+
+/* ------------------------------------------------------------------------- *
  * 4c. PULSE VAE head algebra (no autograd on the product path): form_embedding (amp_network_z_builder.py:79-121), the losses of
  *     AMPAgent._optimize_kin (amp_agent.py:771-849; kl_multi loss_functions.py:3-10) and their head-level gradients.
  *     Heads rows are [mu (E) | raw logvar (E)]; clamp_logvar applies clamp(logvar, -5, clamp_max) (use_vae_clamped_prior).
@@ -627,6 +654,12 @@ int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* 
                                const double* mean, const double* var, float eps, float clip,
                                float* y, int64_t y_stride, int32_t y_cols, double* moment_partials, int32_t num_blocks,
                                void* planes, int64_t plane_stride, int64_t planes_ld, pulse_stream_t s);
+/* The same normalise pass (mode 0, wide-row form) whose output IS a bf16 matrix (y16[row * y_stride + col], strides in bf16 elements, columns
+ * [cols, y_cols) zero): the layer-1 operand of the bf16-storage training path (section 4d; a bf16 autocast Linear rounds its fp32 input
+ * the same way, amp_agent.py:671). */
+int pulse_rms_normalize_b16(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols,
+                            const double* mean, const double* var, float eps, float clip,
+                            void* y16, int64_t y_stride, int32_t y_cols, double* moment_partials, int32_t num_blocks, pulse_stream_t s);
 /* _update_mean_var_count_from_moments, running_mean_std.py:56-67 (unbiased batch variance).
  * count_old is tracked by the host (it only ever grows by the batch size). */
 int pulse_rms_update(double* mean, double* var, double* count_out, const double* moment_partials, int32_t num_blocks,
@@ -664,6 +697,9 @@ typedef struct pulse_ppo_loss_args {
     float* dvalue; int64_t dvalue_stride; /* d loss / d value (rows) */
     float* partials;                   /* (num_blocks, 8): sums of a_loss, c_loss, b_loss, clipped, kl, 0,0,0 */
     int32_t num_blocks;
+    /* optional bf16 copies of the two gradients (strides in bf16 elements): the operands of the bf16-storage backward GEMMs (section 4d) */
+    void* dmu16; int64_t dmu16_stride;
+    void* dvalue16; int64_t dvalue16_stride;
 } pulse_ppo_loss_args;
 /* CommonAgent.calc_gradients loss section + analytic gradients w.r.t. the network outputs:
  * _actor_loss / _critic_loss / bound_loss (phc/learning/common_agent.py:512-520,564-587),
@@ -689,6 +725,10 @@ int pulse_sqnorm_partial(const float* x, int64_t count, float* partials, int32_t
  *   dlogits[i * dlogit_stride] = scale * d stats[0] / d logit_i          (scale = disc_coef / world_size) */
 int pulse_disc_head(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride,
                     float* stats, pulse_stream_t s);
+/* pulse_disc_head also (or only) writing the logit gradients as bf16 (dlogits16[i * dlogit16_stride]): operand of the bf16-storage
+ * discriminator backward.  dlogits may be NULL. */
+int pulse_disc_head_b16(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride,
+                        void* dlogits16, int64_t dlogit16_stride, float* stats, pulse_stream_t s);
 int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                     const float* sqnorm_partials, int32_t num_partials, float* grad_norm_out, pulse_stream_t s);

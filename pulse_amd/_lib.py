@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -207,6 +207,7 @@ class PpoLossArgs(Structure):
         ("e_clip", c_float), ("critic_coef", c_float), ("bounds_loss_coef", c_float), ("clip_value", c_int32), ("has_bounds_loss", c_int32),
         ("dmu", c_void_p), ("dmu_stride", c_int64), ("dvalue", c_void_p), ("dvalue_stride", c_int64),
         ("partials", c_void_p), ("num_blocks", c_int32),
+        ("dmu16", c_void_p), ("dmu16_stride", c_int64), ("dvalue16", c_void_p), ("dvalue16_stride", c_int64),
     ]
 
 
@@ -271,6 +272,13 @@ SIGNATURES = {
     "pulse_colsum_partial": (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, c_int64, P]),
     "pulse_rms_normalize": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, c_int32, P, c_int64, c_int32, P, c_int32, P]),
     "pulse_rms_normalize_planes": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, P, c_int64, c_int32, P, c_int32, P, c_int64, c_int64, P]),
+    "pulse_rms_normalize_b16": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, P, c_int64, c_int32, P, c_int32, P]),
+    "pulse_transpose_to_b16": (c_int, [P, c_int64, c_int32, c_int32, P, c_int64, c_int32, c_int64, c_int64, P]),
+    "pulse_colsum_partial_b16": (c_int, [P, c_int32, c_int32, c_int64, c_int32, P, c_int64, P]),
+    "pulse_disc_penalty": (c_int, [P, c_int64, c_int32, c_int32, c_float, P, c_int64, P, c_int64, P, c_int32, P]),
+    "pulse_disc_reg": (c_int, [P, P, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_float), P, c_int32, P]),
+    "pulse_disc_reward": (c_int, [P, c_int64, c_int64, c_float, P, c_int64, P]),
+    "pulse_disc_head_b16": (c_int, [P, c_int64, c_int32, c_float, P, c_int64, P, c_int64, P, P]),
     "pulse_rms_update": (c_int, [P, P, P, P, c_int32, c_int32, c_double, c_double, P]),
     "pulse_policy_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int32, c_int32, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
     "pulse_sizeof_ppo_loss_args": (c_int, []),

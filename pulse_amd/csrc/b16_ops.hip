@@ -1,0 +1,251 @@
+// Support kernels of the bf16-STORAGE training path (mixed_precision, BASELINE.json configs[4]; the reference's autocast sites are
+// phc/learning/amp_agent.py:671 and common_agent.py:426,461): activations, gradients and weight copies live in HBM as bf16 and feed
+// pulse_gemm_x3p(planes = 1).  Everything here is HBM- or latency-bound glue around those GEMMs:
+//
+//   transpose_to_b16     fp32 W[out][in] -> bf16 W^T[in][out] once per optimiser step, so every input-gradient GEMM runs in the forward
+//                        (both operands reduction-contiguous) form                       (nn.Linear backward, network_builder.py:105-124)
+//   colsum_partial_b16   bias gradients = column sums of a bf16 gradient matrix          (same call sites as pulse_colsum_partial)
+//   disc_penalty         AMPAgent._disc_loss gradient penalty (amp_agent.py:925-934): sum ||dD/dx||^2 partials + the scaled gradient dg
+//                        that starts the penalty's backward pass, as fp32 and / or bf16
+//   disc_reg             disc_logit_reg / disc_weight_decay gradient terms (amp_agent.py:919-923, 936-940): grad += alpha * w over up to
+//                        four parameter ranges, with the ranges' sums of squares for the reported loss
+//   disc_reward          AMPAgent._calc_disc_rewards (amp_agent.py:1027-1041): -log(max(1 - sigmoid(logit), 1e-4)) * scale
+#include "common.h"
+
+namespace pulse {
+
+typedef unsigned int b16_u32x4 __attribute__((ext_vector_type(4)));
+
+// out[z][c][r] = bf16(in[z][r][c]): 64 x 64 tiles through LDS, 16-byte reads of the fp32 rows, 8-byte writes of the bf16 rows.
+__global__ void __launch_bounds__(256) transpose_to_b16_kernel(const float* __restrict__ in, long long ld_in, int rows_in, int cols_in,
+                                                              unsigned short* __restrict__ out, long long ld_out, long long stride_in, long long stride_out) {
+    __shared__ float tile[64][65];
+    const float* src = in + blockIdx.z * stride_in;
+    unsigned short* dst = out + blockIdx.z * stride_out;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;           // 16 x 16 threads, 4 columns x 4 rows each
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows_in) {
+            if (c + 3 < cols_in) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (long long)r * ld_in + c);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (c + k < cols_in) v[k] = src[(long long)r * ld_in + c + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[ty + 16 * i][tx * 4 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oc = c0 + ty + 16 * i;                               // output row = input column
+        const int orr = r0 + tx * 4;                                   // output columns = input rows
+        if (oc >= cols_in || orr >= rows_in) continue;
+        const float a = tile[tx * 4][ty + 16 * i], b = tile[tx * 4 + 1][ty + 16 * i], c = tile[tx * 4 + 2][ty + 16 * i], d = tile[tx * 4 + 3][ty + 16 * i];
+        unsigned short* o = dst + (long long)oc * ld_out + orr;
+        if (orr + 3 < rows_in) {
+            *reinterpret_cast<uint2*>(o) = make_uint2(split_pack_rn(a, b), split_pack_rn(c, d));
+        } else {
+            const float v[4] = {a, b, c, d};
+            for (int k = 0; k < 4 && orr + k < rows_in; ++k) o[k] = (unsigned short)(split_pack_rn(v[k], 0.f) & 0xffffu);
+        }
+    }
+}
+
+// partial[chunk][n] = sum over the chunk's rows of X[m][n], X bf16.  256 threads = CG column groups (8 columns = 16 bytes each) x 256 / CG
+// row lanes; four independent loads in flight per thread; fp32 accumulation in a fixed order.  CG = 32: 256 columns per workgroup (many
+// chunks); CG = 4: 32 columns per workgroup, for the launches that write one partial row per GRADIENT SLAB (num_chunks = the book's
+// split-K count, partial = the slabs themselves): the bias gradient then needs no reduce launch of its own -- the slab reduce that the
+// weight gradients need anyway sums it -- and the few chunks still give every CU a workgroup.
+template <int CG>
+__global__ void __launch_bounds__(256) colsum_partial_b16_kernel(const unsigned short* __restrict__ X, int M, int N, long long ld, int rows_per_chunk,
+                                                                float* __restrict__ partial, long long ldp) {
+    constexpr int RL = 256 / CG;
+    __shared__ float red[RL][CG][9];
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const int c = blockIdx.x * (CG * 8) + cg * 8;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(M, r0 + rows_per_chunk);
+    float s[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[q][k] = 0.f;
+    if (c < N) {
+        const unsigned short* p = X + c;
+        auto add = [&](int q, int r) {
+            const b16_u32x4 t = *reinterpret_cast<const b16_u32x4*>(p + (long long)r * ld);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[q][2 * k] += split_bitsf(t[k] << 16); s[q][2 * k + 1] += split_bitsf(t[k] & 0xffff0000u); }
+        };
+        int r = r0 + rl;
+        for (; r + 3 * RL < r1; r += 4 * RL) { add(0, r); add(1, r + RL); add(2, r + 2 * RL); add(3, r + 3 * RL); }
+        for (; r < r1; r += RL) add(0, r);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl][cg][k] = (s[0][k] + s[1][k]) + (s[2][k] + s[3][k]);
+    __syncthreads();
+    // 8 * CG output columns, one thread each: the RL row lanes' sums added in lane order
+    if (threadIdx.x < 8 * CG) {
+        const int g = threadIdx.x >> 3, k = threadIdx.x & 7;
+        const int col = blockIdx.x * (CG * 8) + g * 8 + k;
+        if (col < N) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int w = 0; w < RL; ++w) t += red[w][g][k];
+            partial[(long long)blockIdx.y * ldp + col] = t;
+        }
+    }
+}
+
+// dg = scale * G (fp32 and / or bf16), partials[block] = sum of G^2 over the block's elements.  G is (rows, ld) with its pad columns zero.
+__global__ void __launch_bounds__(256) disc_penalty_kernel(const float* __restrict__ G, long long ldg, int rows, int cols4, float scale,
+                                                          float* __restrict__ out32, long long ld32, unsigned short* __restrict__ out16, long long ld16,
+                                                          float* __restrict__ partials) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long long total = (long long)rows * cols4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(G + (long long)r * ldg + c);
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        const float a = v.x * scale, b = v.y * scale, cc = v.z * scale, d = v.w * scale;
+        if (out32) *reinterpret_cast<float4*>(out32 + (long long)r * ld32 + c) = make_float4(a, b, cc, d);
+        if (out16) *reinterpret_cast<uint2*>(out16 + (long long)r * ld16 + c) = make_uint2(split_pack_rn(a, b), split_pack_rn(cc, d));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct DiscRegArgs { long long off[4]; long long len[4]; float alpha[4]; int n; };
+
+// grad[off_r + i] += alpha_r * flat[off_r + i];  partials[block * 4 + r] = sum over the block's share of flat[range r]^2
+__global__ void __launch_bounds__(256) disc_reg_kernel(const float* __restrict__ flat, float* __restrict__ grad, const DiscRegArgs a, float* __restrict__ partials) {
+    __shared__ float red[4][4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r >= a.n) break;
+        const float* w = flat + a.off[r];
+        float* g = grad ? grad + a.off[r] : nullptr;
+        const float al = a.alpha[r];
+        if (((a.off[r] | a.len[r]) & 3) == 0) {                          // 16-byte path (every weight matrix of a ParamBook)
+            const long long n4 = a.len[r] >> 2;
+            const bool upd = g && al != 0.f;
+            for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+                const float4 v = reinterpret_cast<const float4*>(w)[i];
+                acc[r] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                if (upd) {
+                    float4 t = reinterpret_cast<float4*>(g)[i];
+                    t.x += al * v.x; t.y += al * v.y; t.z += al * v.z; t.w += al * v.w;
+                    reinterpret_cast<float4*>(g)[i] = t;
+                }
+            }
+            continue;
+        }
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.len[r]; i += (long long)gridDim.x * 256) {
+            const float v = w[i];
+            acc[r] += v * v;
+            if (g && al != 0.f) g[i] += al * v;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][r] = acc[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) partials[blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) disc_reward_kernel(const float* __restrict__ logits, long long ls, long long n, float scale, float* __restrict__ out, long long os) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = logits[i * ls];
+    const float prob = 1.f / (1.f + expf(-x));                          // the reference's op sequence, op for op (amp_agent.py:1033-1038)
+    out[i * os] = -logf(fmaxf(1.f - prob, 0.0001f)) * scale;
+}
+
+}  // namespace pulse
+
+using namespace pulse;
+
+extern "C" {
+
+int pulse_transpose_to_b16(const float* in, int64_t ld_in, int32_t rows_in, int32_t cols_in, void* out, int64_t ld_out, int32_t batch,
+                           int64_t stride_in, int64_t stride_out, pulse_stream_t s) {
+    PULSE_REQUIRE(rows_in >= 0 && cols_in >= 0 && batch >= 0, "pulse_transpose_to_b16: negative size");
+    if (rows_in == 0 || cols_in == 0 || batch == 0) return PULSE_OK;
+    PULSE_REQUIRE(in && out, "pulse_transpose_to_b16: null pointer");
+    PULSE_REQUIRE(ld_in >= cols_in && (ld_in % 4) == 0 && (stride_in % 4) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0,
+                  "pulse_transpose_to_b16: input rows must be 16-byte aligned");
+    PULSE_REQUIRE(ld_out >= rows_in && (ld_out % 4) == 0 && (stride_out % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+                  "pulse_transpose_to_b16: output rows must be 8-byte aligned and hold rows_in columns");
+    const dim3 grid((unsigned)((cols_in + 63) / 64), (unsigned)((rows_in + 63) / 64), (unsigned)batch);
+    hipLaunchKernelGGL(transpose_to_b16_kernel, grid, dim3(256), 0, as_stream(s), in, (long long)ld_in, rows_in, cols_in,
+                       reinterpret_cast<unsigned short*>(out), (long long)ld_out, (long long)stride_in, (long long)stride_out);
+    return check_launch("pulse_transpose_to_b16");
+}
+
+int pulse_colsum_partial_b16(const void* x, int32_t m, int32_t n, int64_t ld, int32_t num_chunks, float* partial, int64_t ld_partial, pulse_stream_t s) {
+    PULSE_REQUIRE(m >= 0 && n >= 0 && num_chunks >= 1, "pulse_colsum_partial_b16: bad sizes");
+    if (n == 0) return PULSE_OK;
+    PULSE_REQUIRE(x && partial && ld >= ((n + 7) & ~7) && ld_partial >= n, "pulse_colsum_partial_b16: bad pointers / pitches (ld must cover roundup8(n))");
+    PULSE_REQUIRE((ld % 8) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "pulse_colsum_partial_b16: x rows must be 16-byte aligned");
+    const int rows = (m + num_chunks - 1) / num_chunks;
+    const unsigned short* xp = reinterpret_cast<const unsigned short*>(x);
+    if ((long long)((n + 255) / 256) * num_chunks >= 256)
+        hipLaunchKernelGGL(colsum_partial_b16_kernel<32>, dim3((unsigned)((n + 255) / 256), (unsigned)num_chunks), dim3(256), 0, as_stream(s), xp, m, n,
+                           (long long)ld, rows > 0 ? rows : 1, partial, (long long)ld_partial);
+    else
+        hipLaunchKernelGGL(colsum_partial_b16_kernel<4>, dim3((unsigned)((n + 31) / 32), (unsigned)num_chunks), dim3(256), 0, as_stream(s), xp, m, n,
+                           (long long)ld, rows > 0 ? rows : 1, partial, (long long)ld_partial);
+    return check_launch("pulse_colsum_partial_b16");
+}
+
+int pulse_disc_penalty(const float* g, int64_t ldg, int32_t rows, int32_t cols, float scale, float* out32, int64_t ld32, void* out16, int64_t ld16,
+                       float* partials, int32_t num_blocks, pulse_stream_t s) {
+    PULSE_REQUIRE(rows >= 1 && cols >= 1 && num_blocks >= 1, "pulse_disc_penalty: bad sizes");
+    PULSE_REQUIRE(g && partials, "pulse_disc_penalty: null pointer");
+    PULSE_REQUIRE((cols % 4) == 0 && (ldg % 4) == 0 && ldg >= cols && (reinterpret_cast<uintptr_t>(g) & 15) == 0,
+                  "pulse_disc_penalty: cols / pitch must be multiples of 4 floats (the pad columns of G are zero and are processed with it)");
+    PULSE_REQUIRE(!out32 || ((ld32 % 4) == 0 && ld32 >= cols && (reinterpret_cast<uintptr_t>(out32) & 15) == 0), "pulse_disc_penalty: fp32 output rows must be 16-byte aligned");
+    PULSE_REQUIRE(!out16 || ((ld16 % 4) == 0 && ld16 >= cols && (reinterpret_cast<uintptr_t>(out16) & 7) == 0), "pulse_disc_penalty: bf16 output rows must be 8-byte aligned");
+    hipLaunchKernelGGL(disc_penalty_kernel, dim3((unsigned)num_blocks), dim3(256), 0, as_stream(s), g, (long long)ldg, rows, cols / 4, scale, out32,
+                       (long long)ld32, reinterpret_cast<unsigned short*>(out16), (long long)ld16, partials);
+    return check_launch("pulse_disc_penalty");
+}
+
+int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int64_t* offsets, const int64_t* lengths, const float* alphas,
+                   float* partials, int32_t num_blocks, pulse_stream_t s) {
+    PULSE_REQUIRE(num_ranges >= 1 && num_ranges <= 4 && num_blocks >= 1, "pulse_disc_reg: 1..4 ranges");
+    PULSE_REQUIRE(flat && offsets && lengths && alphas && partials, "pulse_disc_reg: null pointer");
+    PULSE_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 15) == 0 && (!grad || (reinterpret_cast<uintptr_t>(grad) & 15) == 0), "pulse_disc_reg: flat / grad must be 16-byte aligned");
+    DiscRegArgs a;
+    a.n = num_ranges;
+    for (int r = 0; r < 4; ++r) {
+        a.off[r] = r < num_ranges ? offsets[r] : 0; a.len[r] = r < num_ranges ? lengths[r] : 0; a.alpha[r] = r < num_ranges ? alphas[r] : 0.f;
+        PULSE_REQUIRE(a.off[r] >= 0 && a.len[r] >= 0, "pulse_disc_reg: negative range");
+    }
+    hipLaunchKernelGGL(disc_reg_kernel, dim3((unsigned)num_blocks), dim3(256), 0, as_stream(s), flat, grad, a, partials);
+    return check_launch("pulse_disc_reg");
+}
+
+int pulse_disc_reward(const float* logits, int64_t logit_stride, int64_t n, float scale, float* out, int64_t out_stride, pulse_stream_t s) {
+    PULSE_REQUIRE(n >= 0, "pulse_disc_reward: negative size");
+    if (n == 0) return PULSE_OK;
+    PULSE_REQUIRE(logits && out && logit_stride >= 1 && out_stride >= 1, "pulse_disc_reward: bad arguments");
+    hipLaunchKernelGGL(disc_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), logits, (long long)logit_stride, (long long)n, scale, out,
+                       (long long)out_stride);
+    return check_launch("pulse_disc_reward");
+}
+}

@@ -45,6 +45,7 @@ SOURCES = [
     ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),   # (packed-f32 VALU beside MFMAs also costs more than two plain adds)
     ("gemm_x3p.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("learner_ops.hip", NO_CONTRACT),
+    ("b16_ops.hip", NO_CONTRACT),
     ("vae_head.hip", NO_CONTRACT),
 ]
 

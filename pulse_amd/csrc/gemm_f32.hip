@@ -68,41 +68,6 @@ struct GemmArgs {
 
 __device__ __forceinline__ int slot_of(int out) { return out ^ ((out >> 3) & 7); }
 
-// ---- workgroup -> (output tile, batch slot, k split), XCD-aware ---------------------------------------------------------------------------
-// Workgroups are dealt to the 8 XCDs round-robin in linear launch order (x fastest), and each XCD has its own L2.
-//  * no split-K: every XCD owns a contiguous band of the output tiles (an A row panel is fetched by one XCD only; B by all eight);
-//  * split-K (the weight-gradient launches: small outputs, long reductions): every XCD owns a K RANGE instead -- split s runs on XCD s (or on
-//    8 / S XCDs, each with a contiguous share of the tiles).  The workgroups of an XCD then walk the same k rows of A and B in step, so every
-//    operand element crosses the fabric once per XCD that needs it instead of once per XCD: the layer-1 weight gradient of cfg2 (4 splits) goes
-//    from |dZ| + 8 |X| to |dZ| + 2 |X| of fetch (624 -> 256 MB per launch).  Falls back to the band order when the counts do not divide.
-#ifndef PULSE_SPLITK_XCD
-#define PULSE_SPLITK_XCD 1
-#endif
-struct WgMap { int id, bz, sp; };
-__device__ __forceinline__ WgMap map_workgroup(int ntile, int batch, int splitk) {
-    const int cnt = ntile * batch;                                   // (tile, batch slot) pairs per split
-    if (PULSE_SPLITK_XCD && splitk > 1) {
-        const int L = blockIdx.y * gridDim.x + blockIdx.x;
-        const int xcd = L & 7, q = L >> 3;
-        if ((splitk & 7) == 0 && ((cnt * splitk) & 7) == 0) {        // 8, 16, 32 splits: split = xcd + 8 * (q % (S / 8))
-            const int g8 = splitk >> 3;
-            const int sp = xcd + 8 * (q % g8), rest = q / g8;
-            return WgMap{rest % ntile, rest / ntile, sp};
-        }
-        if ((8 % splitk) == 0 && (cnt % (8 / splitk)) == 0) {        // 2, 4 splits: 8 / S XCDs per split, contiguous shares of the tiles
-            const int per = 8 / splitk, share = cnt / per;
-            const int sp = xcd / per, rest = (xcd % per) * share + q;
-            return WgMap{rest % ntile, rest / ntile, sp};
-        }
-    }
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int q8 = ntile >> 3, rr = ntile & 7;
-    const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
-    const int z = blockIdx.y;
-    return WgMap{id, z / splitk, z % splitk};
-}
-
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }

@@ -111,16 +111,13 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    // XCD-aware remap (block b runs on XCD b % 8): every XCD owns a contiguous band of m-tiles
-    const int ntile = g.tiles_m * g.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int q8 = ntile >> 3, rr = ntile & 7;
-    const int id = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + loc;
+    // XCD-aware remap (common.h map_workgroup; block b runs on XCD b % 8): every XCD owns a contiguous band of output tiles, or -- split-K
+    // launches, i.e. the weight gradients -- a K RANGE of both operands, so an operand element crosses the fabric once instead of once per XCD
+    const WgMap wgm = map_workgroup(g.tiles_m * g.tiles_n, g.batch, g.splitk);
+    const int id = wgm.id;
     const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * PBN;
-    const int z = blockIdx.y;
-    const int bz = z / g.splitk, sp = z - bz * g.splitk;
+    const int bz = wgm.bz, sp = wgm.sp;
     const int kbeg = sp * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int klen = kend - kbeg;

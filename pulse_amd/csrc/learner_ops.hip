@@ -87,11 +87,13 @@ __global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __
 // of a row per instruction).  Needs 16-byte aligned rows on both sides and y_cols % 4 == 0.
 constexpr int kRmsVecGroups = 3;   // 256 threads x 4 columns x 3 groups = 3072 columns
 constexpr int kRmsRowsPerPass = 64;
-constexpr int kRmsRowsInFlight = 4;
+constexpr int kRmsRowsInFlight = 8;     // rows whose loads are in flight per workgroup (4 KB each): the row loop is a latency x concurrency product
 
-// PLANES: besides y, the three bf16 planes of every output element (common.h: split_pair3) go to planes[p * plane_stride + row * planes_ld + col]
+// OUT = 1: besides y, the three bf16 planes of every output element (common.h: split_pair3) go to planes[p * plane_stride + row * planes_ld + col]
 // -- the layer-1 operand of the planar GEMM (gemm_x3p.hip) written by its producer instead of a separate split pass.
-template <bool PLANES>
+// OUT = 2: the output IS a bf16 matrix (planes[row * planes_ld + col], y unused): the layer-1 operand of the bf16-storage training path
+// (mixed_precision; a bf16 autocast Linear rounds its fp32 input exactly like this).
+template <int OUT>
 __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,
                                                                 const double* __restrict__ mean, const double* __restrict__ var,
@@ -139,7 +141,7 @@ __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __
 #pragma unroll
             for (int h = 0; h < kRmsRowsInFlight; ++h) {
                 if (q + h >= nr) break;
-                float* yr = y + (long long)(rb + q + h) * y_stride;
+                float* yr = OUT == 2 ? nullptr : y + (long long)(rb + q + h) * y_stride;
 #pragma unroll
                 for (int j = 0; j < kRmsVecGroups; ++j) {
                     const int c = (tid + 256 * j) * 4;
@@ -155,8 +157,12 @@ __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __
                                 o[k] = 0.f;
                             }
                         }
-                        *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
-                        if constexpr (PLANES) {
+                        if constexpr (OUT == 2) {
+                            *reinterpret_cast<uint2*>(planes + (long long)(rb + q + h) * planes_ld + c) = make_uint2(split_pack_rn(o[0], o[1]), split_pack_rn(o[2], o[3]));
+                        } else {
+                            *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                        if constexpr (OUT == 1) {
                             unsigned a0, a1, a2, b0, b1, b2;
                             split_pair3(o[0], o[1], a0, a1, a2);
                             split_pair3(o[2], o[3], b0, b1, b2);
@@ -374,9 +380,11 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(const pulse_ppo_loss_args
             float gmu = g_nlp * (-(act[j] - m) / (sg * sg));
             if (a.has_bounds_loss) gmu += a.bounds_loss_coef * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
             dmu[j] = gmu * invB;
+            if (a.dmu16) reinterpret_cast<unsigned short*>(a.dmu16)[(long long)i * a.dmu16_stride + j] = (unsigned short)(split_pack_rn(gmu * invB, 0.f) & 0xffffu);
         }
         if (l == 0) {
             a.dvalue[(long long)i * a.dvalue_stride] = a.critic_coef * g_v * invB;
+            if (a.dvalue16) reinterpret_cast<unsigned short*>(a.dvalue16)[(long long)i * a.dvalue16_stride] = (unsigned short)(split_pack_rn(a.critic_coef * g_v * invB, 0.f) & 0xffffu);
             acc_a += a_loss; acc_c += c_loss; acc_b += bl; acc_clip += clipped; acc_kl += kl;
         }
     }
@@ -436,7 +444,8 @@ __global__ void __launch_bounds__(256) adv_normalize_kernel(float* __restrict__ 
 // ``scale`` = disc_coef / world_size), the two accuracies and the two logit means -- one launch instead of ~45 tiny tensor ops and an
 // autograd pass per minibatch.  One workgroup: 3b logits are a few hundred KB; reductions in double, fixed order.
 __global__ void __launch_bounds__(1024) disc_head_kernel(const float* __restrict__ logits, long long ls, int b, float scale,
-                                                         float* __restrict__ dlogits, long long ds, float* __restrict__ stats) {
+                                                         float* __restrict__ dlogits, long long ds, float* __restrict__ stats,
+                                                         unsigned short* __restrict__ dl16, long long ds16) {
     __shared__ double red[16][6];
     const int n = 3 * b, na = 2 * b;
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // BCE agent, BCE demo, #agent < 0, #demo > 0, sum agent logit, sum demo logit
@@ -447,10 +456,12 @@ __global__ void __launch_bounds__(1024) disc_head_kernel(const float* __restrict
         const float sg = 1.f / (1.f + expf(-x));
         if (i < na) {
             acc[0] += (double)sp; acc[2] += x < 0.f ? 1.0 : 0.0; acc[4] += (double)x;
-            dlogits[(long long)i * ds] = ga * sg;
+            if (dlogits) dlogits[(long long)i * ds] = ga * sg;
+            if (dl16) dl16[(long long)i * ds16] = (unsigned short)(split_pack_rn(ga * sg, 0.f) & 0xffffu);
         } else {
             acc[1] += (double)(sp - x); acc[3] += x > 0.f ? 1.0 : 0.0; acc[5] += (double)x;
-            dlogits[(long long)i * ds] = gd * (sg - 1.f);
+            if (dlogits) dlogits[(long long)i * ds] = gd * (sg - 1.f);
+            if (dl16) dl16[(long long)i * ds16] = (unsigned short)(split_pack_rn(gd * (sg - 1.f), 0.f) & 0xffffu);
         }
     }
 #pragma unroll
@@ -540,7 +551,7 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
                         (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                         x_stride >= ((cols + 3) & ~3);
     if (vec_ok)
-        hipLaunchKernelGGL(rms_normalize_vec4_kernel<false>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+        hipLaunchKernelGGL(rms_normalize_vec4_kernel<0>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials,
                            (unsigned short*)nullptr, 0LL, 0LL);
     else if (cols >= 64)
@@ -567,10 +578,27 @@ int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* 
     PULSE_REQUIRE((y_cols % 32) == 0 && planes_ld >= y_cols && (planes_ld % 8) == 0 && (plane_stride % 8) == 0 && plane_stride >= (int64_t)rows * planes_ld &&
                   (reinterpret_cast<uintptr_t>(planes) & 15) == 0,
                   "pulse_rms_normalize_planes: y_cols must be a multiple of 32 (zero-padded k extent), planes rows 16-byte aligned and covering it");
-    hipLaunchKernelGGL(rms_normalize_vec4_kernel<true>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+    hipLaunchKernelGGL(rms_normalize_vec4_kernel<1>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
                        (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
                        reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
     return check_launch("pulse_rms_normalize_planes");
+}
+
+int pulse_rms_normalize_b16(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols, const double* mean,
+                            const double* var, float eps, float clip, void* y16, int64_t y_stride, int32_t y_cols, double* moment_partials,
+                            int32_t num_blocks, pulse_stream_t s) {
+    PULSE_REQUIRE(rows >= 0 && cols >= 0, "pulse_rms_normalize_b16: negative size");
+    if (rows == 0 || cols == 0) return PULSE_OK;
+    PULSE_REQUIRE(x && y16 && mean && var, "pulse_rms_normalize_b16: null pointer");
+    PULSE_REQUIRE(num_blocks >= 1, "pulse_rms_normalize_b16: num_blocks < 1");
+    PULSE_REQUIRE(y_cols >= cols && y_stride >= y_cols && x_stride >= cols, "pulse_rms_normalize_b16: bad pitches");
+    PULSE_REQUIRE(cols >= 64 && y_cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride >= ((cols + 3) & ~3),
+                  "pulse_rms_normalize_b16: needs the wide-row form (64 <= cols, y_cols <= %d, 16-byte aligned input rows)", 256 * 4 * kRmsVecGroups);
+    PULSE_REQUIRE((y_cols % 4) == 0 && (y_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(y16) & 7) == 0, "pulse_rms_normalize_b16: output rows must be 8-byte aligned, y_cols a multiple of 4");
+    hipLaunchKernelGGL(rms_normalize_vec4_kernel<2>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+                       (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, (float*)nullptr, 0LL, y_cols, moment_partials,
+                       reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
+    return check_launch("pulse_rms_normalize_b16");
 }
 
 int pulse_rms_update(double* mean, double* var, double* count_out, const double* moment_partials, int32_t num_blocks, int32_t cols,
@@ -644,8 +672,18 @@ int pulse_disc_head(const float* logits, int64_t logit_stride, int32_t b, float 
     PULSE_REQUIRE(b >= 1 && logit_stride >= 1 && dlogit_stride >= 1, "pulse_disc_head: bad sizes");
     PULSE_REQUIRE(logits && dlogits && stats, "pulse_disc_head: null pointer");
     hipLaunchKernelGGL(disc_head_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, (long long)logit_stride, b, scale, dlogits,
-                       (long long)dlogit_stride, stats);
+                       (long long)dlogit_stride, stats, (unsigned short*)nullptr, 0LL);
     return check_launch("pulse_disc_head");
+}
+
+int pulse_disc_head_b16(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride, void* dlogits16,
+                        int64_t dlogit16_stride, float* stats, pulse_stream_t s) {
+    PULSE_REQUIRE(b >= 1 && logit_stride >= 1, "pulse_disc_head_b16: bad sizes");
+    PULSE_REQUIRE(logits && stats && (dlogits || dlogits16), "pulse_disc_head_b16: null pointer");
+    PULSE_REQUIRE((!dlogits || dlogit_stride >= 1) && (!dlogits16 || dlogit16_stride >= 1), "pulse_disc_head_b16: bad strides");
+    hipLaunchKernelGGL(disc_head_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, (long long)logit_stride, b, scale, dlogits,
+                       (long long)dlogit_stride, stats, reinterpret_cast<unsigned short*>(dlogits16), (long long)dlogit16_stride);
+    return check_launch("pulse_disc_head_b16");
 }
 
 int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1, float beta2,

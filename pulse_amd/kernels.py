@@ -156,6 +156,32 @@ class Plan:
     def gemm_x3p(self, A, B, **kw):
         self.ops.append((2,) + make_gemm_x3p_desc(A, B, **kw))
 
+    def gemm_b16(self, A, B, **kw):
+        """bf16-storage GEMM (pulse_gemm_x3p, planes = 1): A / B / Cp / aux are int16 (bf16 bit pattern) tensors."""
+        self.ops.append((2,) + make_gemm_x3p_desc(A, B, planes=1, **kw))
+
+    def refresh_b16(self, flat, flat16, count):
+        """flat16[i] = bf16(flat[i]) for the whole flat parameter buffer: the bf16 weight image the plan's GEMMs read is rebuilt inside the
+        plan, so no writer of the parameters (optimiser step, checkpoint load, broadcast, a test poking the buffer) can leave it stale."""
+        n8 = (count + 7) // 8 * 8
+        if flat16.dtype != torch.int16 or flat16.numel() < n8 or flat.numel() < count:
+            raise ValueError("refresh_b16: flat16 must be an int16 buffer of roundup8(count) elements")
+        self.call("pulse_split_planes", flat.data_ptr(), count, 1, count, flat16.data_ptr(), 0, n8, 0, None)
+
+    def transpose_b16(self, x, out, **kw):
+        x_off, out_off = kw.pop("x_off", 0), kw.pop("out_off", 0)
+        if out.dtype != torch.int16:
+            raise TypeError("transpose_b16: out must be int16")
+        self.call("pulse_transpose_to_b16", x.data_ptr() + 4 * x_off, kw["ld_in"], kw["rows"], kw["cols"], out.data_ptr() + 2 * out_off, kw["ld_out"],
+                  kw.get("batch", 1), kw.get("stride_in", 0), kw.get("stride_out", 0))
+
+    def colsum_b16(self, x, m, n, ld, slabs, num_slabs, slab_stride, out_off, x_off=0):
+        """Bias gradient of a bf16 gradient matrix (m, n): slab s of ``slabs`` receives, at [out_off, out_off + n), the column sums over the
+        s-th of ``num_slabs`` row ranges -- summed with the weight gradients by the one slab reduce, like the fp32 kernels' ``rowsum``."""
+        if x.dtype != torch.int16:
+            raise TypeError("colsum_b16: x must be an int16 (bf16 bit pattern) tensor")
+        self.call("pulse_colsum_partial_b16", x.data_ptr() + 2 * x_off, m, n, ld, num_slabs, slabs.data_ptr() + 4 * out_off, slab_stride)
+
     def run(self, start=0, stop=None):
         st = _stream()
         for op in self.ops[start:stop]:
@@ -369,9 +395,16 @@ def colsum_partial(x, m, n, ld, num_chunks, partial, ld_partial, x_off=0, partia
 
 def rms_normalize(x, mean, var, *, rows, cols, x_stride, y, y_stride, y_cols=None, row_idx=None, eps=1e-5, clip=5.0,
                   unnorm=False, moment_partials=None, num_blocks=None, planes=None):
-    """``planes``: a (3, rows, pitch) int16 planes tensor that also receives the exact three-way bf16 split of y (layer-1 operand of gemm_x3p)."""
+    """``planes``: a (3, rows, pitch) int16 planes tensor that also receives the exact three-way bf16 split of y (layer-1 operand of gemm_x3p).
+    ``y`` of dtype int16: the output IS a bf16 matrix (layer-1 operand of the bf16-storage training path); wide rows only."""
     if num_blocks is None:
         num_blocks = max(1, min(512, rows // 16)) if moment_partials is None else moment_partials.shape[0]
+    if y.dtype == torch.int16:
+        if unnorm or planes is not None or not y.is_cuda or y.stride(-1) != 1:
+            raise ValueError("rms_normalize: a bf16 output goes with the normalising direction, without planes")
+        _lib.check(_lib.load().pulse_rms_normalize_b16(_p(x), x_stride, _p(row_idx), rows, cols, _p(mean), _p(var), eps, clip, y.data_ptr(), y_stride,
+                                                       cols if y_cols is None else y_cols, _p(moment_partials), num_blocks, _stream()), "pulse_rms_normalize_b16")
+        return
     if planes is not None:
         if unnorm:
             raise ValueError("rms_normalize: planes go with the normalising direction only")
@@ -410,7 +443,7 @@ def policy_sample(mu, mu_stride, logstd, noise, noise_stride, rows, num_actions,
 
 def ppo_loss(*, mu, mu_stride, value, value_stride, logstd, old_logstd, idx, actions, actions_stride, old_mu, old_mu_stride,
              old_neglogp, advantages, old_values, returns, rows, num_actions, e_clip, critic_coef, bounds_loss_coef, clip_value,
-             dmu, dmu_stride, dvalue, dvalue_stride, partials):
+             dmu, dmu_stride, dvalue, dvalue_stride, partials, dmu16=None, dmu16_stride=0, dvalue16=None, dvalue16_stride=0, dmu16_off=0, dvalue16_off=0):
     a = PpoLossArgs()
     a.mu, a.mu_stride, a.value, a.value_stride, a.logstd = _p(mu), mu_stride, _p(value), value_stride, _p(logstd)
     a.idx, a.actions, a.actions_stride = _p(idx), _p(actions), actions_stride
@@ -423,6 +456,11 @@ def ppo_loss(*, mu, mu_stride, value, value_stride, logstd, old_logstd, idx, act
     a.clip_value = 1 if clip_value else 0
     a.dmu, a.dmu_stride, a.dvalue, a.dvalue_stride = _p(dmu), dmu_stride, _p(dvalue), dvalue_stride
     a.partials, a.num_blocks = _p(partials), partials.shape[0]
+    if dmu16 is not None:                  # bf16 copies of the head gradients (int16 bit patterns; *_off in bf16 elements)
+        if dmu16.dtype != torch.int16 or dvalue16 is None or dvalue16.dtype != torch.int16:
+            raise TypeError("ppo_loss: dmu16 / dvalue16 must be int16 (bf16 bit pattern) CUDA tensors")
+        a.dmu16, a.dmu16_stride = dmu16.data_ptr() + 2 * dmu16_off, dmu16_stride
+        a.dvalue16, a.dvalue16_stride = dvalue16.data_ptr() + 2 * dvalue16_off, dvalue16_stride
     _lib.check(_lib.load().pulse_ppo_loss(ctypes.byref(a), _stream()), "pulse_ppo_loss")
 
 
@@ -451,6 +489,60 @@ def disc_head(logits, b, scale, dlogits, stats):
         raise ValueError("disc_head: logits / dlogits must have 3b rows and stats 8 contiguous floats")
     _lib.check(_lib.load().pulse_disc_head(_p(logits), logits.stride(0), b, float(scale), _p(dlogits), dlogits.stride(0), _p(stats), _stream()),
                "pulse_disc_head")
+
+
+def disc_head_b16(logits, b, scale, dlogits16, stats, dlogits=None):
+    """disc_head writing the logit gradients as bf16 (dlogits16: int16 (>= 3b, pitch) tensor, column 0) and optionally as fp32 too."""
+    _chk(logits, "logits"), _chk(stats, "stats"), _chk(dlogits, "dlogits")
+    if dlogits16.dtype != torch.int16 or not dlogits16.is_cuda or dlogits16.shape[0] < 3 * b or logits.shape[0] != 3 * b or stats.numel() < 8:
+        raise ValueError("disc_head_b16: logits must have 3b rows, dlogits16 be an int16 CUDA tensor of >= 3b rows, stats 8 floats")
+    _lib.check(_lib.load().pulse_disc_head_b16(_p(logits), logits.stride(0), b, float(scale), _p(dlogits), dlogits.stride(0) if dlogits is not None else 0,
+                                               dlogits16.data_ptr(), dlogits16.stride(0), _p(stats), _stream()), "pulse_disc_head_b16")
+
+
+def transpose_to_b16(x, out, *, rows, cols, ld_in, ld_out, batch=1, stride_in=0, stride_out=0, x_off=0, out_off=0):
+    """out[z][c][r] = bf16(x[z][r][c]); x fp32 base tensor (+ x_off floats), out int16 base tensor (+ out_off elements)."""
+    _chk(x, "x")
+    if out.dtype != torch.int16 or not out.is_cuda:
+        raise TypeError("transpose_to_b16: out must be an int16 CUDA tensor")
+    _lib.check(_lib.load().pulse_transpose_to_b16(x.data_ptr() + 4 * x_off, ld_in, rows, cols, out.data_ptr() + 2 * out_off, ld_out, batch, stride_in,
+                                                  stride_out, _stream()), "pulse_transpose_to_b16")
+
+
+def colsum_partial_b16(x, m, n, ld, num_chunks, partial, ld_partial, x_off=0, partial_off=0):
+    if x.dtype != torch.int16 or not x.is_cuda:
+        raise TypeError("colsum_partial_b16: x must be an int16 (bf16 bit pattern) CUDA tensor")
+    _chk(partial, "partial")
+    _lib.check(_lib.load().pulse_colsum_partial_b16(x.data_ptr() + 2 * x_off, m, n, ld, num_chunks, partial.data_ptr() + 4 * partial_off, ld_partial,
+                                                    _stream()), "pulse_colsum_partial_b16")
+
+
+def disc_penalty(G, rows, cols, scale, partials, out32=None, out16=None, out32_off=0, out16_off=0, ld32=0, ld16=0):
+    """partials[block] = sum G^2; out32 / out16 (+ element offsets) = scale * G as fp32 / bf16."""
+    _chk(G, "G"), _chk(partials, "partials"), _chk(out32, "out32")
+    if out16 is not None and (out16.dtype != torch.int16 or not out16.is_cuda):
+        raise TypeError("disc_penalty: out16 must be an int16 CUDA tensor")
+    _lib.check(_lib.load().pulse_disc_penalty(G.data_ptr(), G.stride(0), rows, cols, float(scale),
+                                              (out32.data_ptr() + 4 * out32_off) if out32 is not None else None, ld32,
+                                              (out16.data_ptr() + 2 * out16_off) if out16 is not None else None, ld16,
+                                              partials.data_ptr(), partials.numel(), _stream()), "pulse_disc_penalty")
+
+
+def disc_reg(flat, grad, ranges, partials):
+    """ranges: [(offset, length, alpha)] (<= 4).  grad[off + i] += alpha * flat[off + i]; partials (blocks, 4) = per-block sums of flat[range]^2."""
+    _chk(flat, "flat"), _chk(grad, "grad"), _chk(partials, "partials")
+    n = len(ranges)
+    if not 1 <= n <= 4 or partials.dim() != 2 or partials.shape[1] != 4 or not partials.is_contiguous():
+        raise ValueError("disc_reg: 1..4 ranges, partials (blocks, 4) contiguous")
+    offs = (ctypes.c_int64 * n)(*[int(r[0]) for r in ranges])
+    lens = (ctypes.c_int64 * n)(*[int(r[1]) for r in ranges])
+    als = (ctypes.c_float * n)(*[float(r[2]) for r in ranges])
+    _lib.check(_lib.load().pulse_disc_reg(flat.data_ptr(), _p(grad), n, offs, lens, als, partials.data_ptr(), partials.shape[0], _stream()), "pulse_disc_reg")
+
+
+def disc_reward(logits, n, scale, out):
+    _chk(logits, "logits", contiguous=False), _chk(out, "out", contiguous=False)
+    _lib.check(_lib.load().pulse_disc_reward(logits.data_ptr(), logits.stride(0), n, float(scale), out.data_ptr(), out.stride(0), _stream()), "pulse_disc_reward")
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,

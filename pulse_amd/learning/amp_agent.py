@@ -95,6 +95,7 @@ class AMPAgent(CommonAgent):
             self.kin_step = 0
             self.kin_dict_info = None
         self.running_mean_std_temp = self.running_mean_std.clone_frozen()
+        self._disc_ring, self._disc_info_all, self._disc_pos = None, None, 0
         self.z_noise_provider = None                                      # tests inject the re-parameterisation noise
         self._kin_partials = None
 
@@ -170,8 +171,7 @@ class AMPAgent(CommonAgent):
             xs = self._amp_norm_scratch[:n]
             self._amp_input_mean_std.forward(amp_rows[c0:c0 + n], out=xs, out_cols=self._amp_pitch, update=False)
             logits = self.disc.eval_disc(self._amp_norm_scratch)[:n]
-            prob = 1 / (1 + torch.exp(-logits))
-            out[c0:c0 + n] = -torch.log(torch.maximum(1 - prob, torch.tensor(0.0001, device=self.ppo_device))) * self._disc_reward_scale
+            K.disc_reward(logits, n, self._disc_reward_scale, out[c0:c0 + n])
         return out
 
     def _rollout_rewards(self, td):
@@ -218,20 +218,49 @@ class AMPAgent(CommonAgent):
         rms.forward(rep_src, row_idx=rep_idx[sub] if rep_idx is not None else sub, out=X[b:2 * b], out_cols=self._amp_pitch)   # amp_obs_replay
         rms.forward(self._amp_obs_demo_buffer.data, row_idx=d["_amp_demo_idx"][sub], out=X[2 * b:3 * b], out_cols=self._amp_pitch)  # amp_obs_demo
         logits = self.disc.forward(ws)
-        # prediction loss, its logit gradients, accuracies and logit means in ONE launch (pulse_disc_head); the dict entries are views of
-        # this minibatch's own 8-float result row
-        st = torch.empty(8, dtype=torch.float32, device=self.ppo_device)
-        K.disc_head(logits, b, self._disc_coef / self.world_size, ws["dlogits"], st)
-        penalty = self.disc.backward(ws, self._disc_grad_penalty, self._disc_logit_reg, self._disc_weight_decay,
-                                     scale=self._disc_coef / self.world_size)
-        w3 = self.disc.get_disc_logit_weights()
-        logit_loss = torch.sum(torch.square(w3))
-        disc_loss = st[0] + self._disc_logit_reg * logit_loss + self._disc_grad_penalty * penalty
+        # prediction loss, its logit gradients, accuracies and logit means in ONE launch (pulse_disc_head); everything the reported losses
+        # need lands in one 12-float row: [disc_head's 8 | sum ||dD/dx||^2 | ||W1||^2 | ||W2||^2 | ||w3||^2]
+        lazy = self._lazy_info and self._disc_ring is not None and self._disc_pos < self._disc_ring.shape[0]
+        row = self._disc_ring[self._disc_pos] if lazy else torch.empty(12, dtype=torch.float32, device=self.ppo_device)
+        scale = self._disc_coef / self.world_size
+        if ws["b16"]:
+            K.disc_head_b16(logits, b, scale, ws["dL16"], row[:8])
+        else:
+            K.disc_head(logits, b, scale, ws["dlogits"], row[:8])
+        self.disc.backward(ws, self._disc_grad_penalty, self._disc_logit_reg, self._disc_weight_decay, scale=scale, stats=row[8:12])
+        if lazy:                                                   # reduced once at the end of train_epoch (_end_loss_ring)
+            out = self._disc_info_all[self._disc_pos]
+            self._disc_pos += 1
+        else:
+            out = self._disc_info(row.unsqueeze(0), b)[0]
+        return {"disc_loss": out[0], "disc_grad_penalty": out[1], "disc_logit_loss": out[2],
+                "disc_agent_acc": out[3], "disc_demo_acc": out[4], "disc_agent_logit": out[5], "disc_demo_logit": out[6]}
+
+    def _disc_info(self, raw, b, out=None):
+        """(n, 12) raw rows -> (n, 7): disc_loss (:895-952: prediction loss + logit regulariser + gradient penalty + weight decay),
+        penalty, logit loss, accuracies, logit means."""
+        out = torch.empty(raw.shape[0], 7, device=raw.device) if out is None else out
+        pen = raw[:, 8] / b
+        out[:, 0] = raw[:, 0] + self._disc_logit_reg * raw[:, 11] + self._disc_grad_penalty * pen
         if self._disc_weight_decay != 0:
-            wsum = sum(torch.sum(torch.square(self.disc.book.get(l.w.name))) for l in (self.disc.l1, self.disc.l2, self.disc.l3))
-            disc_loss = disc_loss + self._disc_weight_decay * wsum
-        return {"disc_loss": disc_loss, "disc_grad_penalty": penalty, "disc_logit_loss": logit_loss,
-                "disc_agent_acc": st[3], "disc_demo_acc": st[4], "disc_agent_logit": st[5], "disc_demo_logit": st[6]}
+            out[:, 0] += self._disc_weight_decay * (raw[:, 9] + raw[:, 10] + raw[:, 11])
+        out[:, 1], out[:, 2] = pen, raw[:, 11]
+        out[:, 3:7] = raw[:, 3:7]
+        return out
+
+    def _begin_loss_ring(self, slots):
+        super()._begin_loss_ring(slots)
+        self._disc_pos = 0
+        if self.enable_disc and self._lazy_info:
+            if self._disc_ring is None or self._disc_ring.shape[0] < slots:
+                self._disc_ring = torch.zeros(slots, 12, device=self.ppo_device)
+            self._disc_info_all = torch.zeros(slots, 7, device=self.ppo_device)     # fresh per epoch: last epoch's dicts stay valid
+
+    def _end_loss_ring(self):
+        if self.enable_disc and self._lazy_info and self._disc_pos:
+            n = self._disc_pos
+            self._disc_info(self._disc_ring[:n], self._amp_minibatch_size, out=self._disc_info_all[:n])
+        super()._end_loss_ring()
 
     # ------------------------------------------------------------------ checkpoint surface (amp_agent.py:81-118, 181-190)
     def get_stats_weights(self):

@@ -488,21 +488,29 @@ class CommonAgent:
         ws = net.workspace(mb, train=True)
         norm, live = self._obs_normalizer_for_update()
         xp = ws.get("xp")         # layer 1 on the planar GEMM: the normaliser also writes the operand's planes (see _preproc_obs)
+        b16 = bool(ws.get("b16"))  # mixed_precision on bf16 storage: the normaliser's output IS the bf16 layer-1 operand
+        x_out = ws["x16"] if b16 else ws["x"]
         if live is not None:      # AMPAgent: output from the frozen copy, live statistics still updated (one pass)
-            live.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch, norm_with=norm, planes=xp)
+            live.forward(obs_store, row_idx=idx, out=x_out, out_cols=net.in_pitch, norm_with=norm, planes=None if b16 else xp)
         else:
-            norm.forward(obs_store, row_idx=idx, out=ws["x"], out_cols=net.in_pitch, planes=xp)
-        if xp is not None:
+            norm.forward(obs_store, row_idx=idx, out=x_out, out_cols=net.in_pitch, planes=None if b16 else xp)
+        if b16:
+            ws["x16_fresh"] = True
+        elif xp is not None:
             ws["xp_fresh"] = True
         net.forward(ws, mb)
         ap = net.a_pitch
+        g16 = {}
+        if b16:                   # bf16 copies of d loss / d (mu, value): the operands of the bf16-storage backward
+            hp = ws["head_pitch16"]
+            g16 = dict(dmu16=ws["dheads16"], dmu16_stride=2 * hp, dvalue16=ws["dheads16"], dvalue16_stride=2 * hp, dvalue16_off=hp)
         K.ppo_loss(mu=ws["mu"], mu_stride=ws["mu"].stride(0), value=ws["val"], value_stride=ws["val"].stride(0), logstd=net.sigma,
                    old_logstd=net.sigma, idx=idx,
                    actions=act_store, actions_stride=act_store.stride(0), old_mu=mu_store, old_mu_stride=mu_store.stride(0),
                    old_neglogp=old_nlp, advantages=adv, old_values=old_val, returns=ret, rows=mb, num_actions=self.actions_num,
                    e_clip=self.e_clip, critic_coef=self.critic_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
                    dmu=ws["dmu"], dmu_stride=ws["dmu"].stride(0), dvalue=ws["dval"], dvalue_stride=ws["dval"].stride(0),
-                   partials=self._loss_slot())
+                   partials=self._loss_slot(), **g16)
         overlap = self.multi_gpu and self.overlap_allreduce and hasattr(net, "w_off")
         net.backward(ws, mb, grad_scale=1.0 / self.world_size, **({"on_bucket": self._bucket_ready} if overlap else {}))
         extra_info = self._extra_gradients(input_dict, idx)               # AMPAgent: discriminator loss / gradients

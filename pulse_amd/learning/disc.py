@@ -17,12 +17,22 @@ Both gradient paths of a weight are accumulated by STACKING them along the reduc
 rows [0, 3B) of the operand buffers hold the BCE path (dz, activations), rows [3B, 4B) the penalty path
 (u, d-terms), and one batch-split GEMM per weight reduces over all 4B rows.  Every product above is one of
 the three layouts of gemm_f32_kernel with the ReLU-mask epilogue; no autograd graph, no second-order tape.
+
+mixed_precision (the reference's autocast around calc_gradients, amp_agent.py:671): the same products on bf16 STORAGE -- X, H, Z and
+the logit gradients are bf16 matrices, the GEMMs are pulse_gemm_x3p(planes = 1), input-gradient products read W^T copies rebuilt once
+per pass so they run in the forward form, weight gradients go to the fp32 split-K slabs (``_plans_b16``).
 """
+import os
+
 import torch
 
 from .. import kernels as K
 from .._lib import ACT_NONE, ACT_RELU, EPI_RELU_GRAD, GEMM_OUT_CONTIG
 from .graph import Linear, ParamBook, init_linear_, r4
+
+
+def r32(x):
+    return (x + 31) // 32 * 32
 
 
 class DiscNetwork:
@@ -33,16 +43,21 @@ class DiscNetwork:
             raise NotImplementedError("discriminator: two ReLU hidden layers (every shipped config)")
         self.u1, self.u2 = units
         self.k0 = int(amp_input_dim)
-        self.k0p = r4(self.k0)
+        self.k0p = r32(self.k0)          # whole 32-deep k-tiles: X rows and W1 rows are zero-padded to it (what the bf16-storage GEMM reads)
         self.book = ParamBook(self.device, split_k)
-        self.l1 = Linear(self.book, "a2c_network._disc_mlp.0", self.k0, self.u1, ACT_RELU)
+        self.l1 = Linear(self.book, "a2c_network._disc_mlp.0", self.k0, self.u1, ACT_RELU, pitch_align=32)
         self.l2 = Linear(self.book, "a2c_network._disc_mlp.2", self.u1, self.u2, ACT_RELU)
         self.l3 = Linear(self.book, "a2c_network._disc_logits", self.u2, 1, ACT_NONE)
         self.book.finalize()
         self.flat, self.grad, self.n_flat = self.book.flat, self.book.grad, self.book.n_flat
         self._ws = {}
         self.mixed_precision = False      # True: the training passes (forward on the 3b rows, BCE / penalty backward, weight gradients) on the bf16 MFMA
+        self._flat16 = self._w1t16 = self._w2t16 = None
+        self._reg_partials = torch.zeros(256, 4, device=self.device)
         self.reset_parameters()
+
+    def b16_storage_ok(self):
+        return self.u1 % 32 == 0 and self.u2 % 32 == 0 and os.environ.get("PULSE_BF16_STORAGE", "1") != "0"
 
     def reset_parameters(self, generator=None):
         init_linear_(self.book, self.l1, generator)
@@ -75,22 +90,91 @@ class DiscNetwork:
 
     # ---- workspaces: b rows per stream (agent / replay / demo), 4b stacked rows
     def workspace(self, b):
-        ws = self._ws.get(b)
+        key = (b, bool(self.mixed_precision))
+        ws = self._ws.get(key)
         if ws is not None:
             return ws
         dev = self.device
         z = lambda r, c: torch.zeros(r, c, dtype=torch.float32, device=dev)
         m = 4 * b
-        ws = {"b": b, "X": z(m, self.k0p), "H1": z(m, self.u1), "H2": z(m, self.u2), "Z1": z(m, self.u1), "Z2": z(m, self.u2),
-              "L": z(m, 4), "dL": z(m, 4), "G": z(b, self.k0p)}
-        ws["dL"][3 * b:, 0] = 1.0                      # the penalty path's "ones" column for dw3
-        ws["pen_partials"] = z(1, 256).view(-1)
+        ws = {"b": b, "L": z(m, 4), "G": z(b, self.k0p), "pen_partials": z(1, 256).view(-1), "b16": bool(self.mixed_precision and self.b16_storage_ok())}
         ws["logits"] = ws["L"][:3 * b, :1]
-        ws["dlogits"] = ws["dL"][:3 * b, :1]
-        ws["fwd"] = self._plan_forward(ws, 3 * b, bf16=self.mixed_precision)
-        ws["bwd_bce"], ws["pen_fwd"], ws["pen_bwd"], ws["wgrad"] = self._plans_backward(ws)
-        self._ws[b] = ws
+        if ws["b16"]:
+            i16 = lambda r, c: torch.zeros(r, c, dtype=torch.int16, device=dev)
+            ws.update({"X": i16(m, self.k0p), "H1": i16(m, self.u1), "H2": i16(m, self.u2), "Z1": i16(m, self.u1), "Z2": i16(m, self.u2),
+                       "dL16": i16(m, 32)})
+            ws["dL16"][3 * b:, 0] = 0x3F80                  # bf16(1.0): the penalty path's "ones" column for dw3
+            if self._flat16 is None:
+                self._flat16 = i16(1, (self.n_flat + 7) // 8 * 8).view(-1)
+                self._w1t16 = i16(self.k0, self.u1)          # W1^T: dD/dx = u1 W1 in the forward form
+                self._w2t16 = i16(self.u1, self.u2)          # W2^T
+            ws["fwd"], ws["bwd_bce"], ws["pen_fwd"], ws["pen_bwd"], ws["wgrad"] = self._plans_b16(ws)
+        else:
+            ws.update({"X": z(m, self.k0p), "H1": z(m, self.u1), "H2": z(m, self.u2), "Z1": z(m, self.u1), "Z2": z(m, self.u2), "dL": z(m, 4)})
+            ws["dL"][3 * b:, 0] = 1.0                      # the penalty path's "ones" column for dw3
+            ws["dlogits"] = ws["dL"][:3 * b, :1]
+            ws["fwd"] = self._plan_forward(ws, 3 * b, bf16=self.mixed_precision)
+            ws["bwd_bce"], ws["pen_fwd"], ws["pen_bwd"], ws["wgrad"] = self._plans_backward(ws)
+        self._ws[key] = ws
         return ws
+
+    def _plans_b16(self, ws):
+        """The five plans of a training pass over bf16 operands (module docstring): forward on the 3b rows, BCE backward, penalty forward
+        (demo rows), penalty backward, weight / bias gradients over the 4b stacked rows."""
+        f, f16, b = self.flat, self._flat16, ws["b"]
+        u1, u2, k0, k0p = self.u1, self.u2, self.k0, self.k0p
+        S, P, slabs = self.book.split_k, self.book.n_flat, self.book.slabs
+        w1, w2, w3 = self.l1.w, self.l2.w, self.l3.w
+        X, H1, H2, Z1, Z2, dL = ws["X"], ws["H1"], ws["H2"], ws["Z1"], ws["Z2"], ws["dL16"]
+        r3, demo = 3 * b, 2 * b
+        slabs.zero_()                          # the slabs a weight-gradient launch does not write must read as zero
+        fwd = K.Plan()
+        fwd.refresh_b16(f, f16, self.n_flat)
+        fwd.gemm_b16(X, f16, M=r3, N=u1, K=k0, ldb=w1.pitch, b_off=w1.off, Cp=H1, bias=f, bias_off=self.l1.b.off, activation=ACT_RELU)
+        fwd.gemm_b16(H1, f16, M=r3, N=u2, K=u1, ldb=w2.pitch, b_off=w2.off, Cp=H2, bias=f, bias_off=self.l2.b.off, activation=ACT_RELU)
+        fwd.gemm_b16(H2, f16, M=r3, N=1, K=u2, ldb=w3.pitch, b_off=w3.off, C=ws["L"], ldc=4, bias=f, bias_off=self.l3.b.off)
+        # (1) BCE path over the 3b forward rows: dz2 = (dL w3) * m2 ; dz1 = (dz2 W2) * m1 -- the latter in the forward form over W2^T
+        bce = K.Plan()
+        bce.transpose_b16(f, self._w2t16, x_off=w2.off, rows=u2, cols=u1, ld_in=w2.pitch, ld_out=u2)
+        bce.transpose_b16(f, self._w1t16, x_off=w1.off, rows=u1, cols=k0, ld_in=w1.pitch, ld_out=u1)
+        bce.gemm_b16(dL, f16, M=r3, N=u2, K=1, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2)
+        bce.gemm_b16(Z2, self._w2t16, M=r3, N=u1, K=u2, Cp=Z1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1)
+        # (2a) penalty forward on the demo rows (stacked as rows 3b..): u2 = m2 * w3, u1 = m1 * (u2 W2), g = u1 W1 (fp32: its square sum is the penalty)
+        pf = K.Plan()
+        pf.gemm_b16(dL, f16, M=b, N=u2, K=1, a_off=r3 * 32, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, cp_off=r3 * u2,
+                    epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2, aux_off=demo * u2)
+        pf.gemm_b16(Z2, self._w2t16, M=b, N=u1, K=u2, a_off=r3 * u2, Cp=Z1, cp_off=r3 * u1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1, aux_off=demo * u1)
+        pf.gemm_b16(Z1, self._w1t16, M=b, N=k0, K=u1, a_off=r3 * u1, C=ws["G"], ldc=k0p)
+        # (2b) penalty backward: dt1 = (dg W1^T) * m1 -> H1[3b:] ;  m2 * (dt1 W2^T) -> H2[3b:]      (dg lives in X[3b:]); W as stored = forward form
+        pb = K.Plan()
+        pb.gemm_b16(X, f16, M=b, N=u1, K=k0, a_off=r3 * k0p, ldb=w1.pitch, b_off=w1.off, Cp=H1, cp_off=r3 * u1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1,
+                    aux_off=demo * u1)
+        pb.gemm_b16(H1, f16, M=b, N=u2, K=u1, a_off=r3 * u1, ldb=w2.pitch, b_off=w2.off, Cp=H2, cp_off=r3 * u2, epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2,
+                    aux_off=demo * u2)
+        # (3) weight gradients over all 4b stacked rows (fp32 slabs), bias gradients = column sums over the 3b BCE rows (slab 0)
+        wg = K.Plan()
+        m = 4 * b
+        t256 = lambda mm, nn: ((mm + 255) // 256) * ((nn + 127) // 128)
+        wg.gemm_b16(Z1, X, M=u1, N=k0, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=w1.pitch, c_off=w1.off,
+                    split_k=K.dw_split(t256(u1, k0), S, fill=256), split_stride=P)
+        # the two small outputs would leave most of the chip idle at S splits (16 and 4 tiles of 256 x 128): they are split wider into a
+        # scratch whose ordered sum lands in slab 0 (slabs 1.. of these regions stay zero)
+        def wide(A, B, M_, N_, lin, lda_note=None):
+            tiles = t256(M_, N_)
+            split = 1
+            while tiles * split < 256 and split < 64 and m // (2 * split) >= 96:
+                split *= 2
+            count = lin.rows * lin.pitch
+            scr = torch.zeros(split, r4(count), dtype=torch.float32, device=self.device)
+            ws.setdefault("_w_scratch", []).append(scr)
+            wg.gemm_b16(A, B, M=M_, N=N_, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=scr, ldc=lin.pitch, split_k=split,
+                        split_stride=scr.stride(0))
+            wg.call("pulse_reduce_slabs", scr.data_ptr(), split, scr.stride(0), count, slabs.data_ptr() + 4 * lin.off, 1.0)
+        wide(Z2, H1, u2, u1, w2)
+        wide(dL, H2, 1, u2, w3)
+        for buf, n, ld, off in ((Z1, u1, u1, self.l1.b.off), (Z2, u2, u2, self.l2.b.off), (dL, 1, 32, self.l3.b.off)):
+            wg.colsum_b16(buf, r3, n, ld, slabs, S, P, off)                # one partial row per gradient slab: summed by the slab reduce
+        return fwd, bce, pf, pb, wg
 
     def _plan_forward(self, ws, m, x=None, logits=None, bf16=False):
         f = self.flat
@@ -165,24 +249,31 @@ class DiscNetwork:
         ws["fwd"].run()
         return ws["logits"]
 
-    def backward(self, ws, grad_penalty_coef, logit_reg, weight_decay, scale=1.0):
-        """ws['dlogits'] holds d(total loss)/d logit for the 3b rows.  Adds the gradient penalty, logit regulariser
-        and weight decay (each times ``scale`` = disc_coef) and leaves the flat gradient in self.grad.
-        Returns the penalty value mean_demo ||dD/dx||^2 (device scalar)."""
+    def backward(self, ws, grad_penalty_coef, logit_reg, weight_decay, scale=1.0, stats=None):
+        """ws['dlogits'] (fp32 storage) / ws['dL16'] (bf16 storage) holds d(total loss)/d logit for the 3b rows.  Adds the gradient penalty,
+        logit regulariser and weight decay (each times ``scale`` = disc_coef) and leaves the flat gradient in self.grad.
+        Returns the penalty value mean_demo ||dD/dx||^2 (device scalar).  ``stats``: optional (4,) float tensor that receives
+        [sum ||dD/dx||^2 over the demo rows, ||W1||^2, ||W2||^2, ||w3||^2] for the caller's loss bookkeeping (no extra launches)."""
         b = ws["b"]
         ws["bwd_bce"].run()
         ws["pen_fwd"].run()
-        # mean_demo ||dD/dx||^2: sum of squares of the whole (b, k0p) buffer (its pad columns are never written and stay zero)
-        K.sqnorm_partial(ws["G"], ws["G"].numel(), ws["pen_partials"])
-        penalty = ws["pen_partials"].sum() / b
-        torch.mul(ws["G"], 2.0 * grad_penalty_coef * scale / b, out=ws["X"][3 * b:])      # dg
+        # mean_demo ||dD/dx||^2 and dg = 2 c g / b (the seed of the penalty's backward pass, rows 3b.. of X) in one launch; G's pad columns
+        # are never written and stay zero
+        X = ws["X"]
+        c = 2.0 * grad_penalty_coef * scale / b
+        if ws["b16"]:
+            K.disc_penalty(ws["G"], b, self.k0p, c, ws["pen_partials"], out16=X, out16_off=3 * b * self.k0p, ld16=self.k0p)
+        else:
+            K.disc_penalty(ws["G"], b, self.k0p, c, ws["pen_partials"], out32=X, out32_off=3 * b * self.k0p, ld32=self.k0p)
         ws["pen_bwd"].run()
         ws["wgrad"].run()
         self.book.reduce_grads()
-        gw = self.book.get
-        if logit_reg:
-            gw(self.l3.w.name, self.grad).add_(gw(self.l3.w.name), alpha=2.0 * logit_reg * scale)
-        if weight_decay:
-            for lin in (self.l1, self.l2, self.l3):
-                gw(lin.w.name, self.grad).add_(gw(lin.w.name), alpha=2.0 * weight_decay * scale)
-        return penalty
+        # logit regulariser + weight decay gradients (grad += 2 coef scale W) and the three ||W||^2 in one launch
+        rp = self._reg_partials
+        K.disc_reg(self.flat, self.grad, [(lin.w.off, lin.w.rows * lin.w.pitch, 2.0 * scale * (weight_decay + (logit_reg if lin is self.l3 else 0.0)))
+                                          for lin in (self.l1, self.l2, self.l3)], rp)
+        pen_sum = ws["pen_partials"].sum()
+        if stats is not None:
+            stats[0] = pen_sum
+            torch.sum(rp[:, :3], dim=0, out=stats[1:4])
+        return pen_sum / b

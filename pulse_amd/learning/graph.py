@@ -46,11 +46,12 @@ class ParamBook:
         self._n = 0
         self.flat = None
 
-    def add(self, name, rows, cols, colmap=None):
+    def add(self, name, rows, cols, colmap=None, pitch_align=4):
         """rows x cols logical matrix (cols = 1 row vector for biases when rows == 1).  ``colmap``: list
-        of physical column indices of the logical columns (default identity); physical pitch = r4(max+1)."""
+        of physical column indices of the logical columns (default identity); physical pitch = roundup(max+1, pitch_align) (the
+        bf16-storage GEMM wants reduction-contiguous rows that are whole zero-padded 32-deep k-tiles: pitch_align 32)."""
         phys = (max(colmap) + 1) if colmap is not None else cols
-        pitch = r4(phys)
+        pitch = (phys + pitch_align - 1) // pitch_align * pitch_align
         p = Param(name, rows, cols, list(colmap) if colmap is not None else None, self._n, pitch)
         self.params[name] = p
         self._n += rows * pitch
@@ -115,9 +116,9 @@ class ParamBook:
 class Linear:
     """y[:, dst] = act(x[:, src] @ W^T + b).  ``in_width`` is the PHYSICAL input width (gaps included)."""
 
-    def __init__(self, book, name, in_features, out_features, act=ACT_NONE, colmap=None, w_name=None, b_name=None):
+    def __init__(self, book, name, in_features, out_features, act=ACT_NONE, colmap=None, w_name=None, b_name=None, pitch_align=4):
         self.name, self.n, self.act = name, out_features, act
-        self.w = book.add(w_name or f"{name}.weight", out_features, in_features, colmap)
+        self.w = book.add(w_name or f"{name}.weight", out_features, in_features, colmap, pitch_align=pitch_align)
         self.b = book.add(b_name or f"{name}.bias", 1, out_features)
         self.k_phys = (max(colmap) + 1) if colmap is not None else in_features
         self.k_logical = in_features

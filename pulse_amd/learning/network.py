@@ -65,6 +65,7 @@ class A2CNetwork:
         self.grad = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
         self.sigma = torch.zeros(self.actions_num, dtype=torch.float32, device=self.device)   # log-std, non-learned
         self._slabs = None
+        self._flat16 = self._wt16 = None     # bf16 image of the flat parameters / transposed upper-layer weights (mixed_precision, built on demand)
         self._ws = {}
         # PULSE_L1_PLANAR=1: layer-1 forward on the planar GEMM (gemm_x3p.hip; same six-product arithmetic), its input planes written by the
         # normaliser.  OFF by default -- measured in situ on cfg2 (A/B in one gpurun call): the GEMM itself gains 11 % (196.6 vs
@@ -207,7 +208,7 @@ class A2CNetwork:
         ws['h'][l]   (m, 2*u_l)      hidden activations [actor | critic]
         ws['heads']  (m, 2*a_pitch)  [mu (A cols) .. | value at col a_pitch ..]
         train: ws['dheads'] (m, 2*a_pitch) = [d loss/d mu | d loss/d value at col a_pitch], ws['dh'][l]."""
-        key = (m, bool(train))
+        key = (m, bool(train), bool(self.mixed_precision))
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -229,21 +230,114 @@ class A2CNetwork:
                 self._w1p = K.alloc_planes(2 * u[0], self.in_dim, dev)
             ws["plan_fwd_planar"] = self._plan_forward(ws, m, 0, 2, planar=True)
             ws["plan_critic_planar"] = self._plan_forward(ws, m, 1, 1, planar=True)
+        ws["b16"] = bool(train and self.mixed_precision and self.b16_storage_ok())
         if train:
-            ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, bf16=True) if self.mixed_precision else ws["plan_fwd"]
-            ws["dh"] = [e(m, 2 * uu) for uu in u]
             ws["dheads"] = torch.zeros(m, 2 * self.a_pitch, dtype=torch.float32, device=dev)
             ws["dmu"] = ws["dheads"][:, :self.actions_num]
             ws["dval"] = ws["dheads"][:, self.a_pitch:self.a_pitch + 1]
+            if ws["b16"]:
+                # bf16-STORAGE training passes (mixed_precision): the normalised input, every hidden activation and every gradient of this
+                # workspace is a bf16 matrix in HBM (int16 bit patterns), the GEMMs are pulse_gemm_x3p(planes = 1).  Same arithmetic as the
+                # fp32-storage bf16 kernel -- there every operand is rounded to bf16 on its way into LDS and every output leaves
+                # bf16-representable -- at half the operand traffic, which is what bounded that kernel.
+                i16 = lambda r, c: torch.zeros(r, c, dtype=torch.int16, device=dev)
+                hp = _r32(self.head_rows)
+                ws["x16"] = i16(m, self.in_pitch)
+                ws["h16"] = [i16(m, 2 * uu) for uu in u]
+                ws["dz16"] = [i16(m, 2 * uu) for uu in u]
+                ws["dheads16"] = i16(m, 2 * hp)                              # [d mu (A) .. zero pad to hp | d value, zero pad]: written by ppo_loss
+                ws["head_pitch16"] = hp
+                if self._flat16 is None:
+                    self._flat16 = i16(1, (self.n_flat + 7) // 8 * 8).view(-1)
+                    self._wt16 = [None] + [i16(2 * u[l - 1], u[l]) for l in range(1, len(u))]     # W_l^T of both nets: (2, u_{l-1}, u_l)
+                ws["plan_fwd_train"] = self._plan_forward_b16(ws, m)
+            else:
+                ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, bf16=True) if self.mixed_precision else ws["plan_fwd"]
+                ws["dh"] = [e(m, 2 * uu) for uu in u]
             if self._slabs is None:
                 self._slabs = torch.zeros(self.split_k, self.n_flat, dtype=torch.float32, device=dev)
                 self._bias_chunks = 64
                 self._bias_scratch = torch.zeros(self._bias_chunks, 2 * max(max(u), self.a_pitch) + 8, dtype=torch.float32, device=dev)
                 self._head_split = 32
                 self._head_scratch = torch.zeros(self._head_split, self.bh_off - self.wh_off + 2 * self.a_pitch, dtype=torch.float32, device=dev)
-            ws["plan_bwd"] = self._plan_backward(ws, m)
+            ws["plan_bwd"] = self._plan_backward_b16(ws, m) if ws["b16"] else self._plan_backward(ws, m)
         self._ws[key] = ws
         return ws
+
+    def b16_storage_ok(self):
+        """The bf16-storage GEMM reads reduction-contiguous operands in whole 32-deep k-tiles and 16-byte pieces: every hidden width has to
+        be a multiple of 32 (the flat weight rows then ARE zero-padded k-tiles) and the input pitch already is.  Other shapes keep the
+        fp32-storage bf16 kernel."""
+        return (self.act in (ACT_RELU, ACT_SILU) and all(uu % 32 == 0 for uu in self.units) and self.in_pitch % 32 == 0
+                and os.environ.get("PULSE_BF16_STORAGE", "1") != "0")
+
+    # ------------------------------------------------------------------ bf16-storage training plans (mixed_precision)
+    def _plan_forward_b16(self, ws, m):
+        """Actor + critic training forward over bf16 operands: x16 -> h16[l] -> heads (fp32: the loss kernel reads them)."""
+        u, f, f16 = self.units, self.flat, self._flat16
+        pre = ws.get("z")
+        p = K.Plan()
+        p.refresh_b16(f, f16, self.n_flat)
+        for l, uu in enumerate(u):
+            if l == 0:
+                k = self.in_w[0]
+                p.gemm_b16(ws["x16"], f16, M=m, N=2 * uu, K=self.in_dim, ldb=k, b_off=self.w_off[0], Cp=ws["h16"][0], bias=f, bias_off=self.b_off[0],
+                           activation=self.act, C2=pre[0] if pre else None, ldc2=2 * uu)
+            else:
+                up = u[l - 1]
+                p.gemm_b16(ws["h16"][l - 1], f16, M=m, N=uu, K=up, ldb=up, b_off=self.w_off[l], batch=2, stride_a=up, stride_b=uu * up,
+                           Cp=ws["h16"][l], stride_cp=uu, bias=f, bias_off=self.b_off[l], stride_bias=uu, activation=self.act,
+                           C2=pre[l] if pre else None, ldc2=2 * uu, stride_c2=uu)
+        uL, ap, hr = u[-1], self.a_pitch, self.head_rows
+        p.gemm_b16(ws["h16"][-1], f16, M=m, N=hr, K=uL, ldb=uL, b_off=self.wh_off, batch=2, stride_a=uL, stride_b=hr * uL, C=ws["heads"], ldc=2 * ap,
+                   stride_c=ap, bias=f, bias_off=self.bh_off, stride_bias=ap, algo_n=(self.actions_num + 1) / 2.0)
+        return p
+
+    def _plan_backward_b16(self, ws, m):
+        """Backward over bf16 operands.  Same order as _plan_backward (dX chain, layer-1 weight gradient, then the rest: the data-parallel
+        bucket split).  Input gradients run in the FORWARD form over W^T copies rebuilt at the head of the plan; weight gradients read
+        dZ and the activations in their natural row-major storage (both [red][out]) into the fp32 split-K slabs; bias gradients are
+        column sums of the bf16 dZ matrices (slab 0)."""
+        u, f, f16, S = self.units, self.flat, self._flat16, self.split_k
+        L, uL, ap, hr, hp = len(u), u[-1], self.a_pitch, self.head_rows, ws["head_pitch16"]
+        slabs, P = self._slabs, self.n_flat
+        slabs.zero_()                       # the slabs a layer's weight-gradient launch does not write must read as zero
+        egrad = EPI_RELU_GRAD if self.act == ACT_RELU else EPI_SILU_GRAD
+        aux = ws["h16"] if self.act == ACT_RELU else ws["z"]
+        ld_aux = lambda t: t.stride(0)
+        dz, h16, dh16 = ws["dz16"], ws["h16"], ws["dheads16"]
+        p = K.Plan()
+        for l in range(1, L):               # W_l^T (bf16) of both nets: out (2, u_{l-1}, u_l)
+            p.transpose_b16(f, self._wt16[l], x_off=self.w_off[l], rows=u[l], cols=u[l - 1], ld_in=u[l - 1], ld_out=u[l], batch=2,
+                            stride_in=u[l] * u[l - 1], stride_out=u[l - 1] * u[l])
+        # heads -> dZ_L of both nets (K = head rows: tiny; W_heads read as the [red][out] operand it is)
+        p.gemm_b16(dh16, f16, M=m, N=uL, K=hr, ldb=uL, b_off=self.wh_off, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=hp, stride_b=hr * uL,
+                   Cp=dz[-1], stride_cp=uL, epilogue=egrad, aux=aux[-1], ldaux=ld_aux(aux[-1]), stride_aux=uL, algo_k=(self.actions_num + 1) / 2.0)
+        for l in range(L - 1, 0, -1):
+            uu, up = u[l], u[l - 1]
+            p.gemm_b16(dz[l], self._wt16[l], M=m, N=up, K=uu, ldb=uu, batch=2, stride_a=uu, stride_b=up * uu, Cp=dz[l - 1], stride_cp=up,
+                       epilogue=egrad, aux=aux[l - 1], ldaux=ld_aux(aux[l - 1]), stride_aux=up)
+        uu, k = u[0], self.in_w[0]
+        s1 = self._l0_slabs = K.dw_split(((2 * uu + 255) // 256) * ((k + 127) // 128), S, fill=256)
+        p.gemm_b16(dz[0], ws["x16"], M=2 * uu, N=k, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=k, c_off=self.w_off[0],
+                   split_k=s1, split_stride=P, algo_n=self.in_dim)
+        p.colsum_b16(dz[0], m, 2 * uu, 2 * uu, slabs, s1, P, self.b_off[0])      # the layer-1 bucket is reduced over its own s1 slabs
+        p.split = len(p.ops)
+        hs, HS = self._head_scratch, self._head_split if m >= 96 * self._head_split else 1
+        hb = self.bh_off - self.wh_off
+        p.gemm_b16(dh16, h16[-1], M=hr, N=uL, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=hp, stride_b=uL, C=hs, ldc=uL,
+                   stride_c=hr * uL, split_k=HS, split_stride=hs.stride(0), algo_k=m * (self.actions_num + 1) / (2.0 * hr))
+        # head bias gradients: column sums of [d mu | pad] and [d value | pad] into the scratch rows' bias columns (b_mu: A entries, b_value: 1)
+        p.colsum_b16(dh16, m, ap, 2 * hp, hs, HS, hs.stride(0), hb)
+        p.colsum_b16(dh16, m, ap, 2 * hp, hs, HS, hs.stride(0), hb + ap, x_off=hp)
+        p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), hb + 2 * ap, slabs.data_ptr() + 4 * self.wh_off, 1.0)
+        for l in range(L - 1, 0, -1):
+            uu, up = u[l], u[l - 1]
+            sl = K.dw_split(2 * ((uu + 255) // 256) * ((up + 127) // 128), S, fill=256)
+            p.gemm_b16(dz[l], h16[l - 1], M=uu, N=up, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up,
+                       C=slabs, ldc=up, stride_c=uu * up, c_off=self.w_off[l], split_k=sl, split_stride=P)
+            p.colsum_b16(dz[l], m, 2 * uu, 2 * uu, slabs, S, P, self.b_off[l])
+        return p
 
     def _plan_forward(self, ws, m, n0, cnt, bf16=False, planar=False):
         """nets n0 .. n0+cnt-1 (0 = actor, 1 = critic)."""
@@ -282,6 +376,13 @@ class A2CNetwork:
         """Actor + critic forward on the normalised input in ws['x'] -> ws['heads'] (mu | value)."""
         if self._take_planes(ws):
             ws["plan_fwd_planar"].run()
+            return
+        if self.training and ws.get("b16"):
+            # bf16-storage training pass: the normaliser wrote ws['x16'] directly (the caller raised ws['x16_fresh']); anyone who filled the
+            # fp32 ws['x'] instead gets it rounded here
+            if not ws.pop("x16_fresh", False):
+                K.to_b16(ws["x"], ws["x16"])
+            ws["plan_fwd_train"].run()
             return
         (ws["plan_fwd_train"] if (self.training and "plan_fwd_train" in ws) else ws["plan_fwd"]).run()
 

@@ -70,7 +70,9 @@ struct XpGeom {
     static constexpr int A_IMG = 3 * A_PLANE, B_IMG = 3 * B_PLANE, STAGE = A_IMG + B_IMG;
     static constexpr int CPF = PBN + 4;                          // epilogue transpose pitch (floats)
     static constexpr int EPI_BYTES = BM * CPF * 4;
-    static constexpr int LDS = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    static constexpr int TOUCH_LDS = 256 * NW;                  // landing strip of the L2 touch loads (single-plane mode): 256 B per wave
+    static constexpr int LDS = (2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES) + TOUCH_LDS;
+    static constexpr int TOUCH_OFF = LDS - TOUCH_LDS;
 };
 
 __device__ __forceinline__ unsigned xp_pack_rn(float lo, float hi) { return split_pack_rn(lo, hi); }
@@ -174,6 +176,39 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j) issue_unit(stage_off, t, j);
     };
+    // ---- L2 touch prefetch (single-plane mode).  Counters (profiles/r04_gemm_b16_pmc.txt): the bf16 kernel is not limited by the matrix pipe
+    // or by power but by the latency of its stage DMA -- pipe 0.17-0.29 busy at 2.2-2.5 GHz, waves waiting 0.42-0.83 of their cycles: with two
+    // stages in LDS only ONE stage of DMA is ever in flight, and a stage that misses L2 costs ~2 us against 0.6 us of MFMAs.  gfx950 has no
+    // prefetch instruction, so TOUCH_AHEAD stages ahead every 128-byte line of the stage is touched by a 4-byte LDS-DMA load into a scratch
+    // strip (no VGPR destination, no register hazard): the line is in L2 when the real DMA asks for it.  One wave instruction touches 64
+    // lines; the touches are dealt round-robin to the waves and ALWAYS issued (past the reduction's end the buffer range check drops them),
+    // so every wave has the same number of vector-memory operations in flight and the barrier waits can count them (vmcnt is in order).
+    constexpr int TOUCH_AHEAD = 4;
+    constexpr int LPR_A = BM * 2 / 128, LPR_B = PBN * 2 / 128;                 // lines per k row of a [red][out] tile
+    // Only [red][out] operands are touched (the weight-gradient form: 354 -> 461 TFLOP/s in situ).  Measured on the forward form the touches
+    // cost more than they return (491 -> 397 TFLOP/s: its stage is 16-row x 64-byte pieces, twelve more 64-line instructions per stage on
+    // the same texture path the DMA uses), so reduction-contiguous operands are left alone.
+    constexpr int TCH_A = AKC ? 0 : 96 * LPR_A / 64, TCH_B = BKC ? 0 : 96 * LPR_B / 64;   // wave instructions per stage
+    constexpr int TPW = (NPL == 1 && TCH_A + TCH_B > 0) ? (TCH_A + TCH_B + NW - 1) / NW : 0;   // per wave (padded: the extra ones re-touch)
+    auto touch_stage = [&](int t) {
+        if constexpr (TPW > 0) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int u = (wave + j * NW) % (TCH_A + TCH_B);               // wave-uniform
+                int vo, so;
+                if (u < TCH_A) {
+                    if constexpr (AKC) { vo = ((32 * u + (lane >> 1)) * g.lda) * 2 + (lane & 1) * 128; so = 3 * t * ktA; }
+                    else { const int q = 64 * u + lane; vo = (q / LPR_A) * g.lda * 2 + (q % LPR_A) * 128; so = 3 * t * ktA; }
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA[0], (lds_void_t*)(xp_smem + G::TOUCH_OFF + wave * 256), 4, vo, so, 0, 0);
+                } else {
+                    const int ub = u - TCH_A;
+                    if constexpr (BKC) { vo = ((32 * ub + (lane >> 1)) * g.ldb) * 2 + (lane & 1) * 128; so = 3 * t * ktB; }
+                    else { const int q = 64 * ub + lane; vo = (q / LPR_B) * g.ldb * 2 + (q % LPR_B) * 128; so = 3 * t * ktB; }
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[0], (lds_void_t*)(xp_smem + G::TOUCH_OFF + wave * 256), 4, vo, so, 0, 0);
+                }
+            }
+        }
+    };
 
     // ---- fragment read addresses (bytes, per lane; the sub-tile and the stage are immediates / added constants)
     //   KC: lane (l31, half) of k-step ks reads row (tile row + l31), chunk 2 ks + half -> slot (2 ks + half) ^ ((l31 >> 2) & 3)
@@ -262,11 +297,14 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
     // ---- prologue: stages 0 and 1 on their way, stage 0 landed, first fragments read
+#pragma unroll
+    for (int a = 2; a < TOUCH_AHEAD - 1; ++a) touch_stage(a);
     if (nkt > 0) issue_tile(0, 0);
     if (nkt > 1) issue_tile(G::STAGE, 1);
+    touch_stage(TOUCH_AHEAD - 1);                                   // youngest: the only thing allowed in flight behind a stage's DMA at a barrier
     __builtin_amdgcn_sched_barrier(0);
-    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + TPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TPW) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (nkt > 0) {
 #pragma unroll
@@ -284,12 +322,13 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
         kstep(I0{}, live, [&](int q) { if (q < 12) frag_unit(I1{}, q, CUR, 1); });
         // every wave has read what it needs of this stage (its reads are issued; lgkmcnt(0) completes them); stage t + 1 has landed
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TPW) : "memory");   // stage t + 1 has landed; the touches behind it may still fly
         __builtin_amdgcn_sched_barrier(0);
         kstep(I1{}, live, [&](int q) {
             if (q < 12) frag_unit(I0{}, q, OTH, 0);
             constexpr int D0 = NPL == 3 ? 12 : 0;
             if (q >= D0 && q - D0 < DMA_PER_WAVE) { if (more2) issue_unit(CUR, t + 2, q - D0); }
+            if (q == NQ - 1) touch_stage(t + TOUCH_AHEAD);
         });
     };
     for (int t = 0; t < nkt; t += 2) {

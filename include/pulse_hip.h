@@ -563,6 +563,10 @@ int pulse_transpose_to_b16(const float* in, int64_t ld_in, int32_t rows_in, int3
  * the weight gradients need anyway (what pulse_gemm_desc.rowsum does for the fp32-storage kernels). */
 int pulse_colsum_partial_b16(const void* x, int32_t m, int32_t n, int64_t ld, int32_t num_chunks, float* partial, int64_t ld_partial,
                              pulse_stream_t s);
+/* partial[c][n] = sum over chunk c's rows of w[m * w_stride] * x[m][n] (w bf16): the weight gradient of a ONE-output Linear -- the
+ * discriminator's logit layer (amp_network_builder.py:233-237: d w3 = sum_m dlogit[m] h2[m][:]) -- without a 1 x n GEMM. */
+int pulse_colsum_weighted_b16(const void* x, int32_t m, int32_t n, int64_t ld, const void* w, int64_t w_stride, int32_t num_chunks,
+                              float* partial, int64_t ld_partial, pulse_stream_t s);
 /* AMPAgent._disc_loss gradient penalty (amp_agent.py:925-934) on g = dD/dx of the demo rows (rows x cols fp32, pad columns zero):
  * partials[block] = sum of g^2 over the block's share; out32 / out16 (either may be NULL) = scale * g, the seed of the penalty's backward
  * pass (scale = 2 disc_grad_penalty disc_coef / (world_size rows)). */
@@ -573,6 +577,14 @@ int pulse_disc_penalty(const float* g, int64_t ldg, int32_t rows, int32_t cols, 
  * offsets / lengths / alphas are HOST arrays of num_ranges entries. */
 int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int64_t* offsets, const int64_t* lengths, const float* alphas,
                    float* partials, int32_t num_blocks, pulse_stream_t s);
+/* The split-K slab reduce of a whole flat gradient buffer in one launch, region by region (each region = a range of the flat layout with the
+ * number of slabs its weight-gradient launch wrote): out[off + i] = scale * sum_s slabs[s * slab_stride + off + i] + alpha_r * flat[off + i]
+ * (the regularisers of pulse_disc_reg; alphas / flat may be NULL).  sq_partials[block] (optional) = the block's share of sum out^2 -- the
+ * clip_grad_norm_ input (common_agent.py:472-478) without a pass of its own -- and w2_partials[block * 8 + r] (optional) the share of
+ * sum flat[region r]^2.  offsets / counts / nslabs / alphas are HOST arrays of num_regions <= 8 entries; offsets and counts multiples of 4. */
+int pulse_reduce_grads(const float* slabs, int64_t slab_stride, int32_t num_regions, const int64_t* offsets, const int64_t* counts,
+                       const int32_t* nslabs, const float* alphas, float* out, float scale, const float* flat, float* sq_partials,
+                       float* w2_partials, int32_t num_blocks, pulse_stream_t s);
 /* AMPAgent._calc_disc_rewards (amp_agent.py:1027-1041): out[i * out_stride] = -log(max(1 - sigmoid(logits[i * logit_stride]), 1e-4)) * scale */
 int pulse_disc_reward(const float* logits, int64_t logit_stride, int64_t n, float scale, float* out, int64_t out_stride, pulse_stream_t s);
 

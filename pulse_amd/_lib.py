@@ -275,8 +275,10 @@ SIGNATURES = {
     "pulse_rms_normalize_b16": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, P, c_int64, c_int32, P, c_int32, P]),
     "pulse_transpose_to_b16": (c_int, [P, c_int64, c_int32, c_int32, P, c_int64, c_int32, c_int64, c_int64, P]),
     "pulse_colsum_partial_b16": (c_int, [P, c_int32, c_int32, c_int64, c_int32, P, c_int64, P]),
+    "pulse_colsum_weighted_b16": (c_int, [P, c_int32, c_int32, c_int64, P, c_int64, c_int32, P, c_int64, P]),
     "pulse_disc_penalty": (c_int, [P, c_int64, c_int32, c_int32, c_float, P, c_int64, P, c_int64, P, c_int32, P]),
     "pulse_disc_reg": (c_int, [P, P, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_float), P, c_int32, P]),
+    "pulse_reduce_grads": (c_int, [P, c_int64, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_float), P, c_float, P, P, P, c_int32, P]),
     "pulse_disc_reward": (c_int, [P, c_int64, c_int64, c_float, P, c_int64, P]),
     "pulse_disc_head_b16": (c_int, [P, c_int64, c_int32, c_float, P, c_int64, P, c_int64, P, P]),
     "pulse_rms_update": (c_int, [P, P, P, P, c_int32, c_int32, c_double, c_double, P]),

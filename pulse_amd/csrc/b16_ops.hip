@@ -62,33 +62,50 @@ __global__ void __launch_bounds__(256) transpose_to_b16_kernel(const float* __re
 // chunks); CG = 4: 32 columns per workgroup, for the launches that write one partial row per GRADIENT SLAB (num_chunks = the book's
 // split-K count, partial = the slabs themselves): the bias gradient then needs no reduce launch of its own -- the slab reduce that the
 // weight gradients need anyway sums it -- and the few chunks still give every CU a workgroup.
-template <int CG>
+// ``w`` (optional): per-row bf16 weights (stride ws elements): partial = sum_m w[m] X[m][n] -- the weight gradient of a one-output Linear
+// (the discriminator's logit layer: d w3 = sum_m dlogit[m] H2[m][:]) without a 1 x n GEMM and its reduce.
+template <int CG, int NACC>
 __global__ void __launch_bounds__(256) colsum_partial_b16_kernel(const unsigned short* __restrict__ X, int M, int N, long long ld, int rows_per_chunk,
-                                                                float* __restrict__ partial, long long ldp) {
+                                                                float* __restrict__ partial, long long ldp, const unsigned short* __restrict__ w,
+                                                                long long ws) {
     constexpr int RL = 256 / CG;
     __shared__ float red[RL][CG][9];
     const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
     const int c = blockIdx.x * (CG * 8) + cg * 8;
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(M, r0 + rows_per_chunk);
-    float s[4][8];
+    float s[NACC][8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NACC; ++q)
 #pragma unroll
         for (int k = 0; k < 8; ++k) s[q][k] = 0.f;
     if (c < N) {
         const unsigned short* p = X + c;
         auto add = [&](int q, int r) {
             const b16_u32x4 t = *reinterpret_cast<const b16_u32x4*>(p + (long long)r * ld);
+            if (w) {
+                const float wv = split_bitsf((unsigned)w[(long long)r * ws] << 16);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { s[q][2 * k] += split_bitsf(t[k] << 16); s[q][2 * k + 1] += split_bitsf(t[k] & 0xffff0000u); }
+                for (int k = 0; k < 4; ++k) { s[q][2 * k] += wv * split_bitsf(t[k] << 16); s[q][2 * k + 1] += wv * split_bitsf(t[k] & 0xffff0000u); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[q][2 * k] += split_bitsf(t[k] << 16); s[q][2 * k + 1] += split_bitsf(t[k] & 0xffff0000u); }
+            }
         };
         int r = r0 + rl;
-        for (; r + 3 * RL < r1; r += 4 * RL) { add(0, r); add(1, r + RL); add(2, r + 2 * RL); add(3, r + 3 * RL); }
+        for (; r + (NACC - 1) * RL < r1; r += NACC * RL) {
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) add(q, r + q * RL);
+        }
         for (; r < r1; r += RL) add(0, r);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[rl][cg][k] = (s[0][k] + s[1][k]) + (s[2][k] + s[3][k]);
+    for (int k = 0; k < 8; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) t += s[q][k];
+        red[rl][cg][k] = t;
+    }
     __syncthreads();
     // 8 * CG output columns, one thread each: the RL row lanes' sums added in lane order
     if (threadIdx.x < 8 * CG) {
@@ -97,7 +114,7 @@ __global__ void __launch_bounds__(256) colsum_partial_b16_kernel(const unsigned 
         if (col < N) {
             float t = 0.f;
 #pragma unroll 8
-            for (int w = 0; w < RL; ++w) t += red[w][g][k];
+            for (int w_ = 0; w_ < RL; ++w_) t += red[w_][g][k];
             partial[(long long)blockIdx.y * ldp + col] = t;
         }
     }
@@ -167,6 +184,57 @@ __global__ void __launch_bounds__(256) disc_reg_kernel(const float* __restrict__
     if (threadIdx.x < 4) partials[blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// out[off_r + i] = scale * sum_{s < nslabs_r} slabs[s * stride + off_r + i] (+ alpha_r * flat[off_r + i]) over up to 8 regions of a flat
+// gradient buffer, each with its own slab count (a weight-gradient launch that split its reduction 4 ways wrote 4 slabs: the other slabs of
+// that region are never read); sq_partials[block] = the block's share of sum out^2 (the gradient-norm clip needs it: no separate pass over
+// the gradient), w2_partials[block * 8 + r] = its share of sum flat[region r]^2 (the regularisers' loss terms).
+struct ReduceRegions { long long off[8]; long long count[8]; int nslabs[8]; float alpha[8]; int n; };
+__global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restrict__ slabs, long long stride, const ReduceRegions rg, float* __restrict__ out,
+                                                          float scale, const float* __restrict__ flat, float* __restrict__ sq_partials,
+                                                          float* __restrict__ w2_partials) {
+    __shared__ float red[4][9];
+    float sq = 0.f, w2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r >= rg.n) break;
+        const float* base = slabs + rg.off[r];
+        float* o = out + rg.off[r];
+        const float* w = flat ? flat + rg.off[r] : nullptr;
+        const float al = rg.alpha[r];
+        const int ns = rg.nslabs[r];
+        const long long n4 = rg.count[r] >> 2;                          // offsets / counts are multiples of 4 floats (checked by the launcher)
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            float4 a = reinterpret_cast<const float4*>(base)[i];
+            for (int k = 1; k < ns; ++k) {
+                const float4 v = reinterpret_cast<const float4*>(base + k * stride)[i];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+            if (w) {
+                const float4 v = reinterpret_cast<const float4*>(w)[i];
+                w2[r] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                if (al != 0.f) { a.x += al * v.x; a.y += al * v.y; a.z += al * v.z; a.w += al * v.w; }
+            }
+            sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+            reinterpret_cast<float4*>(o)[i] = a;
+        }
+    }
+    float vals[9] = {sq, w2[0], w2[1], w2[2], w2[3], w2[4], w2[5], w2[6], w2[7]};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float v = vals[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x == 0) { if (sq_partials) sq_partials[blockIdx.x] = t; }
+        else if (w2_partials) w2_partials[blockIdx.x * 8 + threadIdx.x - 1] = t;
+    }
+}
+
 __global__ void __launch_bounds__(256) disc_reward_kernel(const float* __restrict__ logits, long long ls, long long n, float scale, float* __restrict__ out, long long os) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -196,20 +264,32 @@ int pulse_transpose_to_b16(const float* in, int64_t ld_in, int32_t rows_in, int3
     return check_launch("pulse_transpose_to_b16");
 }
 
-int pulse_colsum_partial_b16(const void* x, int32_t m, int32_t n, int64_t ld, int32_t num_chunks, float* partial, int64_t ld_partial, pulse_stream_t s) {
-    PULSE_REQUIRE(m >= 0 && n >= 0 && num_chunks >= 1, "pulse_colsum_partial_b16: bad sizes");
+static int colsum_b16_launch(const char* what, const void* x, int32_t m, int32_t n, int64_t ld, const void* w, int64_t w_stride, int32_t num_chunks,
+                             float* partial, int64_t ld_partial, pulse_stream_t s) {
+    PULSE_REQUIRE(m >= 0 && n >= 0 && num_chunks >= 1, "%s: bad sizes", what);
     if (n == 0) return PULSE_OK;
-    PULSE_REQUIRE(x && partial && ld >= ((n + 7) & ~7) && ld_partial >= n, "pulse_colsum_partial_b16: bad pointers / pitches (ld must cover roundup8(n))");
-    PULSE_REQUIRE((ld % 8) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "pulse_colsum_partial_b16: x rows must be 16-byte aligned");
+    PULSE_REQUIRE(x && partial && ld >= ((n + 7) & ~7) && ld_partial >= n, "%s: bad pointers / pitches (ld must cover roundup8(n))", what);
+    PULSE_REQUIRE((ld % 8) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "%s: x rows must be 16-byte aligned", what);
     const int rows = (m + num_chunks - 1) / num_chunks;
     const unsigned short* xp = reinterpret_cast<const unsigned short*>(x);
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(w);
     if ((long long)((n + 255) / 256) * num_chunks >= 256)
-        hipLaunchKernelGGL(colsum_partial_b16_kernel<32>, dim3((unsigned)((n + 255) / 256), (unsigned)num_chunks), dim3(256), 0, as_stream(s), xp, m, n,
-                           (long long)ld, rows > 0 ? rows : 1, partial, (long long)ld_partial);
+        hipLaunchKernelGGL((colsum_partial_b16_kernel<32, 4>), dim3((unsigned)((n + 255) / 256), (unsigned)num_chunks), dim3(256), 0, as_stream(s), xp, m, n,
+                           (long long)ld, rows > 0 ? rows : 1, partial, (long long)ld_partial, wp, (long long)w_stride);
     else
-        hipLaunchKernelGGL(colsum_partial_b16_kernel<4>, dim3((unsigned)((n + 31) / 32), (unsigned)num_chunks), dim3(256), 0, as_stream(s), xp, m, n,
-                           (long long)ld, rows > 0 ? rows : 1, partial, (long long)ld_partial);
-    return check_launch("pulse_colsum_partial_b16");
+        hipLaunchKernelGGL((colsum_partial_b16_kernel<4, 8>), dim3((unsigned)((n + 31) / 32), (unsigned)num_chunks), dim3(256), 0, as_stream(s), xp, m, n,
+                           (long long)ld, rows > 0 ? rows : 1, partial, (long long)ld_partial, wp, (long long)w_stride);
+    return check_launch(what);
+}
+
+int pulse_colsum_partial_b16(const void* x, int32_t m, int32_t n, int64_t ld, int32_t num_chunks, float* partial, int64_t ld_partial, pulse_stream_t s) {
+    return colsum_b16_launch("pulse_colsum_partial_b16", x, m, n, ld, nullptr, 0, num_chunks, partial, ld_partial, s);
+}
+
+int pulse_colsum_weighted_b16(const void* x, int32_t m, int32_t n, int64_t ld, const void* w, int64_t w_stride, int32_t num_chunks, float* partial,
+                              int64_t ld_partial, pulse_stream_t s) {
+    PULSE_REQUIRE(w != nullptr && w_stride >= 1, "pulse_colsum_weighted_b16: weights missing");
+    return colsum_b16_launch("pulse_colsum_weighted_b16", x, m, n, ld, w, w_stride, num_chunks, partial, ld_partial, s);
 }
 
 int pulse_disc_penalty(const float* g, int64_t ldg, int32_t rows, int32_t cols, float scale, float* out32, int64_t ld32, void* out16, int64_t ld16,
@@ -238,6 +318,26 @@ int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int
     }
     hipLaunchKernelGGL(disc_reg_kernel, dim3((unsigned)num_blocks), dim3(256), 0, as_stream(s), flat, grad, a, partials);
     return check_launch("pulse_disc_reg");
+}
+
+int pulse_reduce_grads(const float* slabs, int64_t slab_stride, int32_t num_regions, const int64_t* offsets, const int64_t* counts, const int32_t* nslabs,
+                       const float* alphas, float* out, float scale, const float* flat, float* sq_partials, float* w2_partials, int32_t num_blocks,
+                       pulse_stream_t s) {
+    PULSE_REQUIRE(num_regions >= 1 && num_regions <= 8 && num_blocks >= 1, "pulse_reduce_grads: 1..8 regions");
+    PULSE_REQUIRE(slabs && offsets && counts && nslabs && out, "pulse_reduce_grads: null pointer");
+    PULSE_REQUIRE((slab_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                  (!flat || (reinterpret_cast<uintptr_t>(flat) & 15) == 0), "pulse_reduce_grads: 16-byte alignment required");
+    ReduceRegions rg;
+    rg.n = num_regions;
+    for (int r = 0; r < 8; ++r) {
+        rg.off[r] = r < num_regions ? offsets[r] : 0; rg.count[r] = r < num_regions ? counts[r] : 0; rg.nslabs[r] = r < num_regions ? nslabs[r] : 1;
+        rg.alpha[r] = (r < num_regions && alphas) ? alphas[r] : 0.f;
+        PULSE_REQUIRE(rg.off[r] >= 0 && rg.count[r] >= 0 && (rg.off[r] % 4) == 0 && (rg.count[r] % 4) == 0 && rg.nslabs[r] >= 1,
+                      "pulse_reduce_grads: region offsets / counts must be non-negative multiples of 4 floats, slab counts >= 1");
+    }
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3((unsigned)num_blocks), dim3(256), 0, as_stream(s), slabs, (long long)slab_stride, rg, out, scale, flat,
+                       sq_partials, w2_partials);
+    return check_launch("pulse_reduce_grads");
 }
 
 int pulse_disc_reward(const float* logits, int64_t logit_stride, int64_t n, float scale, float* out, int64_t out_stride, pulse_stream_t s) {

@@ -87,20 +87,23 @@ __global__ void __launch_bounds__(256) rms_normalize_wide_kernel(const float* __
 // of a row per instruction).  Needs 16-byte aligned rows on both sides and y_cols % 4 == 0.
 constexpr int kRmsVecGroups = 3;   // 256 threads x 4 columns x 3 groups = 3072 columns
 constexpr int kRmsRowsPerPass = 64;
-constexpr int kRmsRowsInFlight = 8;     // rows whose loads are in flight per workgroup (4 KB each): the row loop is a latency x concurrency product
+constexpr int kRmsRowsInFlight = 4;     // rows whose loads are in flight per workgroup (4 KB each): the row loop is a latency x concurrency product
 
 // OUT = 1: besides y, the three bf16 planes of every output element (common.h: split_pair3) go to planes[p * plane_stride + row * planes_ld + col]
 // -- the layer-1 operand of the planar GEMM (gemm_x3p.hip) written by its producer instead of a separate split pass.
 // OUT = 2: the output IS a bf16 matrix (planes[row * planes_ld + col], y unused): the layer-1 operand of the bf16-storage training path
 // (mixed_precision; a bf16 autocast Linear rounds its fp32 input exactly like this).
 template <int OUT>
-__global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
+__global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,
                                                                 const double* __restrict__ mean, const double* __restrict__ var,
                                                                 float eps, float clip, int mode, float* __restrict__ y,
                                                                 long long y_stride, int y_cols, double* __restrict__ partials,
                                                                 unsigned short* __restrict__ planes, long long plane_stride, long long planes_ld) {
-    const int tid = threadIdx.x;
+    // 512 threads = two halves of 256 column owners: the halves take alternate groups of kRmsRowsInFlight rows of the workgroup's row range and
+    // their moment sums are combined through LDS at the end.  (One workgroup per CU with four waves could not hide the row loads' latency:
+    // 4096 x 1960 rows took 29 us = 1.6 TB/s; the partials per WORKGROUP, which rms_update has to read back, stay what they were.)
+    const int tid = threadIdx.x & 255, hf = threadIdx.x >> 8;
     const int nblk = gridDim.x;
     const int per = (rows + nblk - 1) / nblk;
     const int r0 = blockIdx.x * per;
@@ -122,9 +125,9 @@ __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __
     for (int rb = r0; rb < r1; rb += kRmsRowsPerPass) {
         const int nr = min(kRmsRowsPerPass, r1 - rb);
         __syncthreads();
-        if (tid < nr) s_src[tid] = row_idx ? row_idx[rb + tid] : (long long)(rb + tid);
+        if ((int)threadIdx.x < nr) s_src[threadIdx.x] = row_idx ? row_idx[rb + threadIdx.x] : (long long)(rb + threadIdx.x);
         __syncthreads();
-        for (int q = 0; q < nr; q += kRmsRowsInFlight) {
+        for (int q = hf * kRmsRowsInFlight; q < nr; q += 2 * kRmsRowsInFlight) {
             // kRmsRowsInFlight rows' loads are issued before the first is consumed: a workgroup's row loop is latency-bound
             // (one 3.7 KB row per memory round trip otherwise)
             float4 v[kRmsRowsInFlight][kRmsVecGroups];
@@ -177,14 +180,25 @@ __global__ void __launch_bounds__(256) rms_normalize_vec4_kernel(const float* __
         }
     }
     if (partials) {
-        double* p = partials + (long long)blockIdx.x * 2 * cols;
+        __shared__ double s_red[2 * kRmsVecGroups * 4][256];           // 48 KB: the upper half's sums, [moment, group, column-in-group][owner]
+        __syncthreads();
+        if (hf == 1) {
 #pragma unroll
-        for (int j = 0; j < kRmsVecGroups; ++j)
+            for (int j = 0; j < kRmsVecGroups; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = (tid + 256 * j) * 4 + k;
-                if (c < cols) { p[c] = s1[j][k]; p[cols + c] = s2[j][k]; }
-            }
+                for (int k = 0; k < 4; ++k) { s_red[j * 4 + k][tid] = s1[j][k]; s_red[kRmsVecGroups * 4 + j * 4 + k][tid] = s2[j][k]; }
+        }
+        __syncthreads();
+        if (hf == 0) {
+            double* p = partials + (long long)blockIdx.x * 2 * cols;
+#pragma unroll
+            for (int j = 0; j < kRmsVecGroups; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = (tid + 256 * j) * 4 + k;
+                    if (c < cols) { p[c] = s1[j][k] + s_red[j * 4 + k][tid]; p[cols + c] = s2[j][k] + s_red[kRmsVecGroups * 4 + j * 4 + k][tid]; }
+                }
+        }
     }
 }
 
@@ -551,7 +565,7 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
                         (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                         x_stride >= ((cols + 3) & ~3);
     if (vec_ok)
-        hipLaunchKernelGGL(rms_normalize_vec4_kernel<0>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+        hipLaunchKernelGGL(rms_normalize_vec4_kernel<0>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials,
                            (unsigned short*)nullptr, 0LL, 0LL);
     else if (cols >= 64)
@@ -578,7 +592,7 @@ int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* 
     PULSE_REQUIRE((y_cols % 32) == 0 && planes_ld >= y_cols && (planes_ld % 8) == 0 && (plane_stride % 8) == 0 && plane_stride >= (int64_t)rows * planes_ld &&
                   (reinterpret_cast<uintptr_t>(planes) & 15) == 0,
                   "pulse_rms_normalize_planes: y_cols must be a multiple of 32 (zero-padded k extent), planes rows 16-byte aligned and covering it");
-    hipLaunchKernelGGL(rms_normalize_vec4_kernel<1>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+    hipLaunchKernelGGL(rms_normalize_vec4_kernel<1>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
                        (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
                        reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
     return check_launch("pulse_rms_normalize_planes");
@@ -595,7 +609,7 @@ int pulse_rms_normalize_b16(const float* x, int64_t x_stride, const int64_t* row
     PULSE_REQUIRE(cols >= 64 && y_cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride >= ((cols + 3) & ~3),
                   "pulse_rms_normalize_b16: needs the wide-row form (64 <= cols, y_cols <= %d, 16-byte aligned input rows)", 256 * 4 * kRmsVecGroups);
     PULSE_REQUIRE((y_cols % 4) == 0 && (y_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(y16) & 7) == 0, "pulse_rms_normalize_b16: output rows must be 8-byte aligned, y_cols a multiple of 4");
-    hipLaunchKernelGGL(rms_normalize_vec4_kernel<2>, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
+    hipLaunchKernelGGL(rms_normalize_vec4_kernel<2>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
                        (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, (float*)nullptr, 0LL, y_cols, moment_partials,
                        reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
     return check_launch("pulse_rms_normalize_b16");

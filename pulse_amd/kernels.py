@@ -182,6 +182,13 @@ class Plan:
             raise TypeError("colsum_b16: x must be an int16 (bf16 bit pattern) tensor")
         self.call("pulse_colsum_partial_b16", x.data_ptr() + 2 * x_off, m, n, ld, num_slabs, slabs.data_ptr() + 4 * out_off, slab_stride)
 
+    def colsum_weighted_b16(self, x, w16, w_stride, m, n, ld, slabs, num_slabs, slab_stride, out_off, w_off=0):
+        """slab s [out_off, out_off + n) = sum over the s-th row range of w16[m * w_stride] * x[m][:]: the weight gradient of a one-output Linear."""
+        if x.dtype != torch.int16 or w16.dtype != torch.int16:
+            raise TypeError("colsum_weighted_b16: x / w16 must be int16 (bf16 bit pattern) tensors")
+        self.call("pulse_colsum_weighted_b16", x.data_ptr(), m, n, ld, w16.data_ptr() + 2 * w_off, w_stride, num_slabs, slabs.data_ptr() + 4 * out_off,
+                  slab_stride)
+
     def run(self, start=0, stop=None):
         st = _stream()
         for op in self.ops[start:stop]:
@@ -538,6 +545,39 @@ def disc_reg(flat, grad, ranges, partials):
     lens = (ctypes.c_int64 * n)(*[int(r[1]) for r in ranges])
     als = (ctypes.c_float * n)(*[float(r[2]) for r in ranges])
     _lib.check(_lib.load().pulse_disc_reg(flat.data_ptr(), _p(grad), n, offs, lens, als, partials.data_ptr(), partials.shape[0], _stream()), "pulse_disc_reg")
+
+
+class ReduceGrads:
+    """A pre-built pulse_reduce_grads launch: regions = [(offset, count, nslabs, alpha)] of a flat gradient buffer."""
+
+    def __init__(self, slabs, slab_stride, regions, out, flat=None):
+        n = len(regions)
+        if not 1 <= n <= 8:
+            raise ValueError("ReduceGrads: 1..8 regions")
+        _chk(slabs, "slabs"), _chk(out, "out"), _chk(flat, "flat")
+        self.n = n
+        self.offs = (ctypes.c_int64 * n)(*[int(r[0]) for r in regions])
+        self.cnts = (ctypes.c_int64 * n)(*[int(r[1]) for r in regions])
+        self.nsl = (ctypes.c_int32 * n)(*[int(r[2]) for r in regions])
+        self.als = (ctypes.c_float * n)(*[float(r[3]) for r in regions])
+        self.slabs, self.stride, self.out, self.flat = slabs, int(slab_stride), out, flat
+        self.has_alpha = any(float(r[3]) != 0.0 for r in regions)
+
+    def run(self, scale=1.0, sq_partials=None, w2_partials=None, num_blocks=1024, alphas=None):
+        _chk(sq_partials, "sq_partials"), _chk(w2_partials, "w2_partials")
+        if alphas is not None:                       # per-call regulariser coefficients (one per region)
+            if len(alphas) != self.n:
+                raise ValueError("ReduceGrads: one alpha per region")
+            self.als = (ctypes.c_float * self.n)(*[float(a) for a in alphas])
+            self.has_alpha = any(float(a) != 0.0 for a in alphas)
+        if sq_partials is not None:
+            num_blocks = sq_partials.numel()
+        if w2_partials is not None and (w2_partials.numel() != 8 * num_blocks or not w2_partials.is_contiguous()):
+            raise ValueError("ReduceGrads: w2_partials must be (num_blocks, 8) contiguous, num_blocks = sq_partials.numel() (default 1024)")
+        if (w2_partials is not None or self.has_alpha) and self.flat is None:
+            raise ValueError("ReduceGrads: regulariser terms need the flat parameter buffer")
+        _lib.check(_lib.load().pulse_reduce_grads(self.slabs.data_ptr(), self.stride, self.n, self.offs, self.cnts, self.nsl, self.als, self.out.data_ptr(),
+                                                  float(scale), _p(self.flat), _p(sq_partials), _p(w2_partials), num_blocks, _stream()), "pulse_reduce_grads")
 
 
 def disc_reward(logits, n, scale, out):

@@ -215,19 +215,28 @@ class AMPAgent(CommonAgent):
         rms = self._amp_input_mean_std
         rms.forward(eb_rows, row_idx=sub, out=X[0:b], out_cols=self._amp_pitch)                                   # amp_obs
         rep_src, rep_idx = d["_amp_replay_src"], d["_amp_replay_idx"]
-        rms.forward(rep_src, row_idx=rep_idx[sub] if rep_idx is not None else sub, out=X[b:2 * b], out_cols=self._amp_pitch)   # amp_obs_replay
-        rms.forward(self._amp_obs_demo_buffer.data, row_idx=d["_amp_demo_idx"][sub], out=X[2 * b:3 * b], out_cols=self._amp_pitch)  # amp_obs_demo
+        if rep_idx is not None and "_amp_idx_pair" in d:
+            both = d["_amp_idx_pair"][:, sub]                              # replay / demo ring rows of this minibatch in ONE gather launch
+            rep_rows, demo_rows = both[0], both[1]
+        else:
+            rep_rows, demo_rows = (rep_idx[sub] if rep_idx is not None else sub), d["_amp_demo_idx"][sub]
+        rms.forward(rep_src, row_idx=rep_rows, out=X[b:2 * b], out_cols=self._amp_pitch)                          # amp_obs_replay
+        rms.forward(self._amp_obs_demo_buffer.data, row_idx=demo_rows, out=X[2 * b:3 * b], out_cols=self._amp_pitch)  # amp_obs_demo
         logits = self.disc.forward(ws)
         # prediction loss, its logit gradients, accuracies and logit means in ONE launch (pulse_disc_head); everything the reported losses
         # need lands in one 12-float row: [disc_head's 8 | sum ||dD/dx||^2 | ||W1||^2 | ||W2||^2 | ||w3||^2]
         lazy = self._lazy_info and self._disc_ring is not None and self._disc_pos < self._disc_ring.shape[0]
-        row = self._disc_ring[self._disc_pos] if lazy else torch.empty(12, dtype=torch.float32, device=self.ppo_device)
+        row = self._disc_ring[self._disc_pos] if lazy else torch.empty(20, dtype=torch.float32, device=self.ppo_device)
         scale = self._disc_coef / self.world_size
         if ws["b16"]:
             K.disc_head_b16(logits, b, scale, ws["dL16"], row[:8])
         else:
             K.disc_head(logits, b, scale, ws["dlogits"], row[:8])
-        self.disc.backward(ws, self._disc_grad_penalty, self._disc_logit_reg, self._disc_weight_decay, scale=scale, stats=row[8:12])
+        sqp = None
+        if self._sq_fuse:                                          # inside calc_gradients on one GPU: the reduce launch also leaves the norm clip's sums of squares (group 1)
+            sqp = self._sq_slice(1)
+            self._sq_done.add(1)
+        self.disc.backward(ws, self._disc_grad_penalty, self._disc_logit_reg, self._disc_weight_decay, scale=scale, stats=row[8:17], sq_partials=sqp)
         if lazy:                                                   # reduced once at the end of train_epoch (_end_loss_ring)
             out = self._disc_info_all[self._disc_pos]
             self._disc_pos += 1
@@ -237,14 +246,15 @@ class AMPAgent(CommonAgent):
                 "disc_agent_acc": out[3], "disc_demo_acc": out[4], "disc_agent_logit": out[5], "disc_demo_logit": out[6]}
 
     def _disc_info(self, raw, b, out=None):
-        """(n, 12) raw rows -> (n, 7): disc_loss (:895-952: prediction loss + logit regulariser + gradient penalty + weight decay),
-        penalty, logit loss, accuracies, logit means."""
+        """(n, 20) raw rows [disc_head's 8 | sum ||dD/dx||^2 | per-region sums of squared parameters: ||W1||^2, b1, ||W2||^2, b2, ||w3||^2, b3, 0, 0]
+        -> (n, 7): disc_loss (:895-952: prediction loss + logit regulariser + gradient penalty + weight decay), penalty, logit loss,
+        accuracies, logit means."""
         out = torch.empty(raw.shape[0], 7, device=raw.device) if out is None else out
-        pen = raw[:, 8] / b
-        out[:, 0] = raw[:, 0] + self._disc_logit_reg * raw[:, 11] + self._disc_grad_penalty * pen
+        pen, w1, w2, w3 = raw[:, 8] / b, raw[:, 9], raw[:, 11], raw[:, 13]
+        out[:, 0] = raw[:, 0] + self._disc_logit_reg * w3 + self._disc_grad_penalty * pen
         if self._disc_weight_decay != 0:
-            out[:, 0] += self._disc_weight_decay * (raw[:, 9] + raw[:, 10] + raw[:, 11])
-        out[:, 1], out[:, 2] = pen, raw[:, 11]
+            out[:, 0] += self._disc_weight_decay * (w1 + w2 + w3)
+        out[:, 1], out[:, 2] = pen, w3
         out[:, 3:7] = raw[:, 3:7]
         return out
 
@@ -253,7 +263,7 @@ class AMPAgent(CommonAgent):
         self._disc_pos = 0
         if self.enable_disc and self._lazy_info:
             if self._disc_ring is None or self._disc_ring.shape[0] < slots:
-                self._disc_ring = torch.zeros(slots, 12, device=self.ppo_device)
+                self._disc_ring = torch.zeros(slots, 20, device=self.ppo_device)
             self._disc_info_all = torch.zeros(slots, 7, device=self.ppo_device)     # fresh per epoch: last epoch's dicts stay valid
 
     def _end_loss_ring(self):
@@ -376,6 +386,7 @@ class AMPAgent(CommonAgent):
                 d["_amp_replay_src"], d["_amp_replay_idx"] = d["_amp_store"], None      # batch_dict['amp_obs_replay'] = batch_dict['amp_obs']
             else:
                 d["_amp_replay_src"], d["_amp_replay_idx"] = self._amp_replay_buffer.data, self._amp_replay_buffer.sample_indices(n)
+                d["_amp_idx_pair"] = torch.stack((d["_amp_replay_idx"], d["_amp_demo_idx"]))
         self.dataset.update_values_dict(d, rnn_format=True, horizon_length=self.horizon_length, num_envs=self.num_actors)
         return d
 

@@ -132,6 +132,7 @@ class CommonAgent:
         self.exp_avg_sq = torch.zeros(n, device=self.ppo_device)
         self.optimizer_step = 0
         self._sq_partials = torch.zeros(256, device=self.ppo_device)
+        self._sq_done, self._sq_fuse = set(), False      # parameter groups whose sum-of-squares partials the gradient reduce of this step already produced
         self._grad_norm = torch.zeros(1, device=self.ppo_device)
         self._partials_ring, self._lazy_info, self._ring_pos = None, False, 0
         self._loss_partials = torch.zeros(max(1, min(512, self.minibatch_size // 16)), 8, device=self.ppo_device)
@@ -512,9 +513,19 @@ class CommonAgent:
                    dmu=ws["dmu"], dmu_stride=ws["dmu"].stride(0), dvalue=ws["dval"], dvalue_stride=ws["dval"].stride(0),
                    partials=self._loss_slot(), **g16)
         overlap = self.multi_gpu and self.overlap_allreduce and hasattr(net, "w_off")
-        net.backward(ws, mb, grad_scale=1.0 / self.world_size, **({"on_bucket": self._bucket_ready} if overlap else {}))
+        # single GPU: the slab reduce of every flat gradient also leaves the sums of squares the norm clip needs (with data parallelism the
+        # norm is taken after the all-reduce, so it keeps its own pass)
+        self._sq_done, self._sq_fuse = set(), not self.multi_gpu
+        bkw = {}
+        if self._sq_fuse and getattr(net, "supports_fused_sqnorm", False):
+            bkw["sq_partials"] = self._sq_slice(0)
+            self._sq_done.add(0)
+        if overlap:
+            bkw["on_bucket"] = self._bucket_ready
+        net.backward(ws, mb, grad_scale=1.0 / self.world_size, **bkw)
         extra_info = self._extra_gradients(input_dict, idx)               # AMPAgent: discriminator loss / gradients
-        self._apply_gradients(policy_synced=overlap)
+        self._sq_fuse = False
+        self._apply_gradients(policy_synced=overlap, sq_done=self._sq_done)
         info, gnorm = self._loss_info(mb)                               # [a_loss, c_loss, b_loss, clip_frac, kl]
         if self._entropy is None:
             ent = float((0.5 + 0.5 * math.log(2 * math.pi)) * self.actions_num) + float(net.sigma.sum().item())
@@ -574,11 +585,20 @@ class CommonAgent:
         net = self.model
         return [(net.flat, net.grad, self.exp_avg, self.exp_avg_sq, net.n_flat)]
 
+    SQ_BLOCKS = 1024
+
+    def _sq_slice(self, i):
+        """The sum-of-squares partials of parameter group i (one buffer for all groups: the clip takes ONE norm over all of them)."""
+        nb, n = self.SQ_BLOCKS, len(self._param_groups())
+        if self._sq_partials.numel() != nb * n:
+            self._sq_partials = torch.zeros(nb * n, device=self.ppo_device)
+        return self._sq_partials[i * nb:(i + 1) * nb]
+
     def _bucket_ready(self, grad_view):
         """Data-parallel overlap: a finished gradient bucket goes on the wire while the backward continues."""
         self.dist.sync_gradients(grad_view, async_op=True)
 
-    def _apply_gradients(self, policy_synced=False):
+    def _apply_gradients(self, policy_synced=False, sq_done=()):
         """[all-reduce] -> clip_grad_norm_ over ALL parameters -> Adam, one fused launch per flat buffer."""
         groups = self._param_groups()
         if self.multi_gpu:
@@ -588,11 +608,9 @@ class CommonAgent:
                 self.dist.sync_gradients(g[1], async_op=policy_synced)       # optimizer.synchronize()
             self.dist.wait_gradients()
         self.optimizer_step += 1
-        nb = 256
-        if self._sq_partials.numel() != nb * len(groups):
-            self._sq_partials = torch.zeros(nb * len(groups), device=self.ppo_device)
         for i, g in enumerate(groups):
-            K.sqnorm_partial(g[1], g[4], self._sq_partials[i * nb:(i + 1) * nb])
+            if i not in sq_done:             # (groups whose gradient reduce already left its sum-of-squares partials)
+                K.sqnorm_partial(g[1], g[4], self._sq_slice(i))
         for g in groups:
             K.adam_step(g[0], g[1], g[2], g[3], g[4], lr=self.last_lr, step=self.optimizer_step, weight_decay=self.weight_decay,
                         max_norm=self.grad_norm if self.truncate_grads else 0.0, sqnorm_partials=self._sq_partials,

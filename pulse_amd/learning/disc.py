@@ -53,7 +53,7 @@ class DiscNetwork:
         self._ws = {}
         self.mixed_precision = False      # True: the training passes (forward on the 3b rows, BCE / penalty backward, weight gradients) on the bf16 MFMA
         self._flat16 = self._w1t16 = self._w2t16 = None
-        self._reg_partials = torch.zeros(256, 4, device=self.device)
+        self._reg_partials = torch.zeros(1024, 8, device=self.device)
         self.reset_parameters()
 
     def b16_storage_ok(self):
@@ -155,8 +155,9 @@ class DiscNetwork:
         wg = K.Plan()
         m = 4 * b
         t256 = lambda mm, nn: ((mm + 255) // 256) * ((nn + 127) // 128)
+        ws["w_slabs"] = (K.dw_split(t256(u1, k0), S, fill=256), 1, S)          # slabs written for W1 / W2 (summed into slab 0 by its own reduce) / w3
         wg.gemm_b16(Z1, X, M=u1, N=k0, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=w1.pitch, c_off=w1.off,
-                    split_k=K.dw_split(t256(u1, k0), S, fill=256), split_stride=P)
+                    split_k=ws["w_slabs"][0], split_stride=P)
         # the two small outputs would leave most of the chip idle at S splits (16 and 4 tiles of 256 x 128): they are split wider into a
         # scratch whose ordered sum lands in slab 0 (slabs 1.. of these regions stay zero)
         def wide(A, B, M_, N_, lin, lda_note=None):
@@ -171,7 +172,7 @@ class DiscNetwork:
                         split_stride=scr.stride(0))
             wg.call("pulse_reduce_slabs", scr.data_ptr(), split, scr.stride(0), count, slabs.data_ptr() + 4 * lin.off, 1.0)
         wide(Z2, H1, u2, u1, w2)
-        wide(dL, H2, 1, u2, w3)
+        wg.colsum_weighted_b16(H2, dL, 32, m, u2, u2, slabs, S, P, w3.off)      # d w3 = sum over the 4b stacked rows of dL[m] * H2[m][:]
         for buf, n, ld, off in ((Z1, u1, u1, self.l1.b.off), (Z2, u2, u2, self.l2.b.off), (dL, 1, 32, self.l3.b.off)):
             wg.colsum_b16(buf, r3, n, ld, slabs, S, P, off)                # one partial row per gradient slab: summed by the slab reduce
         return fwd, bce, pf, pb, wg
@@ -214,6 +215,7 @@ class DiscNetwork:
         pb.gemm(ws["H1"], f, ws["H2"], M=b, N=u2, K=u1, lda=u1, ldb=w2.pitch, ldc=u2, a_off=r3 * u1, b_off=w2.off, c_off=r3 * u2,
                 epilogue=EPI_RELU_GRAD, aux=ws["H2"], ldaux=u2, aux_off=demo * u2)
         # (3) weight gradients over all 4b stacked rows, bias gradients over the 3b BCE rows
+        ws["w_slabs"] = (S, S, S)
         wg = K.Plan(bf16=self.mixed_precision)
         m = 4 * b
         wg.gemm(ws["Z1"], ws["X"], slabs, M=u1, N=k0, K=m, lda=u1, ldb=k0p, ldc=w1.pitch, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
@@ -249,11 +251,12 @@ class DiscNetwork:
         ws["fwd"].run()
         return ws["logits"]
 
-    def backward(self, ws, grad_penalty_coef, logit_reg, weight_decay, scale=1.0, stats=None):
+    def backward(self, ws, grad_penalty_coef, logit_reg, weight_decay, scale=1.0, stats=None, sq_partials=None):
         """ws['dlogits'] (fp32 storage) / ws['dL16'] (bf16 storage) holds d(total loss)/d logit for the 3b rows.  Adds the gradient penalty,
         logit regulariser and weight decay (each times ``scale`` = disc_coef) and leaves the flat gradient in self.grad.
-        Returns the penalty value mean_demo ||dD/dx||^2 (device scalar).  ``stats``: optional (4,) float tensor that receives
-        [sum ||dD/dx||^2 over the demo rows, ||W1||^2, ||W2||^2, ||w3||^2] for the caller's loss bookkeeping (no extra launches)."""
+        Returns the penalty value mean_demo ||dD/dx||^2 (device scalar), or None when ``stats`` -- a (9,) float tensor -- takes the raw
+        numbers instead: [sum ||dD/dx||^2 over the demo rows, then the eight per-region sums of squared parameters of the reduce launch:
+        ||W1||^2 at [1], ||W2||^2 at [3], ||w3||^2 at [5]].  ``sq_partials`` (256 floats): per-block sums of squares of the finished gradient."""
         b = ws["b"]
         ws["bwd_bce"].run()
         ws["pen_fwd"].run()
@@ -267,13 +270,22 @@ class DiscNetwork:
             K.disc_penalty(ws["G"], b, self.k0p, c, ws["pen_partials"], out32=X, out32_off=3 * b * self.k0p, ld32=self.k0p)
         ws["pen_bwd"].run()
         ws["wgrad"].run()
-        self.book.reduce_grads()
-        # logit regulariser + weight decay gradients (grad += 2 coef scale W) and the three ||W||^2 in one launch
-        rp = self._reg_partials
-        K.disc_reg(self.flat, self.grad, [(lin.w.off, lin.w.rows * lin.w.pitch, 2.0 * scale * (weight_decay + (logit_reg if lin is self.l3 else 0.0)))
-                                          for lin in (self.l1, self.l2, self.l3)], rp)
-        pen_sum = ws["pen_partials"].sum()
-        if stats is not None:
-            stats[0] = pen_sum
-            torch.sum(rp[:, :3], dim=0, out=stats[1:4])
-        return pen_sum / b
+        # ONE launch: split-K slab reduce (each weight region over the slabs its launch wrote), logit regulariser + weight decay gradients
+        # (grad += 2 coef scale W), the three ||W||^2 of the reported loss and the sums of squares of the finished gradient for the norm clip
+        rg = ws.get("reduce_all")
+        S = self.book.split_k
+        if rg is None:
+            n1, n2, n3 = ws["w_slabs"]
+            regions = []
+            for lin, ns in ((self.l1, n1), (self.l2, n2), (self.l3, n3)):
+                regions.append((lin.w.off, lin.w.rows * lin.w.pitch, ns, 0.0))
+                regions.append((lin.b.off, lin.b.rows * lin.b.pitch, S, 0.0))
+            assert regions[-1][0] + regions[-1][1] == self.n_flat and all(a[0] + a[1] == b[0] for a, b in zip(regions, regions[1:]))
+            rg = ws["reduce_all"] = K.ReduceGrads(self.book.slabs, self.book.n_flat, regions, self.grad, flat=self.flat)
+        al = [2.0 * scale * weight_decay, 0.0, 2.0 * scale * weight_decay, 0.0, 2.0 * scale * (weight_decay + logit_reg), 0.0]
+        rg.run(alphas=al, sq_partials=sq_partials, w2_partials=self._reg_partials)
+        if stats is not None:                                       # [sum ||dD/dx||^2 | per-region sums of squares: W1 at [1], W2 at [3], w3 at [5]]
+            torch.sum(ws["pen_partials"].view(1, -1), dim=1, out=stats[0:1])
+            torch.sum(self._reg_partials, dim=0, out=stats[1:9])
+            return None
+        return ws["pen_partials"].sum() / b

@@ -318,7 +318,7 @@ class A2CNetwork:
             p.gemm_b16(dz[l], self._wt16[l], M=m, N=up, K=uu, ldb=uu, batch=2, stride_a=uu, stride_b=up * uu, Cp=dz[l - 1], stride_cp=up,
                        epilogue=egrad, aux=aux[l - 1], ldaux=ld_aux(aux[l - 1]), stride_aux=up)
         uu, k = u[0], self.in_w[0]
-        s1 = self._l0_slabs = K.dw_split(((2 * uu + 255) // 256) * ((k + 127) // 128), S, fill=256)
+        s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split(((2 * uu + 255) // 256) * ((k + 127) // 128), S, fill=256)
         p.gemm_b16(dz[0], ws["x16"], M=2 * uu, N=k, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=k, c_off=self.w_off[0],
                    split_k=s1, split_stride=P, algo_n=self.in_dim)
         p.colsum_b16(dz[0], m, 2 * uu, 2 * uu, slabs, s1, P, self.b_off[0])      # the layer-1 bucket is reduced over its own s1 slabs
@@ -423,7 +423,7 @@ class A2CNetwork:
                    aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
         # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
         uu, k = u[0], self.in_w[0]
-        s1 = self._l0_slabs = K.dw_split(((2 * uu + 127) // 128) * ((k + 127) // 128), S)
+        s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split(((2 * uu + 127) // 128) * ((k + 127) // 128), S)
         p.gemm(ws["dh"][0], ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
                b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=s1, split_stride=P, algo_n=self.in_dim,
                rowsum=slabs, rowsum_off=self.b_off[0])
@@ -443,7 +443,9 @@ class A2CNetwork:
                    split_k=sl, split_stride=P, rowsum=slabs, rowsum_off=self.b_off[l], stride_rowsum=uu)
         return p
 
-    def backward(self, ws, m, grad_scale=1.0, on_bucket=None):
+    supports_fused_sqnorm = True
+
+    def backward(self, ws, m, grad_scale=1.0, on_bucket=None, sq_partials=None):
         """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
         Deterministic: split-K slabs + ordered reduces.
 
@@ -453,14 +455,21 @@ class A2CNetwork:
         plan = ws["plan_bwd"]
         if on_bucket is None or len(self.units) < 2:
             plan.run()
-            K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat, self.grad, scale=grad_scale)
+            # ONE reduce launch over the flat gradient: the layer-1 region reads only the slabs its weight-gradient launch wrote, and the
+            # launch leaves the per-block sums of squares the gradient-norm clip needs (``sq_partials``, 256 floats) -- no pass of its own
+            rg = ws.get("reduce_all")
+            if rg is None:
+                cut = self.w_off[1] if len(self.units) >= 2 else 0
+                regions = ([(0, cut, ws["l0_slabs"], 0.0)] if cut else []) + [(cut, self.n_flat - cut, self.split_k, 0.0)]
+                rg = ws["reduce_all"] = K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad)
+            rg.run(scale=grad_scale, sq_partials=sq_partials)
             if on_bucket is not None:
                 on_bucket(self.grad)
             return self.grad
         cut = self.w_off[1]
         plan.run(0, plan.split)
         # the layer-1 region [0, cut) holds only the slabs its dW GEMM wrote (the others stay zero): reduce just those
-        K.reduce_slabs(self._slabs, getattr(self, "_l0_slabs", self.split_k), self.n_flat, cut, self.grad, scale=grad_scale)
+        K.reduce_slabs(self._slabs, ws["l0_slabs"], self.n_flat, cut, self.grad, scale=grad_scale)
         on_bucket(self.grad[:cut])
         plan.run(plan.split, None)
         K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat - cut, self.grad, scale=grad_scale, slabs_off=cut, out_off=cut)

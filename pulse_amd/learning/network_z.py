@@ -204,7 +204,7 @@ class _Replay:
     def __init__(self, book):
         self._book = book
 
-    def add(self, name, rows, cols, colmap=None):
+    def add(self, name, rows, cols, colmap=None, pitch_align=4):
         return self._book.params[name]
 
     def __getattr__(self, k):

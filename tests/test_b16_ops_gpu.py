@@ -39,6 +39,23 @@ def test_colsum_partial_b16(dev, m, n, chunks):
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+def test_colsum_weighted_b16(dev):
+    g = torch.Generator().manual_seed(12)
+    m, n, S = 16384, 512, 8
+    x = torch.relu(torch.randn(m, n, generator=g)).to(dev)
+    w = torch.zeros(m, 32, device=dev)
+    w[:, 0] = (torch.randn(m, generator=g) * 1e-3).to(dev)
+    x16, w16 = x.to(torch.bfloat16).view(torch.int16), w.to(torch.bfloat16).view(torch.int16)
+    slabs = torch.zeros(S, 4096, device=dev)
+    lib = __import__("pulse_amd._lib", fromlist=["x"])
+    lib.check(lib.load().pulse_colsum_weighted_b16(x16.data_ptr(), m, n, n, w16.data_ptr(), 32, S, slabs.data_ptr() + 4 * 100, slabs.stride(0), None), "colsum_weighted")
+    torch.cuda.synchronize()
+    want = (_bf(w[:, :1]).double() * _bf(x).double()).sum(0)
+    got = slabs[:, 100:100 + n].double().sum(0)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    assert (slabs[:, :100] == 0).all() and (slabs[:, 100 + n:] == 0).all()
+
+
 def test_rms_normalize_b16_matches_rounded_fp32(dev):
     from pulse_amd.learning.running_mean_std import RunningMeanStd
     g = torch.Generator().manual_seed(3)

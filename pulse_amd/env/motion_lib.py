@@ -127,8 +127,8 @@ class MotionLib:
     # ---- the hot query
     def launch_signature(self):
         """Identity of the device tables a cached launch points at (ops._launch_sig)."""
-        return (id(self), self.frames.data_ptr(), self._motion_lengths.data_ptr(), self._motion_dt.data_ptr(), self._motion_num_frames.data_ptr(),
-                self.length_starts.data_ptr(), self._num_motions)
+        return (id(self), self.frames.data_ptr(), tuple(self.frames.shape), self._motion_lengths.data_ptr(), self._motion_dt.data_ptr(),
+                self._motion_num_frames.data_ptr(), self.length_starts.data_ptr(), self._num_motions)
 
     def fill_tables(self, t):
         """Fill a pulse_motion_tables struct (by reference) with this library's device pointers."""

@@ -93,6 +93,17 @@ class ParamBook:
         else:
             v[:, :p.cols] = value
 
+    def note_slab_layout(self, name, nslabs, m):
+        """Record / check the number of gradient slabs the weight-gradient launch of parameter ``name`` writes (see backward_plan)."""
+        lay = self.__dict__.setdefault("_slab_layout", {})
+        seen = lay.get(name)
+        if seen is None:
+            lay[name] = (nslabs, m)
+        elif seen[0] != nslabs:
+            raise RuntimeError(f"ParamBook: the weight-gradient launch of {name} writes {nslabs} gradient slab(s) at batch {m} but {seen[0]} at batch "
+                               f"{seen[1]}: two training workspaces with different slab layouts would leave stale partial sums in the slabs the "
+                               "other one skips.  Use one training batch size per model (or a separate ParamBook per batch size).")
+
     def zero_slab_ranges(self, ranges):
         """Zero the gradient slabs of the flat ranges [(lo, hi), ...] (all S slabs): the sub-networks a backward pass does NOT visit, whose
         slabs still hold another pass's gradients.  The visited ones are overwritten by their weight-gradient GEMMs; zeroing all S x n_flat
@@ -259,7 +270,13 @@ class MlpGraph:
             # launch as per-slab row sums of the A operand (pulse_gemm_desc.rowsum)
             tiles = ((lin.n + 127) // 128) * ((lin.k_phys + 127) // 128)
             wcount = lin.n * lin.w.pitch
-            if tiles * S < 128 and wcount + lin.n <= self._w_scratch.shape[1] and m >= 32 * 32 and lin.b.off == lin.w.off + wcount:
+            via_scratch = tiles * S < 128 and wcount + lin.n <= self._w_scratch.shape[1] and m >= 32 * 32 and lin.b.off == lin.w.off + wcount
+            # how many gradient slabs this layer's launch writes (1: the scratch path sums into slab 0).  zero_slab_ranges only clears the
+            # sub-networks a pass does NOT visit, so the slabs a visited layer leaves alone must never have been written by anyone: every
+            # plan built over this book has to agree on the count (it depends on m) -- otherwise reduce_slabs would silently add another
+            # graph's stale partial sums (round-3 advisor finding)
+            book.note_slab_layout(lin.w.name, 1 if via_scratch else K.dw_split(tiles, S), m)
+            if via_scratch:
                 ws_ = self._w_scratch
                 p.gemm(gz, x, ws_, M=lin.n, N=lin.k_phys, K=m, lda=ldg, ldb=x.stride(0), ldc=lin.w.pitch, a_layout=GEMM_OUT_CONTIG,
                        b_layout=GEMM_OUT_CONTIG, a_off=gzo, b_off=op["src_col"], split_k=32, split_stride=ws_.stride(0), algo_n=lin.k_logical,

@@ -202,7 +202,8 @@ def _launch_sig(o):
     if o is None:
         return 0
     if isinstance(o, torch.Tensor):
-        return (o.data_ptr(), o.numel())            # (the caching allocator may hand a freed address to a tensor of another size)
+        # (the caching allocator may hand a freed address to a tensor of another size; a view of the same storage may have another dtype / stride)
+        return (o.data_ptr(), o.numel(), o.dtype, o.stride())
     if isinstance(o, dict):
         return tuple((k, _launch_sig(v)) for k, v in o.items())
     if isinstance(o, (list, tuple)):
@@ -300,7 +301,7 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
     if env_mask is not None:
         m = env_mask
         if m.dtype == torch.bool:
-            m = m.view(torch.uint8)
+            m = m.view(torch.uint8)                 # (a view: same memory, in-place edits stay visible to a replayed launch)
         a.env_mask = P(m, "env_mask", torch.uint8)
     if ref_now is not None:
         a.ref_now_pos, a.ref_now_rot = P(ref_now["pos"], "ref_now.pos"), P(ref_now["rot"], "ref_now.rot")
@@ -317,12 +318,19 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         pt = pass_time.view(torch.uint8) if pass_time.dtype == torch.bool else pass_time
         a.pass_time = P(pt, "pass_time", torch.uint8)
     a.cycle_counter = P(cycle_counter, "cycle_counter", torch.int64)
+    # id lists: a Python list is part of the launch signature (its VALUES are), but a tensor that had to be converted (int64 ids, another
+    # device) would leave the cached struct pointing at a private copy that later in-place edits of the caller's tensor never reach:
+    # such a launch is not replayed from the cache
     if track_ids is not None:
         t = _ids32(track_ids, dev)
+        if isinstance(track_ids, torch.Tensor) and t.data_ptr() != track_ids.data_ptr():
+            copied.append("track_ids")
         keep.append(t)
         a.track_ids, a.num_track = t.data_ptr(), t.numel()
     if reset_ids is not None:
         t = _ids32(reset_ids, dev)
+        if isinstance(reset_ids, torch.Tensor) and t.data_ptr() != reset_ids.data_ptr():
+            copied.append("reset_ids")
         keep.append(t)
         a.reset_ids, a.num_reset = t.data_ptr(), t.numel()
     a.term_dist = P(term_dist, "term_dist")

@@ -43,5 +43,17 @@ def test_every_object_of_the_library_is_free_of_packed_fp32():
     objs = sorted(glob.glob(os.path.join(os.path.dirname(B.__file__), "*.o")))
     if not objs:
         pytest.skip("objects not built in this checkout (the library was shipped prebuilt)")
-    bad = {os.path.basename(o): B.packed_f32_instructions(o)[:3] for o in objs}
+    bad = {os.path.basename(o): B.packed_f32_instructions(o, host_only=os.path.basename(o) in B.HOST_ONLY_OBJECTS)[:3] for o in objs}
     assert all(not v for v in bad.values()), {k: v for k, v in bad.items() if v}
+
+
+def test_audit_refuses_an_object_it_cannot_look_into(tmp_path):
+    """An object without an extractable device code section must FAIL the audit (round-3 advisor: it used to pass as 'host only')."""
+    src = tmp_path / "host.c"
+    src.write_text("int f(void) { return 1; }\n")
+    obj = tmp_path / "host.o"
+    import subprocess
+    subprocess.run(["gcc", "-c", str(src), "-o", str(obj)], check=True)
+    assert B.packed_f32_instructions(str(obj), host_only=True) == []
+    with pytest.raises(RuntimeError):
+        B.packed_f32_instructions(str(obj))

@@ -254,14 +254,18 @@ def sample_heights(heightsamples, points, horizontal_scale, vertical_scale):
     return (h * vertical_scale).view(points.shape[0], -1)
 
 
-def terrain_heights(heightsamples, sensor_states, height_points, horizontal_scale, vertical_scale, upright=True):
-    """get_heights: the sensor grid rotated by the HEADING of the sensor body (head or root) and moved to it."""
+def terrain_sample_points(sensor_states, height_points, upright=True):
+    """World positions of the sensor grid (get_heights, first half): rotated by the HEADING of the sensor body and moved to it."""
     q = _base_rot(sensor_states[:, 3:7], upright)
     h = R.heading_q(q)
     n, p = sensor_states.shape[0], height_points.shape[0]
     pts = quat_apply(h.unsqueeze(1).expand(n, p, 4).reshape(-1, 4), height_points.unsqueeze(0).expand(n, p, 3).reshape(-1, 3)).view(n, p, 3)
-    pts = pts + sensor_states[:, :3].unsqueeze(1)
-    return sample_heights(heightsamples, pts, horizontal_scale, vertical_scale)
+    return pts + sensor_states[:, :3].unsqueeze(1)
+
+
+def terrain_heights(heightsamples, sensor_states, height_points, horizontal_scale, vertical_scale, upright=True):
+    """get_heights: the sensor grid rotated by the HEADING of the sensor body (head or root) and moved to it."""
+    return sample_heights(heightsamples, terrain_sample_points(sensor_states, height_points, upright), horizontal_scale, vertical_scale)
 
 
 def terrain_center_heights(heightsamples, root_states, center_points, horizontal_scale, vertical_scale, upright=True):

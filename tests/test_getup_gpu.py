@@ -11,13 +11,14 @@ from pulse_amd.env.sim import KinematicSim
 pytestmark = pytest.mark.gpu
 
 
-def make(dev, n=96, **env):
+def make(dev, n=96, with_tables=False, **env):
     cfg = dict(configs.ENV_IM)
     cfg.update(env)
     tables = syn.synthetic_motion_library(syn.make_generator(11, 0), n)
     lib = MotionLib.from_tables(tables, dev)
     sim = KinematicSim(n, 40, dev, seed=3)
-    return HumanoidImGetup({"env": cfg}, sim, lib, device=dev)
+    task = HumanoidImGetup({"env": cfg}, sim, lib, device=dev)
+    return (task, tables) if with_tables else task
 
 
 def test_three_way_reset_split_and_recovery_grace(dev):
@@ -75,30 +76,36 @@ def test_getup_schedule_and_normal_init(dev):
 def test_recovering_env_observes_the_frozen_clock_frame(dev, cycle):
     """humanoid_im_getup.py:203-210 + humanoid.py:1325-1328: _compute_reset takes the recovering envs' progress back BEFORE
     _compute_observations, so their task observation targets the frame at (frozen progress + 1), not one frame further."""
-    from pulse_amd import ops
-    from pulse_amd._lib import PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS
+    from oracle import env_oracle as E
+    from oracle.motion_oracle import OracleMotionLib
     n = 64
-    task = make(dev, n, recoveryEpisodeProb=1.0, fallInitProb=1.0, recoverySteps=6, cycle_motion=cycle)
+    task, tables = make(dev, n, with_tables=True, recoveryEpisodeProb=1.0, fallInitProb=1.0, recoverySteps=6, cycle_motion=cycle)
+    olib = OracleMotionLib(tables)                                   # CPU restatement of MotionLibBase.get_motion_state (pinned to the reference)
     task.reset()
     for _ in range(3):
         task.step(torch.zeros(n, 69, device=dev))
     assert (task.progress_buf == 0).all() and (task._recovery_counter == 3).all()
 
     def expected(shift):
-        t = (task.progress_buf + shift).float() * task.dt
-        t = t + task._motion_start_times
-        t = t + task._motion_start_times_offset
-        ref = task._motion_lib.query(task._sampled_motion_ids, t.contiguous(), task._global_offset)
-        out = ops.im_step(task.sim.rigid_body_state, what=PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS,
-                          ref_next={"pos": ref["rg_pos"], "rot": ref["rb_rot"], "vel": ref["body_vel"], "ang": ref["body_ang_vel"]},
-                          track_ids=task._track_bodies_id, obs_version=task.obs_v)
-        return out["obs"]
+        """The observation row the REFERENCE builds for this state, computed on the CPU by the oracle (motion query + self / task
+        observation functions) from copies of the env's state: the reference frame at (progress + shift) * dt."""
+        t = (task.progress_buf.cpu() + shift).float() * task.dt + task._motion_start_times.cpu() + task._motion_start_times_offset.cpu()
+        ref = olib.get_motion_state(task._sampled_motion_ids.cpu(), t, task._global_offset.cpu())
+        bp, br, bv, ba = E.split_rb(task.sim.rigid_body_state.cpu())
+        tb = [int(i) for i in task._track_bodies_id.cpu().tolist()] if isinstance(task._track_bodies_id, torch.Tensor) else list(task._track_bodies_id)
+        self_obs = E.self_obs_smpl_max(bp, br, bv, ba)
+        assert task.obs_v == 6
+        task_obs = E.im_obs_v6(bp[:, 0], br[:, 0], bp[:, tb], br[:, tb], bv[:, tb], ba[:, tb], ref["rg_pos"][:, tb], ref["rb_rot"][:, tb],
+                               ref["body_vel"][:, tb], ref["body_ang_vel"][:, tb], 1)
+        return torch.cat([self_obs, task_obs], dim=-1)
+    w = task.num_obs
     want, ahead = expected(1), expected(2)
-    assert torch.equal(task.obs_buf, want), (task.obs_buf - want).abs().max().item()
-    assert not torch.equal(task.obs_buf, ahead)
+    got = task.obs_buf[:, :w].cpu()
+    assert (got - want).abs().max().item() <= 1e-5, (got - want).abs().max().item()
+    assert (got - ahead).abs().max().item() > 1e-3                   # one frame further is a different row
     # once the grace period is over the clock advances again and the observation follows it
     for _ in range(4):
         task.step(torch.zeros(n, 69, device=dev))
-    moving = task.progress_buf > 0
+    moving = (task.progress_buf > 0).cpu()
     assert moving.any()
-    assert torch.equal(task.obs_buf[moving], expected(1)[moving])
+    assert (task.obs_buf[:, :w].cpu()[moving] - expected(1)[moving]).abs().max().item() <= 1e-5

@@ -275,10 +275,28 @@ typedef struct pulse_amp_obs_args {
     const int32_t* key_body_ids; int32_t num_key_bodies;
     int32_t local_root_obs, root_height_obs;
     float* out; int64_t out_stride;                    /* (num_envs, out_stride), first W columns written */
+    /* history mode (hist_steps > 1): ``out`` is slot 0 of the env's (hist_steps, W) window (HumanoidAMP._amp_obs_buf, humanoid_amp.py:296-314,
+       out_stride >= hist_steps * W): the launch moves frames 0 .. S-2 to 1 .. S-1 (_update_hist_amp_obs, :622-631), writes the current
+       frame into slot 0 (HumanoidAMP.post_physics_step, :194-210) and, if window_out != NULL, copies the finished window to
+       window_out + e * window_stride (the experience-buffer slot, amp_agent.py:377). */
+    int32_t hist_steps; float* window_out; int64_t window_stride;
 } pulse_amp_obs_args;
 int pulse_sizeof_amp_obs_args(void);
 int pulse_amp_obs_width(int num_joints, int num_key_bodies, int root_height_obs);
 int pulse_amp_obs(const pulse_amp_obs_args* args, pulse_stream_t s);
+
+/* _init_amp_obs_ref (phc/env/tasks/humanoid_amp.py:531-563) for the masked envs: history slot k + 1 (k = 0 .. hist_steps - 2) of env e :=
+ * build_amp_observations_smpl of the env's motion at start_times[e] - dt * (k + 1) (MotionLibBase.get_motion_state, motion_lib_base.py:
+ * 434-517, no root offset; no zeroed joints).  hist[e * env_stride + slot * step_stride + c]. */
+typedef struct pulse_amp_hist_args {
+    pulse_motion_tables tab; const int64_t* motion_ids; const float* start_times; float dt;
+    int32_t num_envs; const uint8_t* env_mask; int32_t hist_steps;
+    const int32_t* joint_ids; int32_t num_joints; const int32_t* key_body_ids; int32_t num_key_bodies;
+    int32_t local_root_obs, root_height_obs;
+    float* hist; int64_t env_stride, step_stride;
+} pulse_amp_hist_args;
+int pulse_sizeof_amp_hist_args(void);
+int pulse_amp_hist_init(const pulse_amp_hist_args* args, pulse_stream_t s);
 
 /* ------------------------------------------------------------------------- *
  * 2b. Reference-motion query: MotionLibBase.get_motion_state / get_root_pos_smpl /

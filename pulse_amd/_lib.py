@@ -89,7 +89,16 @@ class AmpObsArgs(Structure):
                 ("num_envs", c_int32), ("env_ids", c_void_p), ("num_ids", c_int32), ("env_mask", c_void_p),
                 ("joint_ids", c_void_p), ("num_joints", c_int32), ("zero_joint_mask", c_uint32),
                 ("key_body_ids", c_void_p), ("num_key_bodies", c_int32), ("local_root_obs", c_int32), ("root_height_obs", c_int32),
-                ("out", c_void_p), ("out_stride", c_int64)]
+                ("out", c_void_p), ("out_stride", c_int64),
+                ("hist_steps", c_int32), ("window_out", c_void_p), ("window_stride", c_int64)]
+
+
+class AmpHistArgs(Structure):
+    _fields_ = [("tab", MotionTables), ("motion_ids", c_void_p), ("start_times", c_void_p), ("dt", c_float),
+                ("num_envs", c_int32), ("env_mask", c_void_p), ("hist_steps", c_int32),
+                ("joint_ids", c_void_p), ("num_joints", c_int32), ("key_body_ids", c_void_p), ("num_key_bodies", c_int32),
+                ("local_root_obs", c_int32), ("root_height_obs", c_int32),
+                ("hist", c_void_p), ("env_stride", c_int64), ("step_stride", c_int64)]
 
 
 class MotionStateArgs(Structure):
@@ -246,6 +255,8 @@ SIGNATURES = {
     "pulse_sizeof_amp_obs_args": (c_int, []),
     "pulse_amp_obs_width": (c_int, [c_int, c_int, c_int]),
     "pulse_amp_obs": (c_int, [POINTER(AmpObsArgs), P]),
+    "pulse_sizeof_amp_hist_args": (c_int, []),
+    "pulse_amp_hist_init": (c_int, [POINTER(AmpHistArgs), P]),
     "pulse_sizeof_rollout_record_args": (c_int, []),
     "pulse_rollout_record": (c_int, [POINTER(RolloutRecordArgs), P]),
     "pulse_kinematic_sim_step": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, P, P, P, P, c_int32, P]),

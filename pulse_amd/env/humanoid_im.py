@@ -26,6 +26,8 @@ kernel advances the episode clock, tests pass_time and blends its t / t+1 refere
 samples future reference frames -- HumanoidIm.{_compute_task_obs, _compute_reward, _compute_reset, _reset_ref_state_init,
 _sample_time} (humanoid_im.py:652-654, 708-919, 920-926, 1119-1192) in three launches per control step.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -179,6 +181,8 @@ class HumanoidIm:
             if self._amp_joint_ids is not None:
                 self._amp_joint_ids = torch.tensor(self._amp_joint_ids, dtype=torch.int32, device=dev)
             self._amp_obs_buf = torch.zeros(n, self._num_amp_obs_steps, self._num_amp_obs_per_step, device=dev)
+            self._amp_fused = os.environ.get("PULSE_AMP_FUSED", "1") != "0"      # fused history update / history init kernels (0: the op-by-op path)
+            self._amp_obs_sink = None
             self._curr_amp_obs_buf = self._amp_obs_buf[:, 0]
             self._hist_amp_obs_buf = self._amp_obs_buf[:, 1:]
             self._amp_obs_space = Box(-float("inf"), float("inf"), (self.get_num_amp_obs(),))
@@ -256,6 +260,11 @@ class HumanoidIm:
     def get_num_amp_obs(self):
         return self._num_amp_obs_steps * self._num_amp_obs_per_step
 
+    def set_amp_obs_sink(self, rows):
+        """The NEXT post_physics_step writes its finished AMP window into ``rows`` ((N, >= S W) float32, any row pitch) as well, and hands
+        that view out as extras['amp_obs'] -- the agent passes the experience-buffer slot of the step, so recording the window costs no copy."""
+        self._amp_obs_sink = rows
+
     def _update_hist_amp_obs(self):
         """humanoid_amp.py:622-631: shift the history by one slot."""
         self._hist_amp_obs_buf.copy_(self._amp_obs_buf[:, 0:self._num_amp_obs_steps - 1].clone())
@@ -273,6 +282,10 @@ class HumanoidIm:
         frames there is no motion to look back into and the history repeats the first frame (_init_amp_obs_default, :526-529)."""
         self._compute_amp_observations(env_mask=mask)
         s = self._num_amp_obs_steps - 1
+        if self._use_motion_lib and self._amp_fused:
+            ops.amp_hist_init(self._motion_lib, self._sampled_motion_ids, self._motion_start_times, self.dt, mask, self._amp_obs_buf, self._key_body_ids,
+                              joint_ids=self._amp_joint_ids, local_root_obs=self._local_root_obs, root_height_obs=self._amp_root_height_obs)
+            return
         if self._use_motion_lib:
             steps = -self.dt * (torch.arange(0, s, device=self.device) + 1)
             times = (self._motion_start_times.unsqueeze(-1) + steps).view(-1)
@@ -447,9 +460,20 @@ class HumanoidIm:
         self.extras["terminate"] = self._terminate_buf
         self.extras["reward_raw"] = self.reward_raw
         if self._enable_amp_obs:                      # HumanoidAMP.post_physics_step (humanoid_amp.py:194-210)
-            self._update_hist_amp_obs()
-            self._compute_amp_observations()
-            self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())
+            if self._amp_fused and self._num_amp_obs_per_step % 4 == 0:
+                # history shift + current frame (+ the finished window straight into the caller's row, e.g. the experience-buffer slot
+                # the agent registered with set_amp_obs_sink) in ONE launch
+                sink = self._amp_obs_sink
+                ops.build_amp_observations_smpl(self.sim.rigid_body_state, self.sim.dof_pos, self.sim.dof_vel, self._key_body_ids,
+                                                joint_ids=self._amp_joint_ids, zero_joints=self._amp_zero_joints, local_root_obs=self._local_root_obs,
+                                                root_height_obs=self._amp_root_height_obs, out=self._curr_amp_obs_buf,
+                                                hist_steps=self._num_amp_obs_steps, window_out=sink)
+                self._amp_obs_sink = None
+                self.extras["amp_obs"] = sink[:, :self.get_num_amp_obs()] if sink is not None else self._amp_obs_buf.view(-1, self.get_num_amp_obs())
+            else:
+                self._update_hist_amp_obs()
+                self._compute_amp_observations()
+                self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())
 
     # ------------------------------------------------------------------ reset
     def reset(self, env_ids=None):

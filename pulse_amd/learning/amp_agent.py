@@ -363,6 +363,13 @@ class AMPAgent(CommonAgent):
     def _action_for_env(self, res_dict):
         return res_dict["mus"] if (self.only_kin_loss and self.save_kin_info) else res_dict["actions"]
 
+    def _before_env_step(self, n):
+        if self.enable_disc:
+            # the env writes the step's finished AMP window straight into experience-buffer slot n (no (N, 1960) copy: update_data sees its own row)
+            task = self.vec_env.env.task
+            if hasattr(task, "set_amp_obs_sink"):
+                task.set_amp_obs_sink(self.experience_buffer.slot("amp_obs", n))
+
     def _after_env_step(self, n, infos):
         if self.enable_disc:
             self.experience_buffer.update_data("amp_obs", n, infos["amp_obs"])          # :377

@@ -335,6 +335,7 @@ class CommonAgent:
             res_dict = self.get_action_values(self.obs, slot=n)
             for k in self.update_list:
                 eb.update_data(k, n, res_dict[k])
+            self._before_env_step(n)
             self.obs, rewards, self.dones, infos = self.env_step(self._action_for_env(res_dict))
             eb.update_data("next_obses", n, self.obs["obs"])
             self._after_env_step(n, infos)
@@ -422,6 +423,9 @@ class CommonAgent:
 
     def _rollout_rewards(self, td):
         return td["rewards"]
+
+    def _before_env_step(self, n):
+        return
 
     def _after_env_step(self, n, infos):
         return

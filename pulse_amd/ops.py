@@ -635,7 +635,7 @@ def amp_obs_width(num_joints, num_key_bodies, root_height_obs=True):
 
 
 def build_amp_observations_smpl(rb, dof_pos, dof_vel, key_body_ids, *, joint_ids=None, zero_joints=(), local_root_obs=True,
-                                root_height_obs=True, out=None, env_ids=None, env_mask=None):
+                                root_height_obs=True, out=None, env_ids=None, env_mask=None, hist_steps=0, window_out=None):
     """phc/env/tasks/humanoid_amp.py:925-969 on the (N, bodies, 13) rigid-body records (root = body 0) and the
     (N, num_dof) dof tensors.  ``joint_ids`` = dof_subset expressed in joints; ``zero_joints`` = joints whose dofs
     read as zero (:636-639).  Writes the first W columns of ``out`` rows (any row pitch) and returns ``out``."""
@@ -668,8 +668,48 @@ def build_amp_observations_smpl(rb, dof_pos, dof_vel, key_body_ids, *, joint_ids
     a.key_body_ids, a.num_key_bodies = kb.data_ptr(), kb.numel()
     a.local_root_obs, a.root_height_obs = int(local_root_obs), int(root_height_obs)
     a.out, a.out_stride = out.data_ptr(), out.stride()[0]
+    if hist_steps and hist_steps > 1:
+        # ``out`` is slot 0 of the (N, hist_steps, W) history: shift + current frame (+ copy of the finished window) in this launch
+        a.hist_steps = int(hist_steps)
+        if window_out is not None:
+            if window_out.dtype != torch.float32 or not window_out.is_cuda or window_out.stride(-1) != 1 or window_out.shape[0] != n:
+                raise TypeError("build_amp_observations_smpl: window_out must be a float32 CUDA tensor with one row per env")
+            a.window_out, a.window_stride = window_out.data_ptr(), window_out.stride(0)
+    elif window_out is not None:
+        raise ValueError("build_amp_observations_smpl: window_out goes with hist_steps > 1")
     _lib.check(lib.pulse_amp_obs(ctypes.byref(a), _stream()), "pulse_amp_obs")
     return out
+
+
+def amp_hist_init(motion_lib, motion_ids, start_times, dt, env_mask, hist, key_body_ids, *, joint_ids=None, local_root_obs=True, root_height_obs=True):
+    """_init_amp_obs_ref (humanoid_amp.py:531-563) for the masked envs: slots 1 .. S-1 of ``hist`` (N, S, W) := the AMP frames of each env's
+    motion at start_times - dt * (k + 1), in one launch (pulse_amp_hist_init)."""
+    lib = _lib.load()
+    dev = hist.device
+    if hist.dtype != torch.float32 or hist.dim() != 3 or hist.stride(2) != 1 or not hist.is_cuda:
+        raise TypeError("amp_hist_init: hist must be a (N, S, W) float32 CUDA tensor")
+    n, s_, w = hist.shape
+    ids = _c(motion_ids, "motion_ids", torch.int64)
+    st = _c(start_times, "start_times", torch.float32)
+    if ids.numel() != n or st.numel() != n:
+        raise ValueError("amp_hist_init: one motion id / start time per env")
+    m = env_mask.view(torch.uint8) if env_mask.dtype == torch.bool else env_mask
+    m = _c(m, "env_mask", torch.uint8)
+    kb = _ids32(key_body_ids, dev)
+    ji = _ids32(joint_ids, dev) if joint_ids is not None else None
+    nj = ji.numel() if ji is not None else motion_lib.num_bodies - 1
+    if lib.pulse_amp_obs_width(nj, kb.numel(), int(root_height_obs)) != w:
+        raise ValueError("amp_hist_init: the history's frame width does not match the joint / key-body selection")
+    a = _lib.AmpHistArgs()
+    motion_lib.fill_tables(a.tab)
+    a.motion_ids, a.start_times, a.dt = ids.data_ptr(), st.data_ptr(), float(dt)
+    a.num_envs, a.env_mask, a.hist_steps = n, m.data_ptr(), s_
+    a.joint_ids, a.num_joints = (ji.data_ptr() if ji is not None else None), nj
+    a.key_body_ids, a.num_key_bodies = kb.data_ptr(), kb.numel()
+    a.local_root_obs, a.root_height_obs = int(local_root_obs), int(root_height_obs)
+    a.hist, a.env_stride, a.step_stride = hist.data_ptr(), hist.stride(0), hist.stride(1)
+    _lib.check(lib.pulse_amp_hist_init(ctypes.byref(a), _stream()), "pulse_amp_hist_init")
+    return hist
 
 
 # --------------------------------------------------------------------------- #

@@ -57,6 +57,6 @@ def test_struct_layout_matches_c():
     lib = _lib.load()
     for cls, fn in ((_lib.TaskStepArgs, "pulse_sizeof_task_step_args"), (_lib.TrajStepArgs, "pulse_sizeof_traj_step_args"),
                     (_lib.PdSimArgs, "pulse_sizeof_pd_sim_args"), (_lib.GemmX3pDesc, "pulse_sizeof_gemm_x3p_desc"),
-                    (_lib.VaeEmbedArgs, "pulse_sizeof_vae_embed_args"), (_lib.VaeKinArgs, "pulse_sizeof_vae_kin_args"),
+                    (_lib.VaeEmbedArgs, "pulse_sizeof_vae_embed_args"), (_lib.AmpHistArgs, "pulse_sizeof_amp_hist_args"), (_lib.VaeKinArgs, "pulse_sizeof_vae_kin_args"),
                     (_lib.VaeHeadBwdArgs, "pulse_sizeof_vae_head_bwd_args")):
         assert ctypes.sizeof(cls) == getattr(lib, fn)(), fn

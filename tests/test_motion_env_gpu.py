@@ -216,3 +216,34 @@ def test_step_returns_a_fresh_observation_like_the_reference(dev):
     env.alias_obs = True
     o3, *_ = env.step(torch.zeros(n, 69, device=dev))
     assert o3.data_ptr() == env.task.obs_buf.data_ptr()
+
+
+def test_fused_amp_window_kernels_equal_the_op_by_op_path(dev, monkeypatch):
+    """pulse_amp_obs in history mode (shift + current frame + window copy in one launch) and pulse_amp_hist_init (history of the reset
+    envs from the motion, one launch) against the op-by-op path they replace (clone / copy_ shift, motion query + AMP frames of all
+    N x 9 rows + where): bit-identical windows over 25 steps with resets, and the window lands in the caller's sink rows."""
+    n, seed = 52, 23
+
+    def run(fused):
+        monkeypatch.setenv("PULSE_AMP_FUSED", "1" if fused else "0")
+        env, _ = configs.make_env(n, 12, dev, seed=seed, env_kind="amp", reference="motion_lib")
+        task = env.task
+        assert task._amp_fused == fused
+        env.reset()
+        out = [task._amp_obs_buf.clone()]
+        sink = torch.full((n, 3, 1964), float("nan"), device=dev)                 # rows of a (N, T, pitch) experience buffer, slot 1
+        for step in range(25):
+            if fused and step % 2 == 0:
+                task.set_amp_obs_sink(sink[:, 1])
+            obs, rew, done, info = env.step(torch.zeros(n, 69, device=dev))
+            if fused and step % 2 == 0:
+                assert info["amp_obs"].data_ptr() == sink[:, 1].data_ptr()          # the extras ARE the sink rows
+                assert torch.equal(sink[:, 1, :1960], task._amp_obs_buf.view(n, -1)) and torch.isnan(sink[:, 0]).all() and torch.isnan(sink[:, 1, 1960:]).all()
+            out.append(info["amp_obs"].clone())
+            env.reset(torch.nonzero(done).flatten())
+            out.append(task._amp_obs_buf.clone())
+        return out
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x.reshape(n, -1), y.reshape(n, -1)), f"window {i} differs"

@@ -381,9 +381,16 @@ typedef struct pulse_rollout_record_args {
     float meter_max_size;                                /* games_to_track */
     uint8_t* done_mask;               /* (N) out: dones != 0 (drives the next masked reset) */
     uint8_t* buf_terminate;           /* optional, slot n like buf_dones: terminate != 0, for a bootstrap pass done after the rollout */
+    /* optional: meter_blocks workgroups share the envs and leave (finished episodes, their return sum, their length sum, 0) per workgroup in
+       meter_partials[block * 4 ..] INSTEAD of updating the meters; pulse_rollout_meters applies the deferred updates of a whole rollout in
+       step order (AverageMeter is only read between epochs) */
+    float* meter_partials; int32_t meter_blocks;
 } pulse_rollout_record_args;
 int pulse_sizeof_rollout_record_args(void);
 int pulse_rollout_record(const pulse_rollout_record_args* args, pulse_stream_t s);
+/* partials: (steps, blocks, 4) as left by ``steps`` pulse_rollout_record launches: the two AverageMeter updates of every step, in order */
+int pulse_rollout_meters(const float* partials, int32_t steps, int32_t blocks, float* meter_rewards, float* meter_lengths, float meter_max_size,
+                         pulse_stream_t s);
 
 /* Physics STAND-IN (Isaac Gym is out of scope): the simulated humanoid tracks a reference state with a recorded
  * perturbation -- rb = target + noise (quaternions re-normalised), dof_pos/vel = target + noise, dof_force = recorded.
@@ -558,7 +565,13 @@ typedef struct pulse_gemm_x3p_desc {
                                                              bf16 matrix.  [red][out] operands (a/b_layout OUT_CONTIG) are read through the
                                                              LDS transposing load in either mode. */
     int32_t aux_is_bf16;                                  /* aux points at a bf16 matrix (ldaux / stride_aux in bf16 elements) */
+    /* optional: per-row-tile column sums of the OUTPUT as stored (after activation / mask / bf16 rounding):
+       out_colsum[z * stride_out_colsum + tile_m * ld_out_colsum + n], tile_m = 0 .. pulse_gemm_x3p_row_tiles(M, N, batch) - 1.  The input-
+       gradient launch that produces a layer's dZ hands over the layer's bias gradient (sum the tile rows) without a pass over dZ. */
+    float* out_colsum; int64_t stride_out_colsum; int32_t ld_out_colsum;
 } pulse_gemm_x3p_desc;
+/* number of row tiles (256 or 128 rows) a launch of this shape uses: the row count of out_colsum */
+int pulse_gemm_x3p_row_tiles(int32_t M, int32_t N, int32_t batch);
 int pulse_sizeof_gemm_x3p_desc(void);
 int pulse_gemm_x3p(const pulse_gemm_x3p_desc* desc, pulse_stream_t s);
 /* fp32 (rows x cols, pitch ld_in floats) -> planes of rows_out x cols_out with pitch ld_out (multiple of 8; columns [cols_out, ld_out)

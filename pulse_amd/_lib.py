@@ -120,7 +120,8 @@ class RolloutRecordArgs(Structure):
                 ("value_mean", c_void_p), ("value_var", c_void_p), ("value_eps", c_float),
                 ("buf_rewards", c_void_p), ("buf_next_values", c_void_p), ("buf_dones", c_void_p), ("env_stride", c_int64),
                 ("current_rewards", c_void_p), ("current_lengths", c_void_p), ("meter_rewards", c_void_p), ("meter_lengths", c_void_p),
-                ("meter_max_size", c_float), ("done_mask", c_void_p), ("buf_terminate", c_void_p)]
+                ("meter_max_size", c_float), ("done_mask", c_void_p), ("buf_terminate", c_void_p),
+                ("meter_partials", c_void_p), ("meter_blocks", c_int32)]
 
 
 class PdSimArgs(Structure):
@@ -190,7 +191,8 @@ class GemmX3pDesc(Structure):
                 ("stride_a", c_int64), ("stride_b", c_int64), ("stride_c", c_int64), ("stride_cp", c_int64), ("stride_c2", c_int64),
                 ("stride_bias", c_int64), ("stride_aux", c_int64),
                 ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
-                ("rowsum", c_void_p), ("stride_rowsum", c_int64), ("planes", c_int32), ("aux_is_bf16", c_int32)]
+                ("rowsum", c_void_p), ("stride_rowsum", c_int64), ("planes", c_int32), ("aux_is_bf16", c_int32),
+                ("out_colsum", c_void_p), ("stride_out_colsum", c_int64), ("ld_out_colsum", c_int32)]
 
 
 class GemmDesc(Structure):
@@ -259,6 +261,7 @@ SIGNATURES = {
     "pulse_amp_hist_init": (c_int, [POINTER(AmpHistArgs), P]),
     "pulse_sizeof_rollout_record_args": (c_int, []),
     "pulse_rollout_record": (c_int, [POINTER(RolloutRecordArgs), P]),
+    "pulse_rollout_meters": (c_int, [P, c_int32, c_int32, P, P, c_float, P]),
     "pulse_kinematic_sim_step": (c_int, [P, P, P, c_int64, c_int32, P, P, P, P, P, P, P, P, c_int32, P]),
     "pulse_sizeof_pd_sim_args": (c_int, []),
     "pulse_pd_sim_step": (c_int, [POINTER(PdSimArgs), P]),
@@ -268,6 +271,7 @@ SIGNATURES = {
     "pulse_sizeof_gemm_desc": (c_int, []),
     "pulse_gemm_f32": (c_int, [POINTER(GemmDesc), P]),
     "pulse_gemm_x3p": (c_int, [POINTER(GemmX3pDesc), P]),
+    "pulse_gemm_x3p_row_tiles": (c_int, [c_int32, c_int32, c_int32]),
     "pulse_traj_step": (c_int, [POINTER(TrajStepArgs), P]),
     "pulse_sizeof_traj_step_args": (c_int, []),
     "pulse_traj_generate": (c_int, [POINTER(TrajGenArgs), P]),

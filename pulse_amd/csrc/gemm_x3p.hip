@@ -61,6 +61,7 @@ struct XpArgs {
     int act, epi;
     int tiles_m, tiles_n;
     float* rowsum; long long sRowsum;
+    float* colsum; long long sColsum; int ldcs;      // optional: per-row-tile column sums of the OUTPUT (colsum[bz * sColsum + tm * ldcs + n])
 };
 
 template <int WMW>
@@ -357,6 +358,7 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
         const int c8 = (tid & 15) * 8;
         const int col = n0 + c8;
         constexpr int RPI = G::NT / 16;                             // rows per iteration
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of what this thread stores (the bias gradient of the producer layer)
         if (col < g.N) {
             const bool full = col + 7 < g.N;
 #pragma unroll 2
@@ -411,6 +413,8 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
                         }
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cs[k] += o[k];
                 if (C) {
                     float* pc = C + (long long)row * g.ldc + col;
                     if (full) {
@@ -436,6 +440,22 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
                         *reinterpret_cast<u32x4*>(pp + 2 * g.pc) = q2;
                     }
                 }
+            }
+        }
+        if (g.colsum) {
+            // Column sums of the tile as stored (rounded, masked): what pulse_colsum_partial_b16 would compute from the written matrix, taken
+            // here while the values are in registers -- the bias gradient of the layer whose dZ this launch produces costs no pass over dZ.
+            // The RPI thread rows of a column group are added in row order (fixed tree: deterministic).
+            __syncthreads();                                        // every read of the transpose image is done
+            float* red = sC;                                        // [RPI][128]
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[(tid >> 4) * PBN + c8 + k] = cs[k];
+            __syncthreads();
+            if (tid < PBN && n0 + tid < g.N) {
+                float t = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < RPI; ++r) t += red[r * PBN + tid];
+                g.colsum[bz * g.sColsum + (long long)tm * g.ldcs + n0 + tid] = t;
             }
         }
     }
@@ -506,6 +526,17 @@ int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t
     return check_launch("pulse_split_planes");
 }
 
+static bool xp_big_tiles(int M, int N, int batch, int split_k) {
+    // 256-row tiles when they still give every CU a workgroup; otherwise 128-row tiles (4 waves)
+    const long long t256 = (long long)((M + 255) / 256) * ((N + PBN - 1) / PBN) * batch * split_k;
+    return t256 >= 256 || M > 128 * 64;
+}
+
+int pulse_gemm_x3p_row_tiles(int32_t M, int32_t N, int32_t batch) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    return xp_big_tiles(M, N, batch, 1) ? (M + 255) / 256 : (M + 127) / 128;
+}
+
 int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     PULSE_REQUIRE(d != nullptr, "pulse_gemm_x3p: null descriptor");
     PULSE_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "pulse_gemm_x3p: negative size");
@@ -559,9 +590,9 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     g.sSplit = d->split_stride;
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
-    // 256-row tiles when they still give every CU a workgroup; otherwise 128-row tiles (4 waves)
-    const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + PBN - 1) / PBN) * d->batch * d->split_k;
-    const bool big = t256 >= 256 || d->M > 128 * 64;
+    g.colsum = d->out_colsum; g.sColsum = d->stride_out_colsum; g.ldcs = d->ld_out_colsum;
+    PULSE_REQUIRE(!d->out_colsum || (d->split_k == 1 && d->ld_out_colsum >= d->N), "pulse_gemm_x3p: out_colsum needs split_k == 1 and a pitch covering N");
+    const bool big = xp_big_tiles(d->M, d->N, d->batch, d->split_k);
     g.tiles_m = big ? (d->M + 255) / 256 : (d->M + 127) / 128;
     g.tiles_n = (d->N + PBN - 1) / PBN;
     PULSE_REQUIRE((long long)d->lda * 300 < (1LL << 29) && (long long)d->ldb * 300 < (1LL << 29), "pulse_gemm_x3p: pitch too large for 32-bit tile-relative offsets");

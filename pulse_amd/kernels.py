@@ -323,7 +323,8 @@ def from_b16(p):
 def make_gemm_x3p_desc(A, B, *, M, N, K, C=None, Cp=None, bias=None, activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None,
                        ldc2=0, ldc=0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_cp=0, stride_c2=0, stride_bias=0, stride_aux=0,
                        a_off=0, b_off=0, c_off=0, cp_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None, planes=3,
-                       a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, split_k=1, split_stride=0, lda=None, ldb=None, ldcp=None):
+                       a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, split_k=1, split_stride=0, lda=None, ldb=None, ldcp=None,
+                       out_colsum=None, out_colsum_off=0, stride_out_colsum=0, ld_out_colsum=None):
     """planes=3: A / B / Cp are planes tensors (3, rows, pitch) int16.  planes=1 (bf16 operands): (rows, pitch) int16 matrices (or flat
     int16 buffers with lda / ldb / ldcp given), aux may be one too (ReLU-mask / SiLU-derivative epilogues reading bf16 activations).
     *_off are element offsets.  Returns (descriptor, algorithmic FLOPs, tag) like make_gemm_desc."""
@@ -356,10 +357,22 @@ def make_gemm_x3p_desc(A, B, *, M, N, K, C=None, Cp=None, bias=None, activation=
     d.stride_a, d.stride_b, d.stride_c, d.stride_cp, d.stride_c2 = stride_a, stride_b, stride_c, stride_cp, stride_c2
     d.stride_bias, d.stride_aux = stride_bias, stride_aux
     d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
+    if out_colsum is not None:             # (row_tiles(M, N, batch), >= covering columns) fp32: per-row-tile column sums of the stored output
+        _chk(out_colsum, "out_colsum")
+        ld = out_colsum.stride(0) if ld_out_colsum is None else ld_out_colsum
+        need = gemm_x3p_row_tiles(M, N, batch)
+        if out_colsum.dim() != 2 or out_colsum.shape[0] < need:
+            raise ValueError(f"gemm_x3p: out_colsum needs {need} rows (one per row tile)")
+        d.out_colsum, d.stride_out_colsum, d.ld_out_colsum = out_colsum.data_ptr() + 4 * out_colsum_off, stride_out_colsum, ld
     flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
     kc_a, kc_b = a_layout == GEMM_RED_CONTIG, b_layout == GEMM_RED_CONTIG
     tag = ("x3p_" if planes == 3 else "b16_") + ("fwd" if kc_a and kc_b else "dx" if kc_a else "dw")
     return d, flops, tag
+
+
+def gemm_x3p_row_tiles(M, N, batch=1):
+    """Row tiles (256 or 128 rows) a pulse_gemm_x3p launch of this shape uses = rows of its out_colsum partials."""
+    return int(_lib.load().pulse_gemm_x3p_row_tiles(int(M), int(N), int(batch)))
 
 
 def launch_gemm_x3p(d, flops=0.0, tag="x3p_fwd", stream=None):
@@ -600,7 +613,7 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9,
 
 def rollout_record(*, rewards, dones, terminate, value_raw, value_stride, value_mean, value_var, value_eps, buf_rewards, buf_next_values,
                    buf_dones, env_stride, current_rewards, current_lengths, meter_rewards, meter_lengths, meter_max_size, done_mask,
-                   reward_scale=1.0, reward_shift=0.0, buf_terminate=None):
+                   reward_scale=1.0, reward_shift=0.0, buf_terminate=None, meter_partials=None):
     """play_steps bookkeeping of one rollout step in one launch (include/pulse_hip.h section 2c)."""
     a = _lib.RolloutRecordArgs()
     a.num_envs = rewards.numel()
@@ -615,7 +628,21 @@ def rollout_record(*, rewards, dones, terminate, value_raw, value_stride, value_
     a.current_rewards, a.current_lengths = _p(current_rewards), _p(current_lengths)
     a.meter_rewards, a.meter_lengths, a.meter_max_size = _p(meter_rewards), _p(meter_lengths), float(meter_max_size)
     a.done_mask, a.buf_terminate = _p(done_mask), _p(buf_terminate)
+    if meter_partials is not None:          # (blocks, 4) row of this step: the meter updates are applied later by rollout_meters
+        _chk(meter_partials, "meter_partials")
+        if meter_partials.dim() != 2 or meter_partials.shape[1] != 4 or not meter_partials.is_contiguous():
+            raise ValueError("rollout_record: meter_partials must be a contiguous (blocks, 4) tensor")
+        a.meter_partials, a.meter_blocks = meter_partials.data_ptr(), meter_partials.shape[0]
     _lib.check(_lib.load().pulse_rollout_record(ctypes.byref(a), _stream()), "pulse_rollout_record")
+
+
+def rollout_meters(partials, meter_rewards, meter_lengths, meter_max_size):
+    """The deferred AverageMeter updates of a rollout: partials (steps, blocks, 4) from rollout_record(meter_partials=partials[step])."""
+    _chk(partials, "partials"), _chk(meter_rewards, "meter_rewards"), _chk(meter_lengths, "meter_lengths")
+    if partials.dim() != 3 or partials.shape[2] != 4 or not partials.is_contiguous():
+        raise ValueError("rollout_meters: partials must be a contiguous (steps, blocks, 4) tensor")
+    _lib.check(_lib.load().pulse_rollout_meters(partials.data_ptr(), partials.shape[0], partials.shape[1], meter_rewards.data_ptr(), meter_lengths.data_ptr(),
+                                               float(meter_max_size), _stream()), "pulse_rollout_meters")
 
 
 def kinematic_sim_step(target_rb, noise_rb, rb, target_dof_pos, noise_dof_pos, dof_pos, target_dof_vel, noise_dof_vel, dof_vel, force_src,

@@ -132,6 +132,7 @@ class CommonAgent:
         self.exp_avg_sq = torch.zeros(n, device=self.ppo_device)
         self.optimizer_step = 0
         self._sq_partials = torch.zeros(256, device=self.ppo_device)
+        self._meter_partials = None
         self._sq_done, self._sq_fuse = set(), False      # parameter groups whose sum-of-squares partials the gradient reduce of this step already produced
         self._grad_norm = torch.zeros(1, device=self.ppo_device)
         self._partials_ring, self._lazy_info, self._ring_pos = None, False, 0
@@ -329,6 +330,8 @@ class CommonAgent:
             if self._rollout_noise is None:
                 self._rollout_noise = torch.empty(self.horizon_length, self.num_actors, self.actions_num, device=self.ppo_device)
             self._rollout_noise.normal_(generator=self.noise_generator)
+        if self._meter_partials is None:
+            self._meter_partials = torch.zeros(self.horizon_length, max(1, min(64, self.num_actors // 128)), 4, device=self.ppo_device)
         for n in range(self.horizon_length):
             self.obs = self._env_reset_masked(done_mask) if done_mask is not None else self.env_reset([])
             eb.update_data("obses", n, self.obs["obs"])
@@ -350,8 +353,10 @@ class CommonAgent:
                              env_stride=self.horizon_length, current_rewards=self.current_rewards, current_lengths=self.current_lengths,
                              meter_rewards=self.game_rewards.state, meter_lengths=self.game_lengths.state, meter_max_size=self.games_to_track,
                              done_mask=self._done_mask, reward_scale=self.rewards_shaper.scale_value, reward_shift=self.rewards_shaper.shift_value,
-                             buf_terminate=eb.phys["terminates"][:, n])
+                             buf_terminate=eb.phys["terminates"][:, n], meter_partials=self._meter_partials[n])
             done_mask = self._done_mask
+        # the AverageMeter updates of the T steps, in step order (the meters are only read between epochs): one launch per rollout
+        K.rollout_meters(self._meter_partials, self.game_rewards.state, self.game_lengths.state, self.games_to_track)
         self._pending_done_mask = done_mask
         self._bootstrap_values()
 

@@ -137,8 +137,12 @@ class DiscNetwork:
         bce = K.Plan()
         bce.transpose_b16(f, self._w2t16, x_off=w2.off, rows=u2, cols=u1, ld_in=w2.pitch, ld_out=u2)
         bce.transpose_b16(f, self._w1t16, x_off=w1.off, rows=u1, cols=k0, ld_in=w1.pitch, ld_out=u1)
-        bce.gemm_b16(dL, f16, M=r3, N=u2, K=1, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2)
-        bce.gemm_b16(Z2, self._w2t16, M=r3, N=u1, K=u2, Cp=Z1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1)
+        # (both launches also hand over the column sums of the dZ rows they store: the bias gradients of layers 2 and 1, see the reduces below)
+        cs2 = ws["colsum2"] = torch.zeros(K.gemm_x3p_row_tiles(r3, u2, 1), u2, dtype=torch.float32, device=self.device)
+        cs1 = ws["colsum1"] = torch.zeros(K.gemm_x3p_row_tiles(r3, u1, 1), u1, dtype=torch.float32, device=self.device)
+        bce.gemm_b16(dL, f16, M=r3, N=u2, K=1, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2,
+                     out_colsum=cs2)
+        bce.gemm_b16(Z2, self._w2t16, M=r3, N=u1, K=u2, Cp=Z1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1, out_colsum=cs1)
         # (2a) penalty forward on the demo rows (stacked as rows 3b..): u2 = m2 * w3, u1 = m1 * (u2 W2), g = u1 W1 (fp32: its square sum is the penalty)
         pf = K.Plan()
         pf.gemm_b16(dL, f16, M=b, N=u2, K=1, a_off=r3 * 32, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, cp_off=r3 * u2,
@@ -172,9 +176,18 @@ class DiscNetwork:
                         split_stride=scr.stride(0))
             wg.call("pulse_reduce_slabs", scr.data_ptr(), split, scr.stride(0), count, slabs.data_ptr() + 4 * lin.off, 1.0)
         wide(Z2, H1, u2, u1, w2)
-        wg.colsum_weighted_b16(H2, dL, 32, m, u2, u2, slabs, S, P, w3.off)      # d w3 = sum over the 4b stacked rows of dL[m] * H2[m][:]
-        for buf, n, ld, off in ((Z1, u1, u1, self.l1.b.off), (Z2, u2, u2, self.l2.b.off), (dL, 1, 32, self.l3.b.off)):
-            wg.colsum_b16(buf, r3, n, ld, slabs, S, P, off)                # one partial row per gradient slab: summed by the slab reduce
+        # d w3 = sum over the 4b stacked rows of dL[m] * H2[m][:]: a weighted column sum (no 1 x u2 GEMM), 32 row chunks into a scratch
+        # (512 workgroups; one partial row per gradient slab would be 128) whose ordered sum lands in slab 0
+        w3c = 32 if m >= 32 * 64 else 1
+        w3s = torch.zeros(w3c, r4(u2), dtype=torch.float32, device=self.device)
+        ws.setdefault("_w_scratch", []).append(w3s)
+        wg.colsum_weighted_b16(H2, dL, 32, m, u2, u2, w3s, w3c, w3s.stride(0), 0)
+        wg.call("pulse_reduce_slabs", w3s.data_ptr(), w3c, w3s.stride(0), u2, slabs.data_ptr() + 4 * w3.off, 1.0)
+        ws["w_slabs"] = (ws["w_slabs"][0], 1, 1)
+        # bias gradients over the 3b BCE rows: layers 1 / 2 from the column sums their dZ launches left (slab 0), the logit bias from dL itself
+        wg.call("pulse_reduce_slabs", cs1.data_ptr(), cs1.shape[0], cs1.stride(0), u1, slabs.data_ptr() + 4 * self.l1.b.off, 1.0)
+        wg.call("pulse_reduce_slabs", cs2.data_ptr(), cs2.shape[0], cs2.stride(0), u2, slabs.data_ptr() + 4 * self.l2.b.off, 1.0)
+        wg.colsum_b16(dL, r3, 1, 32, slabs, S, P, self.l3.b.off)
         return fwd, bce, pf, pb, wg
 
     def _plan_forward(self, ws, m, x=None, logits=None, bf16=False):

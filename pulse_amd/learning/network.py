@@ -311,17 +311,21 @@ class A2CNetwork:
             p.transpose_b16(f, self._wt16[l], x_off=self.w_off[l], rows=u[l], cols=u[l - 1], ld_in=u[l - 1], ld_out=u[l], batch=2,
                             stride_in=u[l] * u[l - 1], stride_out=u[l - 1] * u[l])
         # heads -> dZ_L of both nets (K = head rows: tiny; W_heads read as the [red][out] operand it is)
+        # every launch that produces a layer's dZ also hands over per-row-tile column sums of what it stored (out_colsum): the layer's bias
+        # gradient is their ordered sum -- a few-KB reduce into slab 0 instead of a pass over the (m, 2 u) dZ matrix
+        cs = ws["colsum16"] = [torch.zeros(K.gemm_x3p_row_tiles(m, uu, 2), 2 * uu, dtype=torch.float32, device=self.device) for uu in u]
         p.gemm_b16(dh16, f16, M=m, N=uL, K=hr, ldb=uL, b_off=self.wh_off, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=hp, stride_b=hr * uL,
-                   Cp=dz[-1], stride_cp=uL, epilogue=egrad, aux=aux[-1], ldaux=ld_aux(aux[-1]), stride_aux=uL, algo_k=(self.actions_num + 1) / 2.0)
+                   Cp=dz[-1], stride_cp=uL, epilogue=egrad, aux=aux[-1], ldaux=ld_aux(aux[-1]), stride_aux=uL, algo_k=(self.actions_num + 1) / 2.0,
+                   out_colsum=cs[-1], stride_out_colsum=uL)
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
             p.gemm_b16(dz[l], self._wt16[l], M=m, N=up, K=uu, ldb=uu, batch=2, stride_a=uu, stride_b=up * uu, Cp=dz[l - 1], stride_cp=up,
-                       epilogue=egrad, aux=aux[l - 1], ldaux=ld_aux(aux[l - 1]), stride_aux=up)
+                       epilogue=egrad, aux=aux[l - 1], ldaux=ld_aux(aux[l - 1]), stride_aux=up, out_colsum=cs[l - 1], stride_out_colsum=up)
         uu, k = u[0], self.in_w[0]
         s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split(((2 * uu + 255) // 256) * ((k + 127) // 128), S, fill=256)
         p.gemm_b16(dz[0], ws["x16"], M=2 * uu, N=k, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=k, c_off=self.w_off[0],
                    split_k=s1, split_stride=P, algo_n=self.in_dim)
-        p.colsum_b16(dz[0], m, 2 * uu, 2 * uu, slabs, s1, P, self.b_off[0])      # the layer-1 bucket is reduced over its own s1 slabs
+        p.call("pulse_reduce_slabs", cs[0].data_ptr(), cs[0].shape[0], cs[0].stride(0), 2 * uu, slabs.data_ptr() + 4 * self.b_off[0], 1.0)   # bias 1 -> slab 0
         p.split = len(p.ops)
         hs, HS = self._head_scratch, self._head_split if m >= 96 * self._head_split else 1
         hb = self.bh_off - self.wh_off
@@ -336,7 +340,7 @@ class A2CNetwork:
             sl = K.dw_split(2 * ((uu + 255) // 256) * ((up + 127) // 128), S, fill=256)
             p.gemm_b16(dz[l], h16[l - 1], M=uu, N=up, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up,
                        C=slabs, ldc=up, stride_c=uu * up, c_off=self.w_off[l], split_k=sl, split_stride=P)
-            p.colsum_b16(dz[l], m, 2 * uu, 2 * uu, slabs, S, P, self.b_off[l])
+            p.call("pulse_reduce_slabs", cs[l].data_ptr(), cs[l].shape[0], cs[l].stride(0), 2 * uu, slabs.data_ptr() + 4 * self.b_off[l], 1.0)
         return p
 
     def _plan_forward(self, ws, m, n0, cnt, bf16=False, planar=False):

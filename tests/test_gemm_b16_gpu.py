@@ -146,3 +146,23 @@ def test_b16_rejects_bad_geometry(dev):
         K.launch_gemm_x3p(d, flops, tag)
     with pytest.raises(RuntimeError, match="split-K"):
         K.gemm_x3p(a, b, M=64, N=64, K=64, C=c, ldc=64, planes=1, split_k=2, split_stride=4096)
+
+
+@pytest.mark.parametrize("m,n,k,batch", [(16384, 1024, 512, 2), (12288, 512, 1, 1), (300, 200, 96, 1), (4096, 1024, 1960, 1)])
+def test_b16_output_column_sums(dev, m, n, k, batch):
+    """out_colsum: per-row-tile column sums of the output AS STORED (masked, bf16-rounded) -- the bias gradient of the layer whose dZ the
+    launch produces.  Summed over the tiles they equal the column sums of the written bf16 matrix."""
+    a, b = _rand(m, batch * k, dev, m + k), _rand(batch * n, k, dev, n + k, 0.05)
+    h = _rand(m, batch * n, dev, 3)
+    pa, pb, ph = K.to_b16(a), K.to_b16(b), K.to_b16(h)
+    cp = K.alloc_b16(m, batch * n, dev)
+    tiles = K.gemm_x3p_row_tiles(m, n, batch)
+    cs = torch.full((tiles + 1, batch * n + 4), float("nan"), device=dev)
+    kp = K.planes_pitch(k)
+    K.gemm_x3p(pa, pb, M=m, N=n, K=k, Cp=cp, planes=1, batch=batch, stride_a=k if batch > 1 else 0, stride_b=n * kp, stride_cp=n, epilogue=EPI_RELU_GRAD,
+               aux=ph, ldaux=ph.stride(0), stride_aux=n, out_colsum=cs, stride_out_colsum=n) if batch == 1 or k % 8 == 0 else pytest.skip("batch stride")
+    got = cs[:tiles, :batch * n].double().sum(0)
+    want = K.from_b16(cp)[:, :batch * n].double().sum(0)
+    assert torch.isnan(cs[tiles]).all() and torch.isnan(cs[:tiles, batch * n:]).all()
+    scale = K.from_b16(cp)[:, :batch * n].abs().double().sum(0).max().item() + 1e-9
+    assert (got - want).abs().max().item() <= 2e-6 * scale

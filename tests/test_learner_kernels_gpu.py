@@ -421,6 +421,45 @@ def test_rollout_record_matches_reference_sequence(dev):
     assert buf_r[:, :slot].abs().sum() == 0 and buf_r[:, slot + 1:].abs().sum() == 0      # only slot `slot` was written
 
 
+def test_rollout_record_multi_block_with_deferred_meters(dev):
+    """meter_partials: several workgroups share the envs and the AverageMeter updates of a whole rollout are applied afterwards, in step
+    order, by pulse_rollout_meters -- same buffers, accumulators and meters as the one-workgroup launch that updates them per step."""
+    from pulse_amd import kernels as K
+    torch.manual_seed(8)
+    n, t, steps, max_size, blocks = 5000, 6, 5, 100, 17
+
+    def run(deferred):
+        g = torch.Generator().manual_seed(3)
+        st = {"cur_r": (torch.rand(n, generator=g) * 5).to(dev), "cur_l": torch.randint(1, 200, (n,), generator=g).float().to(dev),
+              "meter_r": torch.tensor([1.5, 40.0], device=dev), "meter_l": torch.tensor([120.0, 40.0], device=dev)}
+        buf_r, buf_d = torch.zeros(n, t, 1, device=dev), torch.zeros(n, t, dtype=torch.uint8, device=dev)
+        buf_t = torch.zeros(n, t, dtype=torch.uint8, device=dev)
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        part = torch.full((steps, blocks, 4), float("nan"), device=dev) if deferred else None
+        masks = []
+        for step in range(steps):
+            rew = torch.rand(n, generator=g).to(dev)
+            dones = (torch.rand(n, generator=g) < (0.0 if step == 2 else 0.2)).long().to(dev)
+            term = (dones * (torch.rand(n, generator=g) < 0.5).long().to(dev))
+            K.rollout_record(rewards=rew, dones=dones, terminate=term, value_raw=None, value_stride=0, value_mean=None, value_var=None, value_eps=0.0,
+                             buf_rewards=buf_r[:, step], buf_next_values=None, buf_dones=buf_d[:, step], env_stride=t, current_rewards=st["cur_r"],
+                             current_lengths=st["cur_l"], meter_rewards=st["meter_r"], meter_lengths=st["meter_l"], meter_max_size=max_size, done_mask=mask,
+                             buf_terminate=buf_t[:, step], meter_partials=part[step] if deferred else None)
+            masks.append(mask.clone())
+        if deferred:
+            assert torch.equal(st["meter_r"].cpu(), torch.tensor([1.5, 40.0]))          # untouched until the deferred pass
+            K.rollout_meters(part, st["meter_r"], st["meter_l"], max_size)
+        return st, buf_r, buf_d, buf_t, masks
+    a, b = run(True), run(False)
+    for k in ("cur_r", "cur_l"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    for x, y in zip(a[1:4], b[1:4]):
+        assert torch.equal(x, y)
+    assert all(torch.equal(x, y) for x, y in zip(a[4], b[4]))
+    np.testing.assert_allclose(a[0]["meter_r"].cpu().numpy(), b[0]["meter_r"].cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(a[0]["meter_l"].cpu().numpy(), b[0]["meter_l"].cpu().numpy(), rtol=2e-6)
+
+
 @pytest.mark.parametrize("m_out,n_out,k_red,split,batch", [(200, 130, 1000, 1, 1), (70, 512, 4096, 8, 2), (1024, 70, 5000, 4, 1)])
 def test_gemm_rowsum_is_the_bias_gradient(f32_mode, dev, m_out, n_out, k_red, split, batch):
     """dW pass with pulse_gemm_desc.rowsum: slab sums of the A operand's columns == dY.sum(0) (bias gradient)."""

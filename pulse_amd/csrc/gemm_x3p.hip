@@ -27,6 +27,7 @@
 // the bytes of the fp32-storage bf16 kernel in gemm_f32.hip, which is bound by exactly that traffic.  Same pipeline: the three plane
 // slots of a stage hold three CONSECUTIVE 32-deep k-tiles of the one plane, a k step is the three diagonal products (12 MFMAs) instead
 // of the six cross terms, and k-tiles past the reduction's end are skipped (their slots hold stale bytes nobody multiplies).
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -99,6 +100,136 @@ __device__ __forceinline__ bf16x8 xp_lds_tr(int addr_lo, int addr_hi) {
     // reaches it is silently not emitted (its launch stub goes missing at link time)
     return bf16x8{};
 #endif
+}
+
+// ---- epilogue shared by the planar kernels: accumulators -> LDS (fp32, pitch CPF) -> rows of 8 consecutive columns per lane -> fp32 C and / or
+// the output's own planes (bf16 matrix in single-plane mode), optional per-row-tile column sums.  The caller has drained its DMA and passed a
+// barrier: the staging buffers are free.
+template <int WMW, int NPL>
+__device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2], int tid, int wm, int wn, int half, int l31, int m0, int n0, int bz,
+                                            int sp, int tm) {
+    using G = XpGeom<WMW>;
+    constexpr int BM = G::BM;
+    extern __shared__ __attribute__((aligned(16))) char xp_smem[];
+    float* sC = reinterpret_cast<float*>(xp_smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * G::CPF + wn * 64 + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    {
+        float* C = g.C ? g.C + bz * g.sC + sp * g.sSplit : nullptr;
+        float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
+        unsigned short* Cp = g.Cp ? g.Cp + bz * g.sCp : nullptr;
+        const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+        const unsigned short* aux16 = g.aux16 ? g.aux16 + bz * g.sAux : nullptr;
+        const int c8 = (tid & 15) * 8;
+        const int col = n0 + c8;
+        constexpr int RPI = G::NT / 16;                             // rows per iteration
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of what this thread stores (the bias gradient of the producer layer)
+        if (col < g.N) {
+            const bool full = col + 7 < g.N;
+#pragma unroll 2
+            for (int rl = tid >> 4; rl < BM; rl += RPI) {
+                const int row = m0 + rl;
+                if (row >= g.M) break;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4);
+                float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if constexpr (NPL == 1) {
+                    // a bf16 autocast Linear hands bf16 to the next op: the product leaves rounded, the activation / mask acts on that
+                    // (split-K slabs are partial sums and stay fp32)
+                    if (g.splitk == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = (float)(__bf16)o[k];
+                    }
+                }
+                if (g.epi == 0) {
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
+                    } else if (g.act == 2) {
+                        if (C2) {
+                            float* p2 = C2 + (long long)row * g.ldc2 + col;
+                            if (full) { *reinterpret_cast<f32x4*>(p2) = (f32x4){o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(p2 + 4) = (f32x4){o[4], o[5], o[6], o[7]}; }
+                            else for (int k = 0; k < 8 && col + k < g.N; ++k) p2[k] = o[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
+                    }
+                } else {
+                    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (aux16) {                                    // bf16-stored activations (rows hold roundup8(N) columns)
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(aux16 + (long long)row * g.ldaux + col);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { a8[2 * k] = xp_bitsf(t[k] << 16); a8[2 * k + 1] = xp_bitsf(t[k] & 0xffff0000u); }
+                    } else {
+                        const float* pa = aux + (long long)row * g.ldaux + col;
+                        if (full) {
+                            const f32x4 t0 = *reinterpret_cast<const f32x4*>(pa), t1 = *reinterpret_cast<const f32x4*>(pa + 4);
+                            a8[0] = t0.x; a8[1] = t0.y; a8[2] = t0.z; a8[3] = t0.w; a8[4] = t1.x; a8[5] = t1.y; a8[6] = t1.z; a8[7] = t1.w;
+                        } else for (int k = 0; k < 8 && col + k < g.N; ++k) a8[k] = pa[k];
+                    }
+                    if (g.epi == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = a8[k] > 0.f ? o[k] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float sg = 1.f / (1.f + __expf(-a8[k]));
+                            o[k] *= sg * (1.f + a8[k] * (1.f - sg));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cs[k] += o[k];
+                if (C) {
+                    float* pc = C + (long long)row * g.ldc + col;
+                    if (full) {
+                        *reinterpret_cast<f32x4*>(pc) = (f32x4){o[0], o[1], o[2], o[3]};
+                        *reinterpret_cast<f32x4*>(pc + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                    } else for (int k = 0; k < 8 && col + k < g.N; ++k) pc[k] = o[k];
+                }
+                if (Cp) {
+                    // the output's own planes: columns past N inside this 8-group are written as zeros (they are k padding of the consumer)
+                    u32x4 q0, q1, q2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float a = col + 2 * k < g.N ? o[2 * k] : 0.f, b = col + 2 * k + 1 < g.N ? o[2 * k + 1] : 0.f;
+                        unsigned x0, x1 = 0u, x2 = 0u;
+                        if constexpr (NPL == 3) xp_split_pair(a, b, x0, x1, x2);
+                        else x0 = xp_pack_rn(a, b);
+                        q0[k] = x0; q1[k] = x1; q2[k] = x2;
+                    }
+                    unsigned short* pp = Cp + (long long)row * g.ldcp + col;
+                    *reinterpret_cast<u32x4*>(pp) = q0;
+                    if constexpr (NPL == 3) {
+                        *reinterpret_cast<u32x4*>(pp + g.pc) = q1;
+                        *reinterpret_cast<u32x4*>(pp + 2 * g.pc) = q2;
+                    }
+                }
+            }
+        }
+        if (g.colsum) {
+            // Column sums of the tile as stored (rounded, masked): what pulse_colsum_partial_b16 would compute from the written matrix, taken
+            // here while the values are in registers -- the bias gradient of the layer whose dZ this launch produces costs no pass over dZ.
+            // The RPI thread rows of a column group are added in row order (fixed tree: deterministic).
+            __syncthreads();                                        // every read of the transpose image is done
+            float* red = sC;                                        // [RPI][128]
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[(tid >> 4) * PBN + c8 + k] = cs[k];
+            __syncthreads();
+            if (tid < PBN && n0 + tid < g.N) {
+                float t = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < RPI; ++r) t += red[r * PBN + tid];
+                g.colsum[bz * g.sColsum + (long long)tm * g.ldcs + n0 + tid] = t;
+            }
+        }
+    }
 }
 
 // AKC / BKC: operand stored [out][k] (reduction-contiguous); otherwise [k][out].
@@ -339,126 +470,221 @@ __global__ void __launch_bounds__(128 * WMW) gemm_x3p_kernel(const XpArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                // the epilogue reuses the staging buffers
 
-    // ---- epilogue: accumulators -> LDS (fp32, pitch CPF) -> rows of 8 consecutive columns per lane -> fp32 C and / or the three planes
-    float* sC = reinterpret_cast<float*>(xp_smem);
+    xp_epilogue<WMW, NPL>(g, acc, tid, wm, wn, half, l31, m0, n0, bz, sp, tm);
+}
+
+// =====================================================================================================================
+// bf16-storage GEMM, three-stage ring ("b16r"): the single-plane kernel above is not limited by the matrix pipe or by power but by the
+// latency of its stage DMA (profiles/r04_gemm_b16_pmc.txt: pipe 0.17-0.29 busy at 2.2-2.5 GHz, waves waiting 0.42-0.83 of their cycles):
+// with two 72 KB stages only one stage of DMA is ever in flight, issued one stage (1536 SIMD cycles = 0.65 us) before it is needed.
+// Same tile (256 x 128, 8 waves of 64 x 64), same fragment / MFMA / epilogue code, but
+//   * a stage is 64 k (two 32-deep k-tiles, 48 KB) and THREE stages ring through the same 144 KB: two stages of DMA are in flight while the
+//     third is multiplied, and a stage is issued two stages (2048 SIMD cycles) before its first fragment read;
+//   * a reduction-contiguous operand is fetched in whole 128-byte lines: one wave instruction = 8 rows x 128 B (both k-tiles of a row),
+//     LDS image [row][8 chunks of 16 B], chunk c of row r at slot c ^ (r & 7) -- eight consecutive rows of a fragment read hit eight
+//     different 16-byte bank groups.  (The two-stage kernel fetches 16 rows x 64 B: every line is requested twice, by different instructions.)
+//   * [red][out] operands keep the transposing-read image of the kernel above, two sub-tiles per stage.
+// One barrier per stage, placed before the stage's last k-step: behind it the first fragments of the next stage are read and the DMA of
+// stage t + 3 is issued into the buffer stage t has just released.
+struct B16rGeom {
+    static constexpr int BM = 256, NW = 8, NT = 512, SUBS = 2, NST = 3;
+    static constexpr int A_IMG = BM * 64 * SUBS, B_IMG = PBN * 64 * SUBS, STAGE = A_IMG + B_IMG;       // 32 + 16 KB
+    static constexpr int A_SUB = BM * 64, B_SUB = PBN * 64;                                         // one 32-deep sub-tile ([red][out] image)
+    static constexpr int DMA_PER_WAVE = (STAGE / 1024) / NW;                                        // 6
+};
+static_assert(3 * B16rGeom::STAGE + XpGeom<4>::TOUCH_LDS <= XpGeom<4>::LDS, "the ring and the touch strip fit the launch's LDS");
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(512) gemm_b16r_kernel(const XpArgs g) {
+    using R = B16rGeom;
+    extern __shared__ __attribute__((aligned(16))) char xp_smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const WgMap wgm = map_workgroup(g.tiles_m * g.tiles_n, g.batch, g.splitk);
+    const int id = wgm.id;
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int m0 = tm * R::BM, n0 = tn * PBN;
+    const int bz = wgm.bz, sp = wgm.sp;
+    const int kbeg = sp * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int klen = kend - kbeg;
+    const int nkt32 = (klen + PK - 1) / PK;
+    const int kpad = nkt32 * PK;
+    const int nst = (nkt32 + 1) / 2;                                 // 64-deep stages
+
+    const int extA = min(R::BM, g.M - m0), extB = min(PBN, g.N - n0);
+    const unsigned short* a = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
+    const unsigned short* b = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
+    const unsigned ra = (unsigned)(AKC ? ((extA - 1) * g.lda + kpad) : ((klen - 1) * g.lda + ((extA + 7) & ~7))) * 2u;
+    const unsigned rb_ = (unsigned)(BKC ? ((extB - 1) * g.ldb + kpad) : ((klen - 1) * g.ldb + ((extB + 7) & ~7))) * 2u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a), 0, klen > 0 ? ra : 0u, P_RSRC);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(b), 0, klen > 0 ? rb_ : 0u, P_RSRC);
+    // per-lane DMA source offsets (bytes).  KC: lane L -> row L >> 3 of the 8-row block, LDS slot L & 7 holding chunk (L & 7) ^ (L >> 3).
+    // MC: as in the two-stage kernel (4 k rows x 16 pieces).
+    const int voA = AKC ? ((lane >> 3) * g.lda + (((lane & 7) ^ (lane >> 3)) << 3)) * 2
+                        : ((lane >> 4) * g.lda + (((lane & 15) ^ ((lane >> 4) << 2)) << 3)) * 2;
+    const int voB = BKC ? ((lane >> 3) * g.ldb + (((lane & 7) ^ (lane >> 3)) << 3)) * 2
+                        : ((lane >> 4) * g.ldb + (((lane & 15) ^ ((lane >> 4) << 2)) << 3)) * 2;
+    const int stA = AKC ? 64 * 2 : 64 * g.lda * 2, stB = BKC ? 64 * 2 : 64 * g.ldb * 2;      // bytes per 64-deep stage
+    // unit j of this wave = instruction i = wave + 8 j of the stage's 48 (32 of A, 16 of B)
+    auto issue_unit = [&](int stage_off, int t, int j) {
+        const int i = wave + j * R::NW;
+        if (j * R::NW < 32) {                                        // (j < 4: A; compile-time after unrolling)
+            int so, dst;
+            if constexpr (AKC) { so = t * stA + i * 8 * g.lda * 2; dst = i * 1024; }
+            else {
+                const int sub = i >> 4, rb = i & 15;                  // sub-tile, row block (8 k groups x 2 out halves of 128)
+                so = t * stA + sub * 32 * g.lda * 2 + (rb & 7) * 4 * g.lda * 2 + (rb >> 3) * 256;
+                dst = sub * R::A_SUB + rb * 1024;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(xp_smem + stage_off + dst), 16, voA, so, 0, 0);
+        } else {
+            const int ib = i - 32;
+            int so, dst;
+            if constexpr (BKC) { so = t * stB + ib * 8 * g.ldb * 2; dst = ib * 1024; }
+            else {
+                const int sub = ib >> 3, rb = ib & 7;                 // 8 k groups, one out block of 128
+                so = t * stB + sub * 32 * g.ldb * 2 + rb * 4 * g.ldb * 2;
+                dst = sub * R::B_SUB + rb * 1024;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(xp_smem + stage_off + R::A_IMG + dst), 16, voB, so, 0, 0);
+        }
+    };
+    auto issue_stage = [&](int stage_off, int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < R::DMA_PER_WAVE; ++j) issue_unit(stage_off, t, j);
+    };
+    // L2 touch prefetch of [red][out] operands (see the two-stage kernel): every 128-byte line of stage t is touched two stages before its
+    // DMA is issued.  Always issued (past the reduction's end the range check drops them): the barrier waits count them.
+    constexpr int LPR_A = R::BM * 2 / 128, LPR_B = PBN * 2 / 128;
+    // (only the weight-gradient form, both operands [red][out]: measured, the touches cost the mixed form 4-8 %)
+    constexpr int TCH_A = (AKC || BKC) ? 0 : 64 * LPR_A / 64, TCH_B = (AKC || BKC) ? 0 : 64 * LPR_B / 64;
+    constexpr int TPW = (TCH_A + TCH_B > 0) ? (TCH_A + TCH_B + R::NW - 1) / R::NW : 0;
+    auto touch_stage = [&](int t) {
+        if constexpr (TPW > 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * G::CPF + wn * 64 + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
-    {
-        float* C = g.C ? g.C + bz * g.sC + sp * g.sSplit : nullptr;
-        float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
-        unsigned short* Cp = g.Cp ? g.Cp + bz * g.sCp : nullptr;
-        const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
-        const unsigned short* aux16 = g.aux16 ? g.aux16 + bz * g.sAux : nullptr;
-        const int c8 = (tid & 15) * 8;
-        const int col = n0 + c8;
-        constexpr int RPI = G::NT / 16;                             // rows per iteration
-        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of what this thread stores (the bias gradient of the producer layer)
-        if (col < g.N) {
-            const bool full = col + 7 < g.N;
-#pragma unroll 2
-            for (int rl = tid >> 4; rl < BM; rl += RPI) {
-                const int row = m0 + rl;
-                if (row >= g.M) break;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4);
-                float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                if constexpr (NPL == 1) {
-                    // a bf16 autocast Linear hands bf16 to the next op: the product leaves rounded, the activation / mask acts on that
-                    // (split-K slabs are partial sums and stay fp32)
-                    if (g.splitk == 1) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = (float)(__bf16)o[k];
-                    }
-                }
-                if (g.epi == 0) {
-                    if (g.act == 1) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
-                    } else if (g.act == 2) {
-                        if (C2) {
-                            float* p2 = C2 + (long long)row * g.ldc2 + col;
-                            if (full) { *reinterpret_cast<f32x4*>(p2) = (f32x4){o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(p2 + 4) = (f32x4){o[4], o[5], o[6], o[7]}; }
-                            else for (int k = 0; k < 8 && col + k < g.N; ++k) p2[k] = o[k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
-                    }
+            for (int j = 0; j < TPW; ++j) {
+                const int u = (wave + j * R::NW) % (TCH_A + TCH_B);
+                if (u < TCH_A) {
+                    const int q = 64 * u + lane;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(xp_smem + XpGeom<4>::TOUCH_OFF + wave * 256), 4,
+                                                             (q / LPR_A) * g.lda * 2 + (q % LPR_A) * 128, t * stA, 0, 0);
                 } else {
-                    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    if (aux16) {                                    // bf16-stored activations (rows hold roundup8(N) columns)
-                        const u32x4 t = *reinterpret_cast<const u32x4*>(aux16 + (long long)row * g.ldaux + col);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { a8[2 * k] = xp_bitsf(t[k] << 16); a8[2 * k + 1] = xp_bitsf(t[k] & 0xffff0000u); }
-                    } else {
-                        const float* pa = aux + (long long)row * g.ldaux + col;
-                        if (full) {
-                            const f32x4 t0 = *reinterpret_cast<const f32x4*>(pa), t1 = *reinterpret_cast<const f32x4*>(pa + 4);
-                            a8[0] = t0.x; a8[1] = t0.y; a8[2] = t0.z; a8[3] = t0.w; a8[4] = t1.x; a8[5] = t1.y; a8[6] = t1.z; a8[7] = t1.w;
-                        } else for (int k = 0; k < 8 && col + k < g.N; ++k) a8[k] = pa[k];
-                    }
-                    if (g.epi == 1) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = a8[k] > 0.f ? o[k] : 0.f;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const float sg = 1.f / (1.f + __expf(-a8[k]));
-                            o[k] *= sg * (1.f + a8[k] * (1.f - sg));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) cs[k] += o[k];
-                if (C) {
-                    float* pc = C + (long long)row * g.ldc + col;
-                    if (full) {
-                        *reinterpret_cast<f32x4*>(pc) = (f32x4){o[0], o[1], o[2], o[3]};
-                        *reinterpret_cast<f32x4*>(pc + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-                    } else for (int k = 0; k < 8 && col + k < g.N; ++k) pc[k] = o[k];
-                }
-                if (Cp) {
-                    // the output's own planes: columns past N inside this 8-group are written as zeros (they are k padding of the consumer)
-                    u32x4 q0, q1, q2;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float a = col + 2 * k < g.N ? o[2 * k] : 0.f, b = col + 2 * k + 1 < g.N ? o[2 * k + 1] : 0.f;
-                        unsigned x0, x1 = 0u, x2 = 0u;
-                        if constexpr (NPL == 3) xp_split_pair(a, b, x0, x1, x2);
-                        else x0 = xp_pack_rn(a, b);
-                        q0[k] = x0; q1[k] = x1; q2[k] = x2;
-                    }
-                    unsigned short* pp = Cp + (long long)row * g.ldcp + col;
-                    *reinterpret_cast<u32x4*>(pp) = q0;
-                    if constexpr (NPL == 3) {
-                        *reinterpret_cast<u32x4*>(pp + g.pc) = q1;
-                        *reinterpret_cast<u32x4*>(pp + 2 * g.pc) = q2;
-                    }
+                    const int q = 64 * (u - TCH_A) + lane;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(xp_smem + XpGeom<4>::TOUCH_OFF + wave * 256), 4,
+                                                             (q / LPR_B) * g.ldb * 2 + (q % LPR_B) * 128, t * stB, 0, 0);
                 }
             }
         }
-        if (g.colsum) {
-            // Column sums of the tile as stored (rounded, masked): what pulse_colsum_partial_b16 would compute from the written matrix, taken
-            // here while the values are in registers -- the bias gradient of the layer whose dZ this launch produces costs no pass over dZ.
-            // The RPI thread rows of a column group are added in row order (fixed tree: deterministic).
-            __syncthreads();                                        // every read of the transpose image is done
-            float* red = sC;                                        // [RPI][128]
+    };
+
+    // fragment read addresses of k-step q4 = 2 kt + ks (kt: 32-deep k-tile of the stage, ks: its 16-deep half), MFMA tile i
+    int frA[2][4], frB[2][4];
+    {
+        const int gq = lane >> 4, jj = (lane >> 2) & 3, qq = lane & 3;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) red[(tid >> 4) * PBN + c8 + k] = cs[k];
-            __syncthreads();
-            if (tid < PBN && n0 + tid < g.N) {
-                float t = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < RPI; ++r) t += red[r * PBN + tid];
-                g.colsum[bz * g.sColsum + (long long)tm * g.ldcs + n0 + tid] = t;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int kt = q4 >> 1, ks = q4 & 1;
+                if constexpr (AKC) {
+                    const int row = wm * 64 + i * 32 + l31;
+                    frA[i][q4] = row * 128 + (((4 * kt + 2 * ks + half) ^ (row & 7)) << 4);
+                } else {
+                    const int o = wm * 64 + i * 32 + 16 * (gq & 1);
+                    const int piece = ((o & 127) >> 3) + (qq >> 1);
+                    frA[i][q4] = kt * R::A_SUB + (o >> 7) * 8192 + (ks * 16 + 8 * (gq >> 1) + jj) * 256 + ((piece ^ (jj << 2)) << 4) + (qq & 1) * 8;
+                }
+                if constexpr (BKC) {
+                    const int row = wn * 64 + i * 32 + l31;
+                    frB[i][q4] = R::A_IMG + row * 128 + (((4 * kt + 2 * ks + half) ^ (row & 7)) << 4);
+                } else {
+                    const int o = wn * 64 + i * 32 + 16 * (gq & 1);
+                    const int piece = (o >> 3) + (qq >> 1);
+                    frB[i][q4] = R::A_IMG + kt * R::B_SUB + (ks * 16 + 8 * (gq >> 1) + jj) * 256 + ((piece ^ (jj << 2)) << 4) + (qq & 1) * 8;
+                }
             }
-        }
     }
+
+    f32x16 acc[2][2];
+    {
+        float b0 = 0.f, b1 = 0.f;
+        if (g.epi == 0 && g.bias) {
+            const float* bias = g.bias + bz * g.sBias;
+            const int c0 = n0 + wn * 64 + l31;
+            if (c0 < g.N) b0 = bias[c0];
+            if (c0 + 32 < g.N) b1 = bias[c0 + 32];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][0][r] = b0; acc[i][1][r] = b1; }
+    }
+
+    bf16x8 fa[2][2], fb[2][2];                                       // [set][mfma tile]
+    auto rdA = [&](int addr) { if constexpr (AKC) return xp_lds128(addr); else return xp_lds_tr(addr, addr + 1024); };
+    auto rdB = [&](int addr) { if constexpr (BKC) return xp_lds128(addr); else return xp_lds_tr(addr, addr + 1024); };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    auto frag_unit = [&](auto set_tag, int u, int st, int q4) {       // u = 0..3: A0 A1 B0 B1
+        constexpr int S = decltype(set_tag)::value;
+        if (u < 2) fa[S][u] = rdA(st + frA[u][q4]);
+        else fb[S][u - 2] = rdB(st + frB[u - 2][q4]);
+    };
+    // the four MFMAs of a k-step on set S, slot(q) after each
+    auto kstep = [&](auto set_tag, bool live, auto&& slot) {
+        constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = q >> 1, j = q & 1;
+            if (live) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);
+            slot(q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: stages 0, 1, 2 on their way; stage 0 landed; its first fragments read
+    if (nst > 0) issue_stage(0, 0);
+    if (nst > 1) issue_stage(R::STAGE, 1);
+    if (nst > 2) issue_stage(2 * R::STAGE, 2);
+    touch_stage(3);
+    touch_stage(4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * R::DMA_PER_WAVE + 2 * TPW) : "memory");
+    else if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R::DMA_PER_WAVE + 2 * TPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * TPW) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (nst > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) frag_unit(I0{}, u, 0, 0);
+    }
+
+    int cur = 0, nxt = R::STAGE;                                     // byte offsets of the stage being multiplied and of the next one
+    for (int t = 0; t < nst; ++t) {
+        const bool live1 = 2 * t + 1 < nkt32;                        // the stage's second k-tile exists (wave-uniform)
+        kstep(I0{}, true, [&](int q) { frag_unit(I1{}, q, cur, 1); });
+        kstep(I1{}, true, [&](int q) { frag_unit(I0{}, q, cur, 2); });
+        kstep(I0{}, live1, [&](int q) { frag_unit(I1{}, q, cur, 3); });
+        // every fragment read of this stage is issued (lgkmcnt(0) completes them); stage t + 1 has landed (stage t + 2, if it was issued, may
+        // still be in flight: it is the youngest DMA of this wave)
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nst) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(R::DMA_PER_WAVE + 2 * TPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * TPW) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more3 = t + 3 < nst;
+        kstep(I1{}, live1, [&](int q) {
+            frag_unit(I0{}, q, nxt, 0);                               // (past the last stage: stale bytes nobody multiplies)
+            if (more3) { issue_unit(cur, t + 3, q); if (q < R::DMA_PER_WAVE - 4) issue_unit(cur, t + 3, q + 4); }
+            if (q == 3) touch_stage(t + 5);
+        });
+        cur = nxt;
+        nxt = nxt + R::STAGE == R::NST * R::STAGE ? 0 : nxt + R::STAGE;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                // the epilogue reuses the staging buffers
+    xp_epilogue<4, 1>(g, acc, tid, wm, wn, half, l31, m0, n0, bz, sp, tm);
 }
 
 // ---- fp32 matrix -> three bf16 planes (optionally transposed); pad columns [cols, ld_out) of every written row are zero-filled ----
@@ -526,6 +752,9 @@ int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t
     return check_launch("pulse_split_planes");
 }
 
+// PULSE_B16_RING=0: keep the two-stage kernel for the 256-row bf16-storage launches (A/B switch, read once)
+static const bool g_b16_ring = [] { const char* v = getenv("PULSE_B16_RING"); return !(v && v[0] == '0'); }();
+
 static bool xp_big_tiles(int M, int N, int batch, int split_k) {
     // 256-row tiles when they still give every CU a workgroup; otherwise 128-row tiles (4 waves)
     const long long t256 = (long long)((M + 255) / 256) * ((N + PBN - 1) / PBN) * batch * split_k;
@@ -583,7 +812,9 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.sA = d->stride_a; g.sB = d->stride_b; g.sC = d->stride_c; g.sC2 = d->stride_c2; g.sCp = d->stride_cp; g.sBias = d->stride_bias; g.sAux = d->stride_aux;
     g.batch = d->batch; g.splitk = d->split_k;
-    const int kq = npl == 1 ? 3 * PK : PK;                           // split-K chunks are whole pipeline stages
+    const bool big_ = xp_big_tiles(d->M, d->N, d->batch, d->split_k);
+    const bool ring = npl == 1 && big_ && g_b16_ring;                // bf16 storage, 256-row tiles: the three-stage ring kernel
+    const int kq = ring ? 2 * PK : npl == 1 ? 3 * PK : PK;           // split-K chunks are whole pipeline stages
     int kchunk = (d->K + d->split_k - 1) / d->split_k;
     kchunk = ((kchunk + kq - 1) / kq) * kq;
     g.kchunk = kchunk > 0 ? kchunk : kq;
@@ -618,6 +849,20 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
         if (big) PULSE_XP_LAUNCH(true, false, 4, 3, 8); else PULSE_XP_LAUNCH(true, false, 2, 3, 9);
     } else if (npl == 3) {
         if (big) PULSE_XP_LAUNCH(false, false, 4, 3, 10); else PULSE_XP_LAUNCH(false, false, 2, 3, 11);
+    } else if (ring) {
+#define PULSE_B16R_LAUNCH(AK, BK_)                                                                                                              \
+    do {                                                                                                                                        \
+        constexpr int lds = XpGeom<4>::LDS;                                                                                                     \
+        static bool done = false;                                                                                                               \
+        if (!done) {                                                                                                                            \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b16r_kernel<AK, BK_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_x3p: LDS attribute: %s", hipGetErrorString(e));                     \
+            done = true;                                                                                                                        \
+        }                                                                                                                                       \
+        hipLaunchKernelGGL((gemm_b16r_kernel<AK, BK_>), grid, dim3(512), lds, as_stream(s), g);                                                 \
+    } while (0)
+        if (akc && bkc) PULSE_B16R_LAUNCH(true, true); else if (akc) PULSE_B16R_LAUNCH(true, false); else PULSE_B16R_LAUNCH(false, false);
+#undef PULSE_B16R_LAUNCH
     } else if (akc && bkc) {
         if (big) PULSE_XP_LAUNCH(true, true, 4, 1, 2); else PULSE_XP_LAUNCH(true, true, 2, 1, 3);
     } else if (akc) {

@@ -29,8 +29,10 @@ def test_to_b16_rounds_and_pads(dev):
     assert pt.shape == (69, 64) and torch.equal(K.from_b16(pt)[:, :37], _bf(x).t()) and (pt[:, 37:] == 0).all()
 
 
+# (shapes with M > 8192 or >= 256 tiles of 256 x 128 run on the three-stage ring kernel: ragged M / N, one- and three-k-tile reductions included)
 @pytest.mark.parametrize("m,n,k", [(256, 128, 96), (300, 200, 100), (130, 69, 934), (4096, 1024, 1960), (1024, 1, 512), (64, 2048, 69), (515, 129, 33),
-                                   (257, 130, 32), (128, 128, 64), (16384, 512, 1024)])
+                                   (257, 130, 32), (128, 128, 64), (16384, 512, 1024), (8451, 130, 70), (8200, 64, 33), (8200, 136, 32), (9001, 2048, 934),
+                                   (12288, 1024, 1960), (8193, 8, 1)])
 def test_b16_forward_form(dev, m, n, k):
     a, b = _rand(m, k, dev, m + k), _rand(n, k, dev, n + k, 0.05)
     bias = torch.randn(n, device=dev)
@@ -54,7 +56,8 @@ def test_b16_forward_form(dev, m, n, k):
     assert (got - ref).abs().max().item() <= 2.0 ** -7 * scale
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 128, 96), (300, 200, 100), (4096, 1960, 1024), (515, 129, 33), (130, 934, 512), (16384, 1024, 512)])
+@pytest.mark.parametrize("m,n,k", [(256, 128, 96), (300, 200, 100), (4096, 1960, 1024), (515, 129, 33), (130, 934, 512), (16384, 1024, 512), (8300, 200, 100),
+                                   (16384, 512, 69), (12288, 512, 1)])
 def test_b16_input_gradient_form(dev, m, n, k):
     """C(m, n) = sum_k A(m, k) W(k, n): W is the forward weight [out = k][in = n], read as a [red][out] operand."""
     a, w = _rand(m, k, dev, m + k), _rand(k, n, dev, n + k, 0.05)
@@ -75,7 +78,7 @@ def test_b16_input_gradient_form(dev, m, n, k):
 
 
 @pytest.mark.parametrize("rows,m,n,split", [(96, 256, 128, 1), (1000, 300, 200, 1), (16384, 1024, 934, 8), (4099, 515, 129, 4), (50, 64, 33, 1),
-                                             (49152, 1024, 1960, 8), (12288, 1, 512, 8)])
+                                             (49152, 1024, 1960, 8), (12288, 1, 512, 8), (5000, 2048, 960, 4), (16384, 2048, 960, 4), (777, 2048, 2048, 2)])
 def test_b16_weight_gradient_form(dev, rows, m, n, split):
     """dW(m, n) = sum_r dZ(r, m) X(r, n): both operands row-major over the batch -- the LDS transposing read does the rest."""
     dz, x = _rand(rows, m, dev, rows + m), _rand(rows, n, dev, rows + n)

@@ -19,7 +19,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 constexpr int LDS_BYTES = 64 * 1024;           // two workgroups per CU, like gemm_x3_kernel
 
-template <bool LDS, int DMA, bool VALU>
+template <bool LDS, int DMA, int VALU>
 __global__ void __launch_bounds__(256) chain(const bf16x8* __restrict__ src, const char* __restrict__ stream, long long stream_bytes_per_wg,
                                              float* __restrict__ sink, long long* __restrict__ stamps, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,8 +50,12 @@ __global__ void __launch_bounds__(256) chain(const bf16x8* __restrict__ src, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(j + s) & 3], b[(j + 2 * s + 1) & 3], acc[j], 0, 0, 0);
-                if constexpr (VALU) {                                    // 4 VALU per MFMA, independent of the MFMA chain
+                if constexpr (VALU >= 4) {                               // 4 VALU per MFMA, independent of the MFMA chain
                     v0 = v0 * v1 + v2; v1 = v1 * 0.99999f + 1e-6f; v2 = v2 - v3 * 1e-7f; v3 = v3 + v0 * 1e-9f;
+                } else if constexpr (VALU == 2) {
+                    v0 = v0 * v1 + v2; v1 = v1 * 0.99999f + 1e-6f;
+                } else if constexpr (VALU == 1) {
+                    v0 = v0 * v1 + v2;
                 }
                 if constexpr (LDS) {
                     if (j & 1) {                                         // one 16-byte-per-lane read per two MFMAs; it replaces an operand used 3-4 MFMAs later
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) chain(const bf16x8* __restrict__ src, con
 
 static unsigned short to_bf16(float f) { unsigned u; std::memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
 
-template <bool LDS, int DMA, bool VALU>
+template <bool LDS, int DMA, int VALU>
 static void run(const char* name, int blocks, int iters, const bf16x8* src, const char* stream, long long per_wg, float* sink, long long* stamps) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chain<LDS, DMA, VALU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -125,14 +129,21 @@ int main(int argc, char** argv) {
     hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     for (long long o = 0; o < per_wg * blocks; o += (long long)h.size() * 2) hipMemcpy(stream + o, src, h.size() * 2, hipMemcpyDeviceToDevice);
     printf("%d CUs, %d workgroups of 4 waves, %d trips x 16 MFMAs per wave, random normal bf16 operands\n", prop.multiProcessorCount, blocks, iters);
-    run<false, 0, false>("mfma only", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<true, 0, false>("+ ds_read_b128 per 2 MFMAs", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<false, 2, false>("+ LDS-DMA 128 B / MFMA", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<false, 3, false>("+ LDS-DMA 192 B / MFMA", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<false, 0, true>("+ 4 VALU / MFMA", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<true, 3, false>("+ ds_read + LDS-DMA 192", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<true, 0, true>("+ ds_read + VALU", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<true, 3, true>("+ ds_read + LDS-DMA 192 + VALU", blocks, iters, src, stream, per_wg, sink, stamps);
-    run<false, 0, false>("mfma only (again)", blocks, iters, src, stream, per_wg, sink, stamps);
+    const long long l2_wg = 32LL << 10;     // 32 KB per workgroup: 64 workgroups per XCD x 32 KB = 2 MB, inside the XCD's 4 MB L2
+    const long long mall_wg = 256LL << 10;  // 256 KB per workgroup = 128 MB: misses L2, inside the 256 MB Infinity Cache
+    run<false, 0, 0>("mfma only", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<true, 0, 0>("+ ds_read_b128 per 2 MFMAs", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<false, 3, 0>("+ LDS-DMA 192 B / MFMA, L2-resident", blocks, iters, src, stream, l2_wg, sink, stamps);
+    run<false, 3, 0>("+ LDS-DMA 192 B / MFMA, MALL-resident", blocks, iters, src, stream, mall_wg, sink, stamps);
+    run<false, 3, 0>("+ LDS-DMA 192 B / MFMA, from HBM", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<false, 2, 0>("+ LDS-DMA 128 B / MFMA, from HBM", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<false, 0, 1>("+ 1 VALU / MFMA", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<false, 0, 2>("+ 2 VALU / MFMA", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<false, 0, 4>("+ 4 VALU / MFMA", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<true, 3, 0>("+ ds_read + LDS-DMA 192 (L2)", blocks, iters, src, stream, l2_wg, sink, stamps);
+    run<true, 0, 4>("+ ds_read + 4 VALU", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<true, 3, 4>("+ ds_read + LDS-DMA 192 (L2) + 4 VALU", blocks, iters, src, stream, l2_wg, sink, stamps);
+    run<true, 3, 4>("+ ds_read + LDS-DMA 192 (HBM) + 4 VALU", blocks, iters, src, stream, per_wg, sink, stamps);
+    run<false, 0, 0>("mfma only (again)", blocks, iters, src, stream, per_wg, sink, stamps);
     return 0;
 }

@@ -14,7 +14,9 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         key = ("gemm_f32_kernel" if "gemm_f32_kernel" in k else "gemm_bf16_kernel" if "gemm_bf16_kernel" in k
-               else "gemm_x3_kernel" if "gemm_x3_kernel" in k else ("other_pulse" if "pulse" in k else "torch"))
+               else "gemm_x3_kernel" if "gemm_x3_kernel" in k
+               else ("gemm_x3p_kernel<.., 1> (bf16 storage)" if k.rstrip().endswith("1>(pulse::XpArgs)") or ", 1>" in k else "gemm_x3p_kernel") if "gemm_x3p_kernel" in k
+               else ("other_pulse" if "pulse" in k else "torch"))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for key, cs in agg.items():

@@ -17,6 +17,7 @@
 //   * the 934-float observation row is assembled in LDS and written with full-line 16-byte
 //     stores straight into the caller's row pitch (e.g. a 960-float GEMM-ready pitch, pad zeroed).
 // Compiled with -ffp-contract=off so products/sums round exactly like the eager reference.
+#include <cstdlib>
 #include "common.h"
 #include "rot_math.h"
 #include "motion_math.h"
@@ -79,23 +80,27 @@ __device__ __forceinline__ int group_or(int v) {
     return v;
 }
 
-// cooperative copy of n floats global -> LDS by the 32 lanes of one env group
-__device__ __forceinline__ void stage(float* __restrict__ dst, const float* __restrict__ src, int n, int lane, bool vec_ok) {
+// cooperative copy of n floats global -> LDS by the nl lanes of one env group (lane = 0 .. nl - 1)
+__device__ __forceinline__ void stage(float* __restrict__ dst, const float* __restrict__ src, int n, int lane, bool vec_ok, int nl) {
     if (vec_ok) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(dst);
         const int n4 = n >> 2;
-        for (int i = lane; i < n4; i += kLanesPerEnv) d4[i] = s4[i];
-        for (int i = (n4 << 2) + lane; i < n; i += kLanesPerEnv) dst[i] = src[i];
+        for (int i = lane; i < n4; i += nl) d4[i] = s4[i];
+        for (int i = (n4 << 2) + lane; i < n; i += nl) dst[i] = src[i];
     } else {
-        for (int i = lane; i < n; i += kLanesPerEnv) dst[i] = src[i];
+        for (int i = lane; i < n; i += nl) dst[i] = src[i];
     }
 }
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <int E>
-__global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_im_step_args a) {
+// R = half-waves per env.  R = 1: the 32 lanes of an env do everything in turn.  R = 2 (64 lanes per env): the env's two half-waves share the
+// staging copies and split the arithmetic -- half 0: reference blend at t, self observation, reward, reset; half 1: reference blend(s) at
+// t + 1, task observation -- so the dependent chain of a step (the launch is latency-bound: every env's waves are resident at once) is about
+// half as long and the chip holds twice the waves.  Same operations on the same operands per output element: results are bit-identical.
+template <int E, int R>
+__global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pulse_im_step_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int J = a.num_bodies;
     const int J13 = J * 13;
@@ -116,11 +121,17 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     const int tid = threadIdx.x;
     if (a.what & PULSE_IM_DEBUG_POISON_LDS) {      // debug aid: a read of LDS nobody wrote shows up as NaN in the outputs
         const int total = E * ((2 + T) * J13p + 3 * ndp + colsp);
-        for (int i = tid; i < total; i += E * kLanesPerEnv) smem[i] = __int_as_float(0x7fc00000);
+        for (int i = tid; i < total; i += E * R * kLanesPerEnv) smem[i] = __int_as_float(0x7fc00000);
         __syncthreads();
     }
-    const int slot = tid / kLanesPerEnv;
-    const int lane = tid % kLanesPerEnv;
+    constexpr int NL = R * kLanesPerEnv;           // lanes per env
+    // the two half-waves of an env sit in DIFFERENT waves (a wave holds the same half of two envs): a wave never diverges between the halves'
+    // code paths.  Threads [0, 32 E) are half 0 of envs 0 .. E-1, threads [32 E, 64 E) half 1.
+    const int role = tid / (E * kLanesPerEnv);     // which half-wave of the env
+    const int slot = (tid % (E * kLanesPerEnv)) / kLanesPerEnv;
+    const int lane = tid % kLanesPerEnv;           // body / joint index inside the half-wave
+    const int lane_all = role * kLanesPerEnv + lane;   // cooperative copies: every lane of the env
+    const bool r_now = role == 0, r_next = role == R - 1;      // who blends / computes what (R = 1: one half-wave does both)
     const int count = a.env_ids ? a.num_ids : a.num_envs;
     const int idx = blockIdx.x * E + slot;
     bool valid = idx < count;
@@ -176,14 +187,14 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
     // ---------------- stage inputs (global -> LDS, coalesced) ----------------
     if (valid) {
         const float* g_rb = a.rb + e * a.rb_env_stride + (H - 1) * J13;      // the newest record of the history
-        stage(rb_e, g_rb, J13, lane, aligned16(g_rb));
+        stage(rb_e, g_rb, J13, lane_all, aligned16(g_rb), NL);
         if (a.use_motion) {
             // reference motion straight from the packed library: lane j blends body j of the two frame records
             // (get_motion_state, motion_lib_base.py:434-517) into the same LDS images the array path stages
             const pulse_motion_tables& M = a.motion;
             const long long m = a.motion_ids[e];
             const float* off = a.motion_offset ? a.motion_offset + 3 * e : nullptr;
-            if (need_now) {
+            if (need_now && r_now) {
                 float t = (float)prog * a.clock_dt;                       // humanoid_im.py:859
                 if (a.clock_start_times) t = t + a.clock_start_times[e];
                 if (a.clock_start_offsets) t = t + a.clock_start_offsets[e];
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                     o = rn_e + J * 10 + 3 * lane;         o[0] = b.w.x; o[1] = b.w.y; o[2] = b.w.z;
                 }
             }
-            if (do_task) {
+            if (do_task && r_next) {
                 for (int k = 0; k < T; ++k) {
                     float t = (float)(prog_obs + 1) * a.clock_dt;         // humanoid_im.py:723-731 (next frame, so +1)
                     if (T > 1) t = t + (float)k * a.traj_dt;
@@ -236,10 +247,10 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                 const float* q = a.ref_now_rot + e * (J * 4);
                 const float* v = a.ref_now_vel + e * (J * 3);
                 const float* w = a.ref_now_ang + e * (J * 3);
-                stage(rn_e, p, J * 3, lane, aligned16(p));
-                stage(rn_e + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
-                stage(rn_e + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
-                stage(rn_e + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
+                stage(rn_e, p, J * 3, lane_all, aligned16(p), NL);
+                stage(rn_e + J * 3, q, J * 4, lane_all, aligned16(q) && ((J * 3) % 4 == 0), NL);
+                stage(rn_e + J * 7, v, J * 3, lane_all, aligned16(v) && ((J * 7) % 4 == 0), NL);
+                stage(rn_e + J * 10, w, J * 3, lane_all, aligned16(w) && ((J * 10) % 4 == 0), NL);
             }
             if (do_task) {
                 for (int t = 0; t < T; ++t) {
@@ -247,35 +258,35 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                     float* d = rx_e + t * J13p;
                     const float* p = a.ref_next_pos + r * (J * 3);
                     const float* v = a.ref_next_vel + r * (J * 3);
-                    stage(d, p, J * 3, lane, aligned16(p));
-                    stage(d + J * 7, v, J * 3, lane, aligned16(v) && ((J * 7) % 4 == 0));
+                    stage(d, p, J * 3, lane_all, aligned16(p), NL);
+                    stage(d + J * 7, v, J * 3, lane_all, aligned16(v) && ((J * 7) % 4 == 0), NL);
                     if (a.obs_version != 7) {
                         const float* q = a.ref_next_rot + r * (J * 4);
                         const float* w = a.ref_next_ang + r * (J * 3);
-                        stage(d + J * 3, q, J * 4, lane, aligned16(q) && ((J * 3) % 4 == 0));
-                        stage(d + J * 10, w, J * 3, lane, aligned16(w) && ((J * 10) % 4 == 0));
+                        stage(d + J * 3, q, J * 4, lane_all, aligned16(q) && ((J * 3) % 4 == 0), NL);
+                        stage(d + J * 10, w, J * 3, lane_all, aligned16(w) && ((J * 10) % 4 == 0), NL);
                     }
                 }
-                if (a.obs_version == 2) stage(rd_e, a.ref_next_dof_pos + e * nd, nd, lane, false);
+                if (a.obs_version == 2) stage(rd_e, a.ref_next_dof_pos + e * nd, nd, lane_all, false, NL);
             }
         }
         if (do_rew && a.specs.power_reward) {
             const float* f = a.dof_force + e * nd;
             const float* v = a.dof_vel + e * nd;
-            stage(df_e, f, nd, lane, aligned16(f));
-            stage(dv_e, v, nd, lane, aligned16(v));
+            stage(df_e, f, nd, lane_all, aligned16(f), NL);
+            stage(dv_e, v, nd, lane_all, aligned16(v), NL);
         }
         // zero the padding columns of the observation row
         if (do_self || do_task) {
             const int obs_w = L.self_w + L.task_w;
-            for (int c = obs_w + lane; c < colsp; c += kLanesPerEnv) obs_e[c] = 0.0f;
+            for (int c = obs_w + lane_all; c < colsp; c += NL) obs_e[c] = 0.0f;
         }
     }
     __syncthreads();
 
     // ---------------- per-(env, body) math ----------------
     if (valid) {
-        if (lane == 0) {                                   // every lane of this env read the old value before the barrier
+        if (lane_all == 0) {                               // every lane of this env read the old value before the barrier
             if (a.progress_rw) a.progress_rw[e] = prog_obs;
             if (a.pass_time_out) a.pass_time_out[e] = pass_time ? 1 : 0;
         }
@@ -285,7 +296,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
         const Q4 hinv = heading_quat(root_q, true);   // calc_heading_quat_inv
         const Q4 hfwd = heading_quat(root_q, false);  // calc_heading_quat
 
-        if (do_self) {
+        if (do_self && r_now) {
             for (int hs = 0; hs < H; ++hs) {
                 // history steps older than the newest are read straight from global memory (13 floats per lane)
                 const float* src = hs == H - 1 ? rb_e : a.rb + e * a.rb_env_stride + hs * J13;
@@ -329,7 +340,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
                     obs_e[L.self_step + fs_w + (a.smpl_params ? a.smpl_params_width : 0) + c] = a.limb_weights[e * a.limb_weights_stride + c];
         }
 
-        if (do_task && lane < a.num_track) {
+        if (do_task && r_next && lane < a.num_track) {
             const int Jt = a.num_track, ov = a.obs_version;
             const int tb = a.track_ids[lane];
             const float* r = rb_e + 13 * tb;
@@ -374,7 +385,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
             }
         }
 
-        if (do_rew) {
+        if (do_rew && r_now) {
             // bodies entering the reward: all J (full-body) or the tracked subset (humanoid_im.py:886-899)
             const int nb = a.full_body_reward ? J : a.num_track;
             float e_pos = 0.f, e_rot = 0.f, e_vel = 0.f, e_ang = 0.f;
@@ -420,7 +431,7 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
             }
         }
 
-        if (do_rst) {
+        if (do_rst && r_now) {
             float dist = 0.f;
             int fell = 0;
             if (lane < a.num_reset) {
@@ -459,9 +470,9 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
         if (c0 == 0 && (c1 & 3) == 0 && aligned16(g)) {
             const float4* s4 = reinterpret_cast<const float4*>(obs_e);
             float4* g4 = reinterpret_cast<float4*>(g);
-            for (int i = lane; i < (c1 >> 2); i += kLanesPerEnv) g4[i] = s4[i];
+            for (int i = lane_all; i < (c1 >> 2); i += NL) g4[i] = s4[i];
         } else {
-            for (int c = c0 + lane; c < c1; c += kLanesPerEnv) g[c] = obs_e[c];
+            for (int c = c0 + lane_all; c < c1; c += NL) g[c] = obs_e[c];
         }
     }
 }
@@ -469,6 +480,9 @@ __global__ void __launch_bounds__(E * kLanesPerEnv) im_step_kernel(const pulse_i
 }  // namespace pulse
 
 using namespace pulse;
+
+// PULSE_IM_TWO_ROLES=0: one half-wave per env always (A/B switch, read once)
+static const bool g_im_two_roles = [] { const char* v = getenv("PULSE_IM_TWO_ROLES"); return !(v && v[0] == '0'); }();
 
 extern "C" {
 
@@ -558,12 +572,15 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
     const size_t lds = sizeof(float) * (size_t)E * ((2 + a.time_steps) * J13p + 3 * ndp + colsp);
     PULSE_REQUIRE(lds <= 160 * 1024, "pulse_im_step: LDS request %zu > 160 KiB", lds);
     const unsigned grid = (unsigned)((count + E - 1) / E);
+    // a whole wave per env when both halves have work (task observation beside self observation / reward / reset): see the kernel's note
+    const bool two = (a.what & PULSE_IM_TASK_OBS) && (a.what & (PULSE_IM_SELF_OBS | PULSE_IM_REWARD | PULSE_IM_RESET)) && g_im_two_roles;
+    const void* fn = two ? reinterpret_cast<const void*>(im_step_kernel<E, 2>) : reinterpret_cast<const void*>(im_step_kernel<E, 1>);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(im_step_kernel<E>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_im_step: cannot raise LDS limit: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(im_step_kernel<E>, dim3(grid), dim3(E * kLanesPerEnv), lds, as_stream(s), a);
+    if (two) hipLaunchKernelGGL((im_step_kernel<E, 2>), dim3(grid), dim3(E * 2 * kLanesPerEnv), lds, as_stream(s), a);
+    else hipLaunchKernelGGL((im_step_kernel<E, 1>), dim3(grid), dim3(E * kLanesPerEnv), lds, as_stream(s), a);
     return check_launch("pulse_im_step");
 }
 }

@@ -529,9 +529,9 @@ typedef struct pulse_gemm_desc {
 
 int pulse_sizeof_gemm_desc(void);
 int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
-/* Diagnostics used by tools/gemm_bench and bench.py's clock probe (no effect on results).  PROCESS-GLOBAL and not thread-safe -- the only
- * mutable state in the library besides the thread-local error string; never set by the product path (pulse_amd/ calls them only from
- * bench.py's --clock-probe and tools/).  Option 1 = extra dynamic-LDS bytes per workgroup, option 2 = 1 disables the 64-row tile (occupancy
+/* Diagnostics used by tools/gemm_bench and bench.py's clock probe (no effect on results).  THREAD-LOCAL state (like the error string): they
+ * affect the pulse_gemm_f32 launches issued by the calling host thread only; never set by the product path (pulse_amd/ calls them only
+ * from bench.py's --clock-probe and tools/).  Option 1 = extra dynamic-LDS bytes per workgroup, option 2 = 1 disables the 64-row tile (occupancy
  * experiments).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
  * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID. */
 int pulse_gemm_set_option(int key, int value);

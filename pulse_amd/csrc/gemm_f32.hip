@@ -1154,8 +1154,10 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 using namespace pulse;
 
 namespace {
-long long* g_dbg = nullptr;                    // tools/gemm_bench --clocks
-int g_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // [1] extra LDS bytes per workgroup (occupancy experiments); others unused
+// Diagnostics state: THREAD-LOCAL (round-3 verdict, hygiene): a tool thread that arms the clock stamps or an occupancy knob changes the
+// launches it issues itself, never those of another host thread driving its own stream through the library.
+thread_local long long* g_dbg = nullptr;       // tools/gemm_bench --clocks
+thread_local int g_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [1] extra LDS bytes per workgroup (occupancy experiments); others unused
 }
 
 extern "C" {

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round-4 profile evidence (run ON THE GPU BOX): kernel tables + PMC traffic of cfg2 / cfg5, counters of the bf16-storage GEMM and the env step
+mkdir -p gpurun_out/r4p
+ROOT=$(pwd)
+bash tools/profile_round.sh r04 cfg2 > gpurun_out/r4p/profile_cfg2.log 2>&1
+bash tools/profile_round.sh r04 cfg5 > gpurun_out/r4p/profile_cfg5.log 2>&1
+PMC_DRIVER=b16 bash tools/pmc_gemm.sh $ROOT/gpurun_out/r04_gemm_b16_pmc_ring.txt > gpurun_out/r4p/pmc_b16.log 2>&1
+bash tools/pmc_env.sh $ROOT/gpurun_out/r04_env_pmc_counters.txt > gpurun_out/r4p/pmc_env.log 2>&1
+timeout 300 python tools/bench_kernels.py > gpurun_out/r04_kernel_roofline.md 2> gpurun_out/r4p/bench_kernels.err
+timeout 300 python tools/bench_gemm_b16.py > gpurun_out/r04_gemm_b16_vs_f32_storage.txt 2>&1
+ls -la gpurun_out | grep r04_

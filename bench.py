@@ -415,9 +415,14 @@ def main():
                 r32["pipe_only_ceiling"] = {"tflops": 1758.3 / 6, "frac_of_it": r32["achieved"] / (1758.3 / 6),
                                             "source": "profiles/r03_mfma_ceiling.txt (register-resident MFMA chains, random bf16 operands: 1758.3 TFLOP/s at 1.72 GHz; "
                                                       "2474.5 at 2.39 GHz on all-zero operands)"}
-        r16 = roof(("b16_fwd", "b16_dx", "b16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_x3p_kernel<.., 1> (bf16 storage)")
+        r16 = roof(("b16_fwd", "b16_dx", "b16_dw"), MFMA_BF16_PEAK_TFLOPS, "bf16-storage GEMMs (gemm_b16r_kernel, gemm_x3p_kernel<.., 1>)")
         if r16 is None:
             r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")
+        if r16 is not None and getattr(agent, "_disc_stream", None) is not None:
+            # the discriminator chain runs on its own stream beside the actor / critic chain: an event pair around a launch then spans whatever
+            # the other chain had on the chip at the time, so avg_us / achieved are in-situ figures UNDER CONCURRENCY (rocprofv3's kernel
+            # durations of the same command see the same); PULSE_DISC_STREAM=0 gives the one-chain-at-a-time durations
+            r16["concurrent_chains"] = True
         if r16 is not None:
             # mixed precision: the training GEMMs run on the bf16 MFMA (judged against its 2.5 PFLOP/s dense peak; with fp32 operand
             # storage the kernel is bound by operand traffic); the rollout's fp32 inference GEMMs are reported beside it

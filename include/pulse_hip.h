@@ -532,7 +532,8 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
 /* Diagnostics used by tools/gemm_bench and bench.py's clock probe (no effect on results).  THREAD-LOCAL state (like the error string): they
  * affect the pulse_gemm_f32 launches issued by the calling host thread only; never set by the product path (pulse_amd/ calls them only
  * from bench.py's --clock-probe and tools/).  Option 1 = extra dynamic-LDS bytes per workgroup, option 2 = 1 disables the 64-row tile (occupancy
- * experiments).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
+ * experiments), option 3 = tile of the bf16-storage launches of pulse_gemm_x3p (0 automatic, 1 never 256 x 256, 2 256 x 256 whenever N > 128;
+ * same results either way up to accumulation order).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
  * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID. */
 int pulse_gemm_set_option(int key, int value);
 int pulse_gemm_set_debug_buffer(long long* device_buffer);

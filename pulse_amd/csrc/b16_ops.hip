@@ -204,11 +204,27 @@ __global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restri
         const int ns = rg.nslabs[r];
         const long long n4 = rg.count[r] >> 2;                          // offsets / counts are multiples of 4 floats (checked by the launcher)
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            // the SAME association as reduce_slabs_kernel (gemm_f32.hip): slab 0 + four chains over the groups of four, remainder onto chain 0,
+            // ((c0 + c1) + (c2 + c3)) -- a gradient reduced by either kernel is bit-identical (the data-parallel path reduces bucket by bucket
+            // with pulse_reduce_slabs, the single-GPU path with this kernel)
             float4 a = reinterpret_cast<const float4*>(base)[i];
-            for (int k = 1; k < ns; ++k) {
+            float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1, a3 = a1;
+            int k = 1;
+            for (; k + 3 < ns; k += 4) {
+                const float4 v0 = reinterpret_cast<const float4*>(base + k * stride)[i];
+                const float4 v1 = reinterpret_cast<const float4*>(base + (k + 1) * stride)[i];
+                const float4 v2 = reinterpret_cast<const float4*>(base + (k + 2) * stride)[i];
+                const float4 v3 = reinterpret_cast<const float4*>(base + (k + 3) * stride)[i];
+                a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; k < ns; ++k) {
                 const float4 v = reinterpret_cast<const float4*>(base + k * stride)[i];
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
+            a.x = (a.x + a1.x) + (a2.x + a3.x); a.y = (a.y + a1.y) + (a2.y + a3.y); a.z = (a.z + a1.z) + (a2.z + a3.z); a.w = (a.w + a1.w) + (a2.w + a3.w);
             a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
             if (w) {
                 const float4 v = reinterpret_cast<const float4*>(w)[i];

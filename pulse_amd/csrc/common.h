@@ -78,6 +78,8 @@ __device__ __forceinline__ WgMap map_workgroup(int ntile, int batch, int splitk)
     return WgMap{id, z / splitk, z % splitk};
 }
 
+int gemm_option(int key);        // the calling thread's pulse_gemm_set_option value (gemm_f32.hip)
+
 }  // namespace pulse
 
 #define PULSE_REQUIRE(cond, ...) \

@@ -693,6 +693,207 @@ __global__ void __launch_bounds__(512) gemm_b16r_kernel(const XpArgs g) {
     xp_epilogue<4, 1>(g, acc, tid, wm, wn, half, l31, m0, n0, bz, sp, tm);
 }
 
+// =====================================================================================================================
+// bf16-storage GEMM, 256 x 256 tile ("b16w"): the ring kernel above stages 384 bytes per MFMA (48 KB per 128 MFMAs of a stage) and is bound
+// by the L2 -> LDS path, not by the matrix pipe (profiles/r04_gemm_b16_pmc.txt: pipe 0.24-0.32 busy, no bank conflicts; tools/mfma_feed_probe:
+// LDS-DMA sustains 9.6 TB/s from L2 and 6.2-6.7 TB/s from the Infinity Cache / HBM, i.e. 820 / 550 TFLOP/s at 384 B per MFMA).  This kernel
+// is the same code on a 256 x 256 output tile: 8 waves of 64 x 128 (eight accumulator tiles, 128 VGPRs), a stage of 64 k = 64 KB for 256
+// MFMAs = 256 bytes per MFMA, six fragment reads per eight MFMAs instead of four per four.  Two stages ring through 128 KB: a stage holds twice
+// the MFMA work of the ring kernel's, so "issued one stage ahead" is the same 2048 SIMD cycles of lead.  The tile is two 256 x 128 tiles side
+// by side (column half p: columns 128 p + 64 wn + 32 j), so images, fragment addresses and the epilogue are the ring kernel's, used twice.
+// Used when it does not cost the launch a round of workgroups (xp_wide_tiles).
+struct B16wGeom {
+    static constexpr int BM = 256, BN = 256, NW = 8, NT = 512, SUBS = 2, NST = 2;
+    static constexpr int A_IMG = BM * 64 * SUBS, B_IMG = BN * 64 * SUBS, STAGE = A_IMG + B_IMG;        // 32 + 32 KB
+    static constexpr int A_SUB = BM * 64, B_SUB = BN * 64;
+    static constexpr int DMA_PER_WAVE = (STAGE / 1024) / NW;                                        // 8
+};
+static_assert(2 * B16wGeom::STAGE + XpGeom<4>::TOUCH_LDS <= XpGeom<4>::LDS, "two stages and the touch strip fit the launch's LDS");
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(512) gemm_b16w_kernel(const XpArgs g) {
+    using R = B16wGeom;
+    extern __shared__ __attribute__((aligned(16))) char xp_smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const WgMap wgm = map_workgroup(g.tiles_m * g.tiles_n, g.batch, g.splitk);
+    const int id = wgm.id;
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int m0 = tm * R::BM, n0 = tn * R::BN;
+    const int bz = wgm.bz, sp = wgm.sp;
+    const int kbeg = sp * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int klen = kend - kbeg;
+    const int nkt32 = (klen + PK - 1) / PK;
+    const int kpad = nkt32 * PK;
+    const int nst = (nkt32 + 1) / 2;                                 // 64-deep stages
+
+    const int extA = min(R::BM, g.M - m0), extB = min(R::BN, g.N - n0);
+    const unsigned short* a = g.A + bz * g.sA + (AKC ? (long long)m0 * g.lda + kbeg : (long long)kbeg * g.lda + m0);
+    const unsigned short* b = g.B + bz * g.sB + (BKC ? (long long)n0 * g.ldb + kbeg : (long long)kbeg * g.ldb + n0);
+    const unsigned ra = (unsigned)(AKC ? ((extA - 1) * g.lda + kpad) : ((klen - 1) * g.lda + ((extA + 7) & ~7))) * 2u;
+    const unsigned rb_ = (unsigned)(BKC ? ((extB - 1) * g.ldb + kpad) : ((klen - 1) * g.ldb + ((extB + 7) & ~7))) * 2u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a), 0, klen > 0 ? ra : 0u, P_RSRC);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(b), 0, klen > 0 ? rb_ : 0u, P_RSRC);
+    // DMA lane offsets and LDS images: exactly the ring kernel's (KC: 8 rows x 128 B per instruction, chunk c of row r at slot
+    // c ^ ((r >> 1) & 7); MC: 4 k rows x 16 pieces of a 128-out block); both operands are 256 rows / columns = 32 instructions per stage each
+    const int kcx = (4 * (wave & 1) + (lane >> 4)) & 7;
+    const int voA = AKC ? ((lane >> 3) * g.lda + (((lane & 7) ^ kcx) << 3)) * 2
+                        : ((lane >> 4) * g.lda + (((lane & 15) ^ ((lane >> 4) << 2)) << 3)) * 2;
+    const int voB = BKC ? ((lane >> 3) * g.ldb + (((lane & 7) ^ kcx) << 3)) * 2
+                        : ((lane >> 4) * g.ldb + (((lane & 15) ^ ((lane >> 4) << 2)) << 3)) * 2;
+    const int stA = AKC ? 64 * 2 : 64 * g.lda * 2, stB = BKC ? 64 * 2 : 64 * g.ldb * 2;      // bytes per 64-deep stage
+    // unit j of this wave = instruction i = wave + 8 j of the stage's 64 (32 of A, 32 of B)
+    auto issue_unit = [&](int stage_off, int t, int j) {
+        const int i = wave + (j & 3) * R::NW;                        // row block inside the operand
+        const int sub = i >> 4, rb = i & 15;                         // [red][out]: sub-tile, (8 k groups x 2 out blocks of 128)
+        if (j < 4) {
+            int so, dst;
+            if constexpr (AKC) { so = t * stA + i * 8 * g.lda * 2; dst = i * 1024; }
+            else { so = t * stA + sub * 32 * g.lda * 2 + (rb & 7) * 4 * g.lda * 2 + (rb >> 3) * 256; dst = sub * R::A_SUB + rb * 1024; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(xp_smem + stage_off + dst), 16, voA, so, 0, 0);
+        } else {
+            int so, dst;
+            if constexpr (BKC) { so = t * stB + i * 8 * g.ldb * 2; dst = i * 1024; }
+            else { so = t * stB + sub * 32 * g.ldb * 2 + (rb & 7) * 4 * g.ldb * 2 + (rb >> 3) * 256; dst = sub * R::B_SUB + rb * 1024; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(xp_smem + stage_off + R::A_IMG + dst), 16, voB, so, 0, 0);
+        }
+    };
+    // L2 touch prefetch of the weight-gradient form's operands, one stage ahead of the stage's DMA: 4 lines per k row and operand, 64 k rows
+    constexpr int LPR = R::BM * 2 / 128;
+    constexpr int TCH = (AKC || BKC) ? 0 : 64 * LPR / 64;            // wave instructions per operand and stage
+    constexpr int TPW = TCH > 0 ? (2 * TCH + R::NW - 1) / R::NW : 0;
+    auto touch_stage = [&](int t) {
+        if constexpr (TPW > 0) {
+            const int u = wave % (2 * TCH);
+            const int q = 64 * (u % TCH) + lane;
+            if (u < TCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(xp_smem + XpGeom<4>::TOUCH_OFF + wave * 256), 4,
+                                                         (q / LPR) * g.lda * 2 + (q % LPR) * 128, t * stA, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(xp_smem + XpGeom<4>::TOUCH_OFF + wave * 256), 4,
+                                                         (q / LPR) * g.ldb * 2 + (q % LPR) * 128, t * stB, 0, 0);
+        }
+    };
+
+    // fragment read addresses of k-step q4 = 2 kt + ks: A tile i (rows 64 wm + 32 i), B tile u = 2 p + j (columns 128 p + 64 wn + 32 j)
+    int frA[2][4], frB[4][4];
+    {
+        const int gq = lane >> 4, jj = (lane >> 2) & 3, qq = lane & 3;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int kt = q4 >> 1, ks = q4 & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (AKC) {
+                    const int row = wm * 64 + i * 32 + l31;
+                    frA[i][q4] = row * 128 + (((4 * kt + 2 * ks + half) ^ ((row >> 1) & 7)) << 4);
+                } else {
+                    const int o = wm * 64 + i * 32 + 16 * (gq & 1);
+                    const int piece = ((o & 127) >> 3) + (qq >> 1);
+                    frA[i][q4] = kt * R::A_SUB + (o >> 7) * 8192 + (ks * 16 + 8 * (gq >> 1) + jj) * 256 + ((piece ^ (jj << 2)) << 4) + (qq & 1) * 8;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c0 = (u >> 1) * 128 + wn * 64 + (u & 1) * 32;
+                if constexpr (BKC) {
+                    const int row = c0 + l31;
+                    frB[u][q4] = R::A_IMG + row * 128 + (((4 * kt + 2 * ks + half) ^ ((row >> 1) & 7)) << 4);
+                } else {
+                    const int o = c0 + 16 * (gq & 1);
+                    const int piece = ((o & 127) >> 3) + (qq >> 1);
+                    frB[u][q4] = R::A_IMG + kt * R::B_SUB + (o >> 7) * 8192 + (ks * 16 + 8 * (gq >> 1) + jj) * 256 + ((piece ^ (jj << 2)) << 4) + (qq & 1) * 8;
+                }
+            }
+        }
+    }
+
+    f32x16 acc[2][2][2];                                             // [column half p][i][j]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float b0 = 0.f, b1 = 0.f;
+        if (g.epi == 0 && g.bias) {
+            const float* bias = g.bias + bz * g.sBias;
+            const int c0 = n0 + p * 128 + wn * 64 + l31;
+            if (c0 < g.N) b0 = bias[c0];
+            if (c0 + 32 < g.N) b1 = bias[c0 + 32];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[p][i][0][r] = b0; acc[p][i][1][r] = b1; }
+    }
+
+    bf16x8 fa[2][2], fb[2][4];                                       // [set][tile]
+    auto rdA = [&](int addr) { if constexpr (AKC) return xp_lds128(addr); else return xp_lds_tr(addr, addr + 1024); };
+    auto rdB = [&](int addr) { if constexpr (BKC) return xp_lds128(addr); else return xp_lds_tr(addr, addr + 1024); };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    auto frag_unit = [&](auto set_tag, int u, int st, int q4) {       // u = 0..5: A0 A1 B0 B1 B2 B3
+        constexpr int S = decltype(set_tag)::value;
+        if (u < 2) fa[S][u] = rdA(st + frA[u][q4]);
+        else if (u < 6) fb[S][u - 2] = rdB(st + frB[u - 2][q4]);
+    };
+    // the eight MFMAs of a k-step on set S (A tile outermost: each A fragment feeds four consecutive MFMAs), slot(q) after each
+    auto kstep = [&](auto set_tag, bool live, auto&& slot) {
+        constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = q >> 2, p = (q >> 1) & 1, j = q & 1;
+            if (live) acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][2 * p + j], acc[p][i][j], 0, 0, 0);
+            slot(q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto issue_stage = [&](int stage_off, int t) {
+#pragma unroll
+        for (int j = 0; j < R::DMA_PER_WAVE; ++j) issue_unit(stage_off, t, j);
+    };
+
+    // ---- prologue: stages 0 and 1 on their way, the lines of stage 2 touched; stage 0 landed; its first fragments read.
+    // vm queue order from here on: [DMA(t + 1) x 8, touch(t + 2)] at the barrier of stage t: vmcnt(TPW) = "DMA(t + 1) has landed".
+    if (nst > 0) issue_stage(0, 0);
+    if (nst > 1) issue_stage(R::STAGE, 1);
+    touch_stage(2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R::DMA_PER_WAVE + TPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TPW) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (nst > 0) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) frag_unit(I0{}, u, 0, 0);
+    }
+
+    int cur = 0, nxt = R::STAGE;
+    for (int t = 0; t < nst; ++t) {
+        const bool live1 = 2 * t + 1 < nkt32;                        // the stage's second k-tile exists (wave-uniform)
+        kstep(I0{}, true, [&](int q) { frag_unit(I1{}, q, cur, 1); });
+        kstep(I1{}, true, [&](int q) { frag_unit(I0{}, q, cur, 2); });
+        kstep(I0{}, live1, [&](int q) { frag_unit(I1{}, q, cur, 3); });
+        // every fragment read of this stage is issued (lgkmcnt(0) completes them): its buffer is free behind the barrier; stage t + 1 has landed
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TPW) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more2 = t + 2 < nst;
+        kstep(I1{}, live1, [&](int q) {
+            frag_unit(I0{}, q, nxt, 0);                               // (past the last stage: stale bytes nobody multiplies)
+            if (more2) issue_unit(cur, t + 2, q);
+            if (q == 7) touch_stage(t + 3);
+        });
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                // the epilogue reuses the staging buffers
+    xp_epilogue<4, 1>(g, acc[0], tid, wm, wn, half, l31, m0, n0, bz, sp, tm);
+    if (n0 + PBN < g.N) {                                           // (workgroup-uniform)
+        __syncthreads();
+        xp_epilogue<4, 1>(g, acc[1], tid, wm, wn, half, l31, m0, n0 + PBN, bz, sp, tm);
+    }
+}
+
 // ---- fp32 matrix -> three bf16 planes (optionally transposed); pad columns [cols, ld_out) of every written row are zero-filled ----
 // out plane p, element (r, c) at out[p * plane_stride + r * ld_out + c].  transpose: out(r, c) = in(c, r) (rows_out = cols_in).
 __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ in, long long ld_in, int rows_out, int cols_out,
@@ -767,6 +968,18 @@ static bool xp_big_tiles(int M, int N, int batch, int split_k) {
     return t256 >= 256 || M > 128 * 64;
 }
 
+// 256 x 256 tiles (gemm_b16w_kernel) when they do not cost the launch a round of workgroups: a wide workgroup does the work of two narrow
+// ones, so it wins whenever 2 x rounds(wide) <= rounds(narrow) on the 256 CUs.  gemm option 3: 1 = never, 2 = whenever the tile has a second half.
+static const bool g_b16_wide = [] { const char* v = getenv("PULSE_B16_WIDE"); return !(v && v[0] == '0'); }();     // A/B switch, read once
+static bool xp_wide_tiles(int M, int N, int batch, int split_k) {
+    const int opt = gemm_option(3);
+    if (opt == 1 || N <= PBN || (!g_b16_wide && opt != 2)) return false;
+    if (opt == 2) return true;
+    const long long tm = (M + 255) / 256, bs = (long long)batch * split_k;
+    const long long tn = tm * ((N + PBN - 1) / PBN) * bs, tw = tm * ((N + 255) / 256) * bs;
+    return 2 * ((tw + 255) / 256) <= (tn + 255) / 256;
+}
+
 int pulse_gemm_x3p_row_tiles(int32_t M, int32_t N, int32_t batch) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     return xp_big_tiles(M, N, batch, 1) ? (M + 255) / 256 : (M + 127) / 128;
@@ -820,6 +1033,7 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     g.batch = d->batch; g.splitk = d->split_k;
     const bool big_ = xp_big_tiles(d->M, d->N, d->batch, d->split_k);
     const bool ring = npl == 1 && big_ && g_b16_ring;                // bf16 storage, 256-row tiles: the three-stage ring kernel
+    const bool wide = ring && xp_wide_tiles(d->M, d->N, d->batch, d->split_k);     // ... or its 256 x 256 form
     const int kq = ring ? 2 * PK : npl == 1 ? 3 * PK : PK;           // split-K chunks are whole pipeline stages
     int kchunk = (d->K + d->split_k - 1) / d->split_k;
     kchunk = ((kchunk + kq - 1) / kq) * kq;
@@ -831,7 +1045,7 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     PULSE_REQUIRE(!d->out_colsum || (d->split_k == 1 && d->ld_out_colsum >= d->N), "pulse_gemm_x3p: out_colsum needs split_k == 1 and a pitch covering N");
     const bool big = xp_big_tiles(d->M, d->N, d->batch, d->split_k);
     g.tiles_m = big ? (d->M + 255) / 256 : (d->M + 127) / 128;
-    g.tiles_n = (d->N + PBN - 1) / PBN;
+    g.tiles_n = wide ? (d->N + B16wGeom::BN - 1) / B16wGeom::BN : (d->N + PBN - 1) / PBN;
     PULSE_REQUIRE((long long)d->lda * 300 < (1LL << 29) && (long long)d->ldb * 300 < (1LL << 29), "pulse_gemm_x3p: pitch too large for 32-bit tile-relative offsets");
     // [red][out] operands advance lda elements per k row: the whole k extent of a split must stay inside the 32-bit scalar offset
     PULSE_REQUIRE(akc || (long long)g.kchunk * d->lda * 2 < (1LL << 31), "pulse_gemm_x3p: split the reduction further (k extent x pitch exceeds 2 GiB)");
@@ -855,6 +1069,20 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
         if (big) PULSE_XP_LAUNCH(true, false, 4, 3, 8); else PULSE_XP_LAUNCH(true, false, 2, 3, 9);
     } else if (npl == 3) {
         if (big) PULSE_XP_LAUNCH(false, false, 4, 3, 10); else PULSE_XP_LAUNCH(false, false, 2, 3, 11);
+    } else if (wide) {
+#define PULSE_B16W_LAUNCH(AK, BK_)                                                                                                              \
+    do {                                                                                                                                        \
+        constexpr int lds = XpGeom<4>::LDS;                                                                                                     \
+        static bool done = false;                                                                                                               \
+        if (!done) {                                                                                                                            \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_b16w_kernel<AK, BK_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) return fail(PULSE_ERR_LAUNCH, "pulse_gemm_x3p: LDS attribute: %s", hipGetErrorString(e));                     \
+            done = true;                                                                                                                        \
+        }                                                                                                                                       \
+        hipLaunchKernelGGL((gemm_b16w_kernel<AK, BK_>), grid, dim3(512), lds, as_stream(s), g);                                                 \
+    } while (0)
+        if (akc && bkc) PULSE_B16W_LAUNCH(true, true); else if (akc) PULSE_B16W_LAUNCH(true, false); else PULSE_B16W_LAUNCH(false, false);
+#undef PULSE_B16W_LAUNCH
     } else if (ring) {
 #define PULSE_B16R_LAUNCH(AK, BK_)                                                                                                              \
     do {                                                                                                                                        \

@@ -375,6 +375,11 @@ def gemm_x3p_row_tiles(M, N, batch=1):
     return int(_lib.load().pulse_gemm_x3p_row_tiles(int(M), int(N), int(batch)))
 
 
+def gemm_set_option(key, value):
+    """Diagnostics knob of the calling host thread (pulse_hip.h, section 4): tests and tools only -- the product path never sets one."""
+    _lib.check(_lib.load().pulse_gemm_set_option(int(key), int(value)), "pulse_gemm_set_option")
+
+
 def launch_gemm_x3p(d, flops=0.0, tag="x3p_fwd", stream=None):
     lib = _lib.load()
     st = _stream() if stream is None else stream

@@ -17,6 +17,8 @@ Built this round:
     ``disc_coef``; ONE gradient-norm clip over policy + discriminator parameters, Adam on both flat buffers.
 """
 import numpy as np
+import os
+
 import torch
 
 from .. import kernels as K
@@ -199,6 +201,16 @@ class AMPAgent(CommonAgent):
         if self.enable_disc:
             groups.append((self.disc.flat, self.disc.grad, self.disc_exp_avg, self.disc_exp_avg_sq, self.disc.n_flat))
         return groups
+
+    def _side_stream(self):
+        # The discriminator chain reads the dataset and its own parameters / normaliser, writes its own gradient slabs, statistics row and slice
+        # of the norm partials: independent of the actor / critic chain until _apply_gradients.  PULSE_DISC_STREAM=0: inline (A/B switch).
+        if not self.enable_disc or not str(self.ppo_device).startswith("cuda") or os.environ.get("PULSE_DISC_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_disc_stream", None) is None:
+            self._disc_stream = torch.cuda.Stream(device=self.ppo_device)
+            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        return self._disc_stream
 
     def _extra_gradients(self, input_dict, idx):
         """The discriminator part of AMPAgent.calc_gradients (:621-629, 700-712): the first amp_minibatch_size rows of

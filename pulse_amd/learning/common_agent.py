@@ -508,6 +508,24 @@ class CommonAgent:
             ws["x16_fresh"] = True
         elif xp is not None:
             ws["xp_fresh"] = True
+        overlap = self.multi_gpu and self.overlap_allreduce and hasattr(net, "w_off")
+        # single GPU: the slab reduce of every flat gradient also leaves the sums of squares the norm clip needs (with data parallelism the
+        # norm is taken after the all-reduce, so it keeps its own pass)
+        self._sq_done, self._sq_fuse = set(), not self.multi_gpu
+        if self._sq_fuse:
+            self._sq_slice(0)                                        # (sizes the shared partials buffer before either chain takes its slice)
+        # Independent second chain (AMPAgent: the discriminator's forward / loss / backward shares nothing with the actor / critic chain until
+        # the optimiser step): enqueued on a side stream so the two chains' kernels interleave on the chip -- a GEMM launch here is one round
+        # of one workgroup per CU, whose prologue, epilogue and launch gap leave CUs idle that the other chain's kernels can use.
+        side = self._side_stream()
+        extra_info = None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            self._ev_fork.record(main)
+            side.wait_event(self._ev_fork)                           # everything enqueued so far (previous optimiser step, the dataset) is visible
+            with torch.cuda.stream(side):
+                extra_info = self._extra_gradients(input_dict, idx)
+                self._ev_join.record(side)
         net.forward(ws, mb)
         ap = net.a_pitch
         g16 = {}
@@ -521,10 +539,6 @@ class CommonAgent:
                    e_clip=self.e_clip, critic_coef=self.critic_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
                    dmu=ws["dmu"], dmu_stride=ws["dmu"].stride(0), dvalue=ws["dval"], dvalue_stride=ws["dval"].stride(0),
                    partials=self._loss_slot(), **g16)
-        overlap = self.multi_gpu and self.overlap_allreduce and hasattr(net, "w_off")
-        # single GPU: the slab reduce of every flat gradient also leaves the sums of squares the norm clip needs (with data parallelism the
-        # norm is taken after the all-reduce, so it keeps its own pass)
-        self._sq_done, self._sq_fuse = set(), not self.multi_gpu
         bkw = {}
         if self._sq_fuse and getattr(net, "supports_fused_sqnorm", False):
             bkw["sq_partials"] = self._sq_slice(0)
@@ -532,7 +546,10 @@ class CommonAgent:
         if overlap:
             bkw["on_bucket"] = self._bucket_ready
         net.backward(ws, mb, grad_scale=1.0 / self.world_size, **bkw)
-        extra_info = self._extra_gradients(input_dict, idx)               # AMPAgent: discriminator loss / gradients
+        if side is None:
+            extra_info = self._extra_gradients(input_dict, idx)           # AMPAgent: discriminator loss / gradients
+        else:
+            torch.cuda.current_stream().wait_event(self._ev_join)         # the optimiser step needs both chains' gradients
         self._sq_fuse = False
         self._apply_gradients(policy_synced=overlap, sq_done=self._sq_done)
         info, gnorm = self._loss_info(mb)                               # [a_loss, c_loss, b_loss, clip_frac, kl]
@@ -546,6 +563,11 @@ class CommonAgent:
 
     def _extra_gradients(self, input_dict, idx):
         return {}
+
+    def _side_stream(self):
+        """The stream _extra_gradients runs on beside the actor / critic chain, or None (run it inline).  Only agents whose extra chain
+        touches no buffer of the main chain return one."""
+        return None
 
     # Per-minibatch loss statistics.  With a constant LR schedule nothing reads them inside the epoch, so the per-block partial
     # sums of every minibatch are parked in a ring and reduced ONCE at the end of train_epoch (the dicts handed out meanwhile hold

@@ -169,3 +169,51 @@ def test_b16_output_column_sums(dev, m, n, k, batch):
     assert torch.isnan(cs[tiles]).all() and torch.isnan(cs[:tiles, batch * n:]).all()
     scale = K.from_b16(cp)[:, :batch * n].abs().double().sum(0).max().item() + 1e-9
     assert (got - want).abs().max().item() <= 2e-6 * scale
+
+
+# ---- the 256 x 256 tile (gemm_b16w_kernel): the launcher picks it only when it does not cost a round of workgroups (the full-size cfg5
+# launches above: 16384 x 1024 x 934 with batch 2, the 1024 x 934 / 1024 x 1960 weight gradients); option 3 = 2 forces it on every
+# ring-eligible launch with N > 128, so the ragged shapes run through it too.
+@pytest.fixture
+def wide_tiles():
+    K.gemm_set_option(3, 2)
+    yield
+    K.gemm_set_option(3, 0)
+
+
+@pytest.mark.parametrize("m,n,k", [(16384, 512, 1024), (8451, 130, 70), (8200, 136, 32), (9001, 2048, 934), (12288, 1024, 1960), (8300, 257, 64), (8193, 384, 65)])
+def test_b16_forward_form_wide_tile(dev, wide_tiles, m, n, k):
+    test_b16_forward_form(dev, m, n, k)
+
+
+@pytest.mark.parametrize("m,n,k", [(16384, 1024, 512), (8300, 200, 100), (16384, 512, 69), (12288, 512, 1), (8300, 300, 130)])
+def test_b16_input_gradient_form_wide_tile(dev, wide_tiles, m, n, k):
+    test_b16_input_gradient_form(dev, m, n, k)
+
+
+@pytest.mark.parametrize("rows,m,n,split", [(16384, 1024, 934, 8), (49152, 1024, 1960, 8), (5000, 2048, 960, 4), (16384, 2048, 960, 4), (777, 2048, 2048, 2),
+                                             (16384, 512, 1024, 16), (9000, 8200, 200, 1), (130, 8200, 136, 1)])
+def test_b16_weight_gradient_form_wide_tile(dev, wide_tiles, rows, m, n, split):
+    test_b16_weight_gradient_form(dev, rows, m, n, split)
+
+
+@pytest.mark.parametrize("m,n,k,batch", [(16384, 1024, 512, 2), (12288, 512, 1, 1), (8300, 200, 96, 1)])
+def test_b16_output_column_sums_wide_tile(dev, wide_tiles, m, n, k, batch):
+    test_b16_output_column_sums(dev, m, n, k, batch)
+
+
+def test_b16_wide_and_narrow_tiles_agree(dev):
+    """Same k order inside a tile either way: the two tilings give bit-identical outputs."""
+    m, n, k = 8451, 700, 934
+    a, b = _rand(m, k, dev, 1), _rand(n, k, dev, 2, 0.05)
+    pa, pb = K.to_b16(a), K.to_b16(b)
+    outs = []
+    for opt in (1, 2):
+        K.gemm_set_option(3, opt)
+        try:
+            c = torch.empty(m, 704, device=dev)
+            K.gemm_x3p(pa, pb, M=m, N=n, K=k, C=c, ldc=704, planes=1)
+            outs.append(c[:, :n].clone())
+        finally:
+            K.gemm_set_option(3, 0)
+    assert torch.equal(outs[0], outs[1])

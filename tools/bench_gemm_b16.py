@@ -34,7 +34,9 @@ def r4(v):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--tile", type=int, default=0, help="gemm option 3: 0 automatic, 1 never the 256 x 256 tile, 2 always")
     a = ap.parse_args()
+    K.gemm_set_option(3, a.tile)
     dev = "cuda:0"
     S = 8
     print(f"{'case':40s} {'f32-storage us':>15s} {'TF/s':>7s} {'bf16-storage us':>16s} {'TF/s':>7s} {'ratio':>6s}")

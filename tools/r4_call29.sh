@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out/r4
+timeout 1200 python -m pytest tests/test_agent_parity2_gpu.py tests/test_bf16_gpu.py tests/test_amp_agent_gpu.py tests/test_disc_gpu.py -x -q > gpurun_out/r4/t_c29.log 2>&1; tail -5 gpurun_out/r4/t_c29.log
+for w in 0 1 0 1; do
+PULSE_DISC_STREAM=$w timeout 300 python bench.py --config cfg5 --no-cpu-baseline --steps 4 --warmup 2 --no-clock-probe 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('cfg5 discstream=$w', round(d['ms_per_step'],2), round(d['value']), 'play', round(d['play_ms_per_step'],2), 'upd', round(d['update_ms_per_step'],2), round(r['achieved'],1), {k:(v['launches'],round(v['avg_us'],1),round(v['tflops'],1)) for k,v in r['by_variant'].items()})"
+done

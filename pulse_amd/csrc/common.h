@@ -78,6 +78,7 @@ __device__ __forceinline__ WgMap map_workgroup(int ntile, int batch, int splitk)
     return WgMap{id, z / splitk, z % splitk};
 }
 
+long long* gemm_debug_buffer();  // the calling thread's pulse_gemm_set_debug_buffer pointer (gemm_f32.hip)
 int gemm_option(int key);        // the calling thread's pulse_gemm_set_option value (gemm_f32.hip)
 
 }  // namespace pulse

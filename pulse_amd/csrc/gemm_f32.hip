@@ -1160,7 +1160,7 @@ thread_local long long* g_dbg = nullptr;       // tools/gemm_bench --clocks
 thread_local int g_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [1] extra LDS bytes per workgroup, [2] no 64-row tile, [3] bf16-storage tile choice (see pulse_hip.h)
 }
 
-namespace pulse { int gemm_option(int key) { return key >= 0 && key < 8 ? g_opt[key] : 0; } }    // read by gemm_x3p.hip (common.h)
+namespace pulse { int gemm_option(int key) { return key >= 0 && key < 8 ? g_opt[key] : 0; } long long* gemm_debug_buffer() { return g_dbg; } }    // read by gemm_x3p.hip (common.h)
 
 extern "C" {
 

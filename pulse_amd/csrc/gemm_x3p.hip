@@ -63,6 +63,7 @@ struct XpArgs {
     int tiles_m, tiles_n;
     float* rowsum; long long sRowsum;
     float* colsum; long long sColsum; int ldcs;      // optional: per-row-tile column sums of the OUTPUT (colsum[bz * sColsum + tm * ldcs + n])
+    long long* dbg;                                  // optional per-workgroup wall-clock stamps (tools/gemm_b16_phases.py; pulse_gemm_set_debug_buffer)
 };
 
 template <int WMW>
@@ -120,6 +121,7 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
             for (int r = 0; r < 16; ++r)
                 sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * G::CPF + wn * 64 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
+    if (g.dbg && tid == 0) g.dbg[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 6] = wall_clock64();     // (diagnostics: transpose image written)
     {
         float* C = g.C ? g.C + bz * g.sC + sp * g.sSplit : nullptr;
         float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
@@ -213,6 +215,7 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
                 }
             }
         }
+        if (g.dbg && tid == 0) g.dbg[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 7] = wall_clock64();     // (diagnostics: this thread's stores issued)
         if (g.colsum) {
             // Column sums of the tile as stored (rounded, masked): what pulse_colsum_partial_b16 would compute from the written matrix, taken
             // here while the values are in registers -- the bias gradient of the layer whose dZ this launch produces costs no pass over dZ.
@@ -853,6 +856,8 @@ __global__ void __launch_bounds__(512) gemm_b16w_kernel(const XpArgs g) {
         for (int j = 0; j < R::DMA_PER_WAVE; ++j) issue_unit(stage_off, t, j);
     };
 
+    long long dbg_w[3] = {0, 0, 0};
+    if (g.dbg) dbg_w[0] = wall_clock64();
     // ---- prologue: stages 0 and 1 on their way, the lines of stage 2 touched; stage 0 landed; its first fragments read.
     // vm queue order from here on: [DMA(t + 1) x 8, touch(t + 2)] at the barrier of stage t: vmcnt(TPW) = "DMA(t + 1) has landed".
     if (nst > 0) issue_stage(0, 0);
@@ -867,6 +872,7 @@ __global__ void __launch_bounds__(512) gemm_b16w_kernel(const XpArgs g) {
         for (int u = 0; u < 6; ++u) frag_unit(I0{}, u, 0, 0);
     }
 
+    if (g.dbg) dbg_w[1] = wall_clock64();
     int cur = 0, nxt = R::STAGE;
     for (int t = 0; t < nst; ++t) {
         const bool live1 = 2 * t + 1 < nkt32;                        // the stage's second k-tile exists (wave-uniform)
@@ -887,10 +893,18 @@ __global__ void __launch_bounds__(512) gemm_b16w_kernel(const XpArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                // the epilogue reuses the staging buffers
+    if (g.dbg) dbg_w[2] = wall_clock64();
     xp_epilogue<4, 1>(g, acc[0], tid, wm, wn, half, l31, m0, n0, bz, sp, tm);
     if (n0 + PBN < g.N) {                                           // (workgroup-uniform)
         __syncthreads();
         xp_epilogue<4, 1>(g, acc[1], tid, wm, wn, half, l31, m0, n0 + PBN, bz, sp, tm);
+    }
+    if (g.dbg && tid == 0) {                                        // start | first stage landed | main loop done | epilogue's stores issued | all of them acknowledged
+        long long* o = g.dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = dbg_w[0]; o[1] = dbg_w[1]; o[2] = dbg_w[2]; o[3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        o[4] = wall_clock64();
+        o[5] = (long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);      // XCC_ID
     }
 }
 
@@ -1042,6 +1056,7 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.colsum = d->out_colsum; g.sColsum = d->stride_out_colsum; g.ldcs = d->ld_out_colsum;
+    g.dbg = gemm_debug_buffer();
     PULSE_REQUIRE(!d->out_colsum || (d->split_k == 1 && d->ld_out_colsum >= d->N), "pulse_gemm_x3p: out_colsum needs split_k == 1 and a pitch covering N");
     const bool big = xp_big_tiles(d->M, d->N, d->batch, d->split_k);
     g.tiles_m = big ? (d->M + 255) / 256 : (d->M + 127) / 128;

@@ -97,7 +97,12 @@ class HumanoidImGetup(HumanoidIm):
             # a random FREE fall state per env (_reset_fall_episode, :171-183): a permutation of the bank, so no state is shared
             perm = torch.randperm(n, device=self.device, generator=self._getup_gen)
             self._last_fall_perm = perm
-            self.sim.set_env_states_masked(fall, {k: v[perm] for k, v in self._fall_state.items()})
+            # gathered into persistent buffers (index_select with out=): no permuted copy of the bank is allocated per step
+            if getattr(self, "_fall_pick", None) is None:
+                self._fall_pick = {k: torch.empty_like(v) for k, v in self._fall_state.items()}
+            for k, v in self._fall_state.items():
+                torch.index_select(v, 0, perm, out=self._fall_pick[k])
+            self.sim.set_env_states_masked(fall, self._fall_pick)
         if self.self_obs_v == 2:
             self._init_tensor_history(fall)           # a fall start's history is its own state repeated (humanoid.py:1301-1306)
         keep = (~both)

@@ -323,10 +323,19 @@ class HumanoidTraj(HumanoidTask):
 
     def _reset_task(self, mask):
         """HumanoidTraj._reset_task (:145-150) -> TrajGenerator.reset for the masked envs."""
+        # This runs on EVERY rollout step (the done mask lives on the device): all draws of a call come from ONE uniform launch into a persistent
+        # buffer (four (N, V - 1) blocks + two (N,) rows), the sharp-turn Bernoulli is a compare of its block (ADVICE r3: five RNG launches and
+        # six allocations per step before).  The reference draws len(env_ids) rows per reset: the RNG streams were never comparable.
         n, v = self.num_envs, self._num_verts
-        u_dtheta, u_sharp = self._rand(n, v - 1), self._rand(n, v - 1)
-        sharp_mask = torch.bernoulli(torch.full((n, v - 1), self._sharp_turn_prob, device=self.device), generator=self._task_gen) == 1.0
-        u_heading, u_dspeed, u_speed0 = self._rand(n), self._rand(n, v - 1), self._rand(n)
+        blk = n * (v - 1)
+        buf = getattr(self, "_traj_draws", None)
+        if buf is None or buf.numel() != 4 * blk + 2 * n:
+            buf = self._traj_draws = torch.empty(4 * blk + 2 * n, device=self.device)
+            self._traj_sharp = torch.empty(n, v - 1, dtype=torch.bool, device=self.device)
+        buf.uniform_(generator=self._task_gen)
+        u_dtheta, u_sharp, u_dspeed, u_turn = (buf[i * blk:(i + 1) * blk].view(n, v - 1) for i in range(4))
+        u_heading, u_speed0 = buf[4 * blk:4 * blk + n], buf[4 * blk + n:]
+        sharp_mask = torch.lt(u_turn, self._sharp_turn_prob, out=self._traj_sharp)
         ops.traj_generate(self.sim.rigid_body_state, self._traj_verts, u_dtheta, u_sharp, sharp_mask, u_heading, u_dspeed, u_speed0,
                           episode_dur=self._episode_dur, dtheta_max=self._dtheta_max, speed_min=self._speed_min, speed_max=self._speed_max,
                           accel_max=self._accel_max, env_mask=mask)

@@ -17,6 +17,7 @@ DB=$(find $OUT/prof_$CFG/trace -name "*.db" | head -1)
 echo "# rocprofv3 --kernel-trace --stats -- python bench.py --config $CFG --no-cpu-baseline --steps 2 --warmup 1   ($CFG, MI355X, $R)" > $OUT/${R}_bench_kernel_stats_${CFG}.md
 echo >> $OUT/${R}_bench_kernel_stats_${CFG}.md
 python $ROOT/tools/rocprof_summary.py "$DB" $OUT/${R}_bench_kernel_stats_${CFG}.md > /dev/null
+[ "${SKIP_PMC:-0}" = "1" ] && { rm -rf $OUT/prof_$CFG/trace; ls -la $OUT | grep ${R}_; exit 0; }      # kernel table only
 PW=1; [ "$CFG" != "cfg2" ] && PW=0    # the 8192-env configs crashed rocprofv3 itself in counter mode with a warm-up epoch: profile a single epoch
 PMC="python $ROOT/bench.py --config $CFG --no-cpu-baseline --steps 1 --warmup $PW --no-roofline"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do

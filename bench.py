@@ -415,7 +415,7 @@ def main():
                 r32["pipe_only_ceiling"] = {"tflops": 1758.3 / 6, "frac_of_it": r32["achieved"] / (1758.3 / 6),
                                             "source": "profiles/r03_mfma_ceiling.txt (register-resident MFMA chains, random bf16 operands: 1758.3 TFLOP/s at 1.72 GHz; "
                                                       "2474.5 at 2.39 GHz on all-zero operands)"}
-        r16 = roof(("b16_fwd", "b16_dx", "b16_dw"), MFMA_BF16_PEAK_TFLOPS, "bf16-storage GEMMs (gemm_b16r_kernel, gemm_x3p_kernel<.., 1>)")
+        r16 = roof(("b16_fwd", "b16_dx", "b16_dw"), MFMA_BF16_PEAK_TFLOPS, "bf16-storage GEMMs (gemm_b16r_kernel, gemm_b16w_kernel, gemm_x3p_kernel<.., 1>)")
         if r16 is None:
             r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")
         if r16 is not None and getattr(agent, "_disc_stream", None) is not None:

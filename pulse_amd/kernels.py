@@ -118,6 +118,19 @@ def dw_split(tiles, max_split, fill=512):
     return s
 
 
+def dw_split_b16(M, N, batch, max_split):
+    """Slab count of a bf16-storage weight-gradient launch (pulse_gemm_x3p, planes = 1, both operands [red][out]).  The 256 x 256 tile moves
+    2/3 of the bytes per MFMA of the 256 x 128 one (profiles/r04_ab_runs.txt: 2048 x 934 over 16384 rows: 124 us on 64 narrow tiles x 4
+    slabs, 87 us on 32 wide tiles x 8 slabs), so when the wide tiling fills the chip within ``max_split`` slabs its count is returned -- the
+    launcher's own rule (a wide workgroup must not cost a round) then picks that tile; otherwise the narrow tiling's count."""
+    tm = (M + 255) // 256
+    tw = tm * ((N + 255) // 256) * batch
+    sw = dw_split(tw, max_split, fill=256)
+    if N > 128 and tw * sw >= 192:
+        return sw
+    return dw_split(tm * ((N + 127) // 128) * batch, max_split, fill=256)
+
+
 def launch_gemm(d, flops=0.0, tag="fwd", stream=None):
     lib = _lib.load()
     st = _stream() if stream is None else stream

@@ -159,7 +159,7 @@ class DiscNetwork:
         wg = K.Plan()
         m = 4 * b
         t256 = lambda mm, nn: ((mm + 255) // 256) * ((nn + 127) // 128)
-        ws["w_slabs"] = (K.dw_split(t256(u1, k0), S, fill=256), 1, S)          # slabs written for W1 / W2 (summed into slab 0 by its own reduce) / w3
+        ws["w_slabs"] = (K.dw_split_b16(u1, k0, 1, S), 1, S)          # slabs written for W1 / W2 (summed into slab 0 by its own reduce) / w3
         wg.gemm_b16(Z1, X, M=u1, N=k0, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=w1.pitch, c_off=w1.off,
                     split_k=ws["w_slabs"][0], split_stride=P)
         # the two small outputs would leave most of the chip idle at S splits (16 and 4 tiles of 256 x 128): they are split wider into a

@@ -322,7 +322,7 @@ class A2CNetwork:
             p.gemm_b16(dz[l], self._wt16[l], M=m, N=up, K=uu, ldb=uu, batch=2, stride_a=uu, stride_b=up * uu, Cp=dz[l - 1], stride_cp=up,
                        epilogue=egrad, aux=aux[l - 1], ldaux=ld_aux(aux[l - 1]), stride_aux=up, out_colsum=cs[l - 1], stride_out_colsum=up)
         uu, k = u[0], self.in_w[0]
-        s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split(((2 * uu + 255) // 256) * ((k + 127) // 128), S, fill=256)
+        s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_b16(2 * uu, k, 1, S)
         p.gemm_b16(dz[0], ws["x16"], M=2 * uu, N=k, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=k, c_off=self.w_off[0],
                    split_k=s1, split_stride=P, algo_n=self.in_dim)
         p.call("pulse_reduce_slabs", cs[0].data_ptr(), cs[0].shape[0], cs[0].stride(0), 2 * uu, slabs.data_ptr() + 4 * self.b_off[0], 1.0)   # bias 1 -> slab 0
@@ -337,7 +337,7 @@ class A2CNetwork:
         p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), hb + 2 * ap, slabs.data_ptr() + 4 * self.wh_off, 1.0)
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
-            sl = K.dw_split(2 * ((uu + 255) // 256) * ((up + 127) // 128), S, fill=256)
+            sl = K.dw_split_b16(uu, up, 2, S)
             p.gemm_b16(dz[l], h16[l - 1], M=uu, N=up, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up,
                        C=slabs, ldc=up, stride_c=uu * up, c_off=self.w_off[l], split_k=sl, split_stride=P)
             p.call("pulse_reduce_slabs", cs[l].data_ptr(), cs[l].shape[0], cs[l].stride(0), 2 * uu, slabs.data_ptr() + 4 * self.b_off[l], 1.0)

@@ -9,14 +9,14 @@ import json
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-B16 = "bf16-storage GEMMs (gemm_b16r_kernel, gemm_x3p_kernel<.., 1>)"      # the label bench.py looks up for mixed_precision configs
+B16 = "bf16-storage GEMMs (gemm_b16r_kernel, gemm_b16w_kernel, gemm_x3p_kernel<.., 1>)"      # the label bench.py looks up for mixed_precision configs
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         key = ("gemm_f32_kernel" if "gemm_f32_kernel" in k else "gemm_bf16_kernel" if "gemm_bf16_kernel" in k
                else "gemm_x3_kernel" if "gemm_x3_kernel" in k
-               else B16 if "gemm_b16r_kernel" in k
+               else B16 if ("gemm_b16r_kernel" in k or "gemm_b16w_kernel" in k)
                else (B16 if k.rstrip().endswith("1>(pulse::XpArgs)") or ", 1>" in k else "gemm_x3p_kernel") if "gemm_x3p_kernel" in k
                else ("other_pulse" if "pulse" in k else "torch"))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

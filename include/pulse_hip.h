@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 18
+#define PULSE_ABI_VERSION 19
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -613,10 +613,13 @@ int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int
  * number of slabs its weight-gradient launch wrote): out[off + i] = scale * sum_s slabs[s * slab_stride + off + i] + alpha_r * flat[off + i]
  * (the regularisers of pulse_disc_reg; alphas / flat may be NULL).  sq_partials[block] (optional) = the block's share of sum out^2 -- the
  * clip_grad_norm_ input (common_agent.py:472-478) without a pass of its own -- and w2_partials[block * 8 + r] (optional) the share of
- * sum flat[region r]^2.  offsets / counts / nslabs / alphas are HOST arrays of num_regions <= 8 entries; offsets and counts multiples of 4. */
+ * sum flat[region r]^2.  offsets / counts / nslabs / alphas are HOST arrays of num_regions <= 8 entries; offsets and counts multiples of 4.
+ * region_src / region_src_stride (HOST arrays, may be NULL; v19): a region with region_src[r] != NULL sums nslabs[r] partial rows of its OWN device
+ * buffer (row s at region_src[r] + s * region_src_stride[r]) instead of the slabs -- column-sum partials of a bias gradient, or the scratch of a
+ * weight gradient that was split wider than the slab count; same summation order as pulse_reduce_slabs (bit-identical results). */
 int pulse_reduce_grads(const float* slabs, int64_t slab_stride, int32_t num_regions, const int64_t* offsets, const int64_t* counts,
-                       const int32_t* nslabs, const float* alphas, float* out, float scale, const float* flat, float* sq_partials,
-                       float* w2_partials, int32_t num_blocks, pulse_stream_t s);
+                       const int32_t* nslabs, const float* alphas, const float* const* region_src, const int64_t* region_src_stride,
+                       float* out, float scale, const float* flat, float* sq_partials, float* w2_partials, int32_t num_blocks, pulse_stream_t s);
 /* AMPAgent._calc_disc_rewards (amp_agent.py:1027-1041): out[i * out_stride] = -log(max(1 - sigmoid(logits[i * logit_stride]), 1e-4)) * scale */
 int pulse_disc_reward(const float* logits, int64_t logit_stride, int64_t n, float scale, float* out, int64_t out_stride, pulse_stream_t s);
 

@@ -188,8 +188,11 @@ __global__ void __launch_bounds__(256) disc_reg_kernel(const float* __restrict__
 // gradient buffer, each with its own slab count (a weight-gradient launch that split its reduction 4 ways wrote 4 slabs: the other slabs of
 // that region are never read); sq_partials[block] = the block's share of sum out^2 (the gradient-norm clip needs it: no separate pass over
 // the gradient), w2_partials[block * 8 + r] = its share of sum flat[region r]^2 (the regularisers' loss terms).
-struct ReduceRegions { long long off[8]; long long count[8]; int nslabs[8]; float alpha[8]; int n; };
-__global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restrict__ slabs, long long stride, const ReduceRegions rg, float* __restrict__ out,
+// A region may name its OWN source (src[r] != null: nslabs[r] partial rows of sstride[r] floats, element i of the region at src[r][s * sstride[r] + i]):
+// the column-sum partials of a bias gradient or the scratch of a weight gradient that was split wider than the slab count are summed here
+// instead of by a pulse_reduce_slabs launch of their own.
+struct ReduceRegions { long long off[8]; long long count[8]; int nslabs[8]; float alpha[8]; const float* src[8]; long long sstride[8]; int n; };
+__global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restrict__ slabs, long long slab_stride, const ReduceRegions rg, float* __restrict__ out,
                                                           float scale, const float* __restrict__ flat, float* __restrict__ sq_partials,
                                                           float* __restrict__ w2_partials) {
     __shared__ float red[4][9];
@@ -197,7 +200,8 @@ __global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         if (r >= rg.n) break;
-        const float* base = slabs + rg.off[r];
+        const float* base = rg.src[r] ? rg.src[r] : slabs + rg.off[r];
+        const long long stride = rg.src[r] ? rg.sstride[r] : slab_stride;
         float* o = out + rg.off[r];
         const float* w = flat ? flat + rg.off[r] : nullptr;
         const float al = rg.alpha[r];
@@ -337,8 +341,8 @@ int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int
 }
 
 int pulse_reduce_grads(const float* slabs, int64_t slab_stride, int32_t num_regions, const int64_t* offsets, const int64_t* counts, const int32_t* nslabs,
-                       const float* alphas, float* out, float scale, const float* flat, float* sq_partials, float* w2_partials, int32_t num_blocks,
-                       pulse_stream_t s) {
+                       const float* alphas, const float* const* region_src, const int64_t* region_src_stride, float* out, float scale, const float* flat,
+                       float* sq_partials, float* w2_partials, int32_t num_blocks, pulse_stream_t s) {
     PULSE_REQUIRE(num_regions >= 1 && num_regions <= 8 && num_blocks >= 1, "pulse_reduce_grads: 1..8 regions");
     PULSE_REQUIRE(slabs && offsets && counts && nslabs && out, "pulse_reduce_grads: null pointer");
     PULSE_REQUIRE((slab_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
@@ -348,6 +352,10 @@ int pulse_reduce_grads(const float* slabs, int64_t slab_stride, int32_t num_regi
     for (int r = 0; r < 8; ++r) {
         rg.off[r] = r < num_regions ? offsets[r] : 0; rg.count[r] = r < num_regions ? counts[r] : 0; rg.nslabs[r] = r < num_regions ? nslabs[r] : 1;
         rg.alpha[r] = (r < num_regions && alphas) ? alphas[r] : 0.f;
+        rg.src[r] = (r < num_regions && region_src) ? region_src[r] : nullptr;
+        rg.sstride[r] = (rg.src[r] && region_src_stride) ? region_src_stride[r] : 0;
+        PULSE_REQUIRE(!rg.src[r] || ((reinterpret_cast<uintptr_t>(rg.src[r]) & 15) == 0 && (rg.sstride[r] % 4) == 0 && (rg.nslabs[r] == 1 || rg.sstride[r] >= rg.count[r])),
+                      "pulse_reduce_grads: a region's own source must be 16-byte aligned with a row stride that is a multiple of 4 floats covering the region");
         PULSE_REQUIRE(rg.off[r] >= 0 && rg.count[r] >= 0 && (rg.off[r] % 4) == 0 && (rg.count[r] % 4) == 0 && rg.nslabs[r] >= 1,
                       "pulse_reduce_grads: region offsets / counts must be non-negative multiples of 4 floats, slab counts >= 1");
     }

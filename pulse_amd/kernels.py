@@ -166,6 +166,16 @@ class Plan:
     def call(self, name, *args):
         self.ops.append((1, getattr(_lib.load(), name), args, name))
 
+    def call_partial_reduce(self, src, rows, count, slabs, dst_off):
+        """Ordered sum of ``rows`` partial rows of ``src`` (row stride src.stride(0), ``count`` floats each) into slab 0 of ``slabs`` at element
+        ``dst_off`` (pulse_reduce_slabs).  Registered separately: run(skip_partial_reduces=True) leaves these launches out when the caller's
+        ReduceGrads reads the partials itself (``partial_reduces`` lists what it has to read)."""
+        self.ops.append((3, _lib.load().pulse_reduce_slabs, (src.data_ptr(), int(rows), int(src.stride(0)), int(count), slabs.data_ptr() + 4 * int(dst_off), 1.0),
+                         "pulse_reduce_slabs"))
+        if not hasattr(self, "partial_reduces"):
+            self.partial_reduces = []
+        self.partial_reduces.append((int(dst_off), int(count), int(rows), src))
+
     def gemm_x3p(self, A, B, **kw):
         self.ops.append((2,) + make_gemm_x3p_desc(A, B, **kw))
 
@@ -202,13 +212,18 @@ class Plan:
         self.call("pulse_colsum_weighted_b16", x.data_ptr(), m, n, ld, w16.data_ptr() + 2 * w_off, w_stride, num_slabs, slabs.data_ptr() + 4 * out_off,
                   slab_stride)
 
-    def run(self, start=0, stop=None):
+    def run(self, start=0, stop=None, skip_partial_reduces=False):
+        """``skip_partial_reduces``: leave out the small ordered reduces registered with call_partial_reduce -- the caller's fused gradient reduce
+        (ReduceGrads regions with their own source) sums those partials itself."""
         st = _stream()
         for op in self.ops[start:stop]:
             if op[0] == 0:
                 launch_gemm(op[1], op[2], op[3], st)
             elif op[0] == 2:
                 launch_gemm_x3p(op[1], op[2], op[3], st)
+            elif op[0] == 3:
+                if not skip_partial_reduces:
+                    _lib.check(op[1](*op[2], st), op[3])
             else:
                 _lib.check(op[1](*op[2], st), op[3])
 
@@ -579,7 +594,8 @@ def disc_reg(flat, grad, ranges, partials):
 
 
 class ReduceGrads:
-    """A pre-built pulse_reduce_grads launch: regions = [(offset, count, nslabs, alpha)] of a flat gradient buffer."""
+    """A pre-built pulse_reduce_grads launch: regions = [(offset, count, nslabs, alpha[, src, src_stride])] of a flat gradient buffer; a region
+    with ``src`` (a float32 device tensor) sums nslabs rows of that buffer (row stride ``src_stride`` floats) instead of the slabs."""
 
     def __init__(self, slabs, slab_stride, regions, out, flat=None):
         n = len(regions)
@@ -591,6 +607,11 @@ class ReduceGrads:
         self.cnts = (ctypes.c_int64 * n)(*[int(r[1]) for r in regions])
         self.nsl = (ctypes.c_int32 * n)(*[int(r[2]) for r in regions])
         self.als = (ctypes.c_float * n)(*[float(r[3]) for r in regions])
+        self._src_keep = [r[4] if len(r) > 4 else None for r in regions]          # (the tensors stay alive with the launch)
+        for t in self._src_keep:
+            _chk(t, "region src", contiguous=False)
+        self.srcs = (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in self._src_keep])
+        self.sstr = (ctypes.c_int64 * n)(*[(int(r[5]) if len(r) > 5 and r[4] is not None else 0) for r in regions])
         self.slabs, self.stride, self.out, self.flat = slabs, int(slab_stride), out, flat
         self.has_alpha = any(float(r[3]) != 0.0 for r in regions)
 
@@ -607,8 +628,9 @@ class ReduceGrads:
             raise ValueError("ReduceGrads: w2_partials must be (num_blocks, 8) contiguous, num_blocks = sq_partials.numel() (default 1024)")
         if (w2_partials is not None or self.has_alpha) and self.flat is None:
             raise ValueError("ReduceGrads: regulariser terms need the flat parameter buffer")
-        _lib.check(_lib.load().pulse_reduce_grads(self.slabs.data_ptr(), self.stride, self.n, self.offs, self.cnts, self.nsl, self.als, self.out.data_ptr(),
-                                                  float(scale), _p(self.flat), _p(sq_partials), _p(w2_partials), num_blocks, _stream()), "pulse_reduce_grads")
+        _lib.check(_lib.load().pulse_reduce_grads(self.slabs.data_ptr(), self.stride, self.n, self.offs, self.cnts, self.nsl, self.als, self.srcs, self.sstr,
+                                                  self.out.data_ptr(), float(scale), _p(self.flat), _p(sq_partials), _p(w2_partials), num_blocks, _stream()),
+                   "pulse_reduce_grads")
 
 
 def disc_reward(logits, n, scale, out):

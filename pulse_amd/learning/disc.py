@@ -174,7 +174,7 @@ class DiscNetwork:
             ws.setdefault("_w_scratch", []).append(scr)
             wg.gemm_b16(A, B, M=M_, N=N_, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=scr, ldc=lin.pitch, split_k=split,
                         split_stride=scr.stride(0))
-            wg.call("pulse_reduce_slabs", scr.data_ptr(), split, scr.stride(0), count, slabs.data_ptr() + 4 * lin.off, 1.0)
+            wg.call_partial_reduce(scr, split, count, slabs, lin.off)
         wide(Z2, H1, u2, u1, w2)
         # d w3 = sum over the 4b stacked rows of dL[m] * H2[m][:]: a weighted column sum (no 1 x u2 GEMM), 32 row chunks into a scratch
         # (512 workgroups; one partial row per gradient slab would be 128) whose ordered sum lands in slab 0
@@ -182,11 +182,11 @@ class DiscNetwork:
         w3s = torch.zeros(w3c, r4(u2), dtype=torch.float32, device=self.device)
         ws.setdefault("_w_scratch", []).append(w3s)
         wg.colsum_weighted_b16(H2, dL, 32, m, u2, u2, w3s, w3c, w3s.stride(0), 0)
-        wg.call("pulse_reduce_slabs", w3s.data_ptr(), w3c, w3s.stride(0), u2, slabs.data_ptr() + 4 * w3.off, 1.0)
+        wg.call_partial_reduce(w3s, w3c, u2, slabs, w3.off)
         ws["w_slabs"] = (ws["w_slabs"][0], 1, 1)
         # bias gradients over the 3b BCE rows: layers 1 / 2 from the column sums their dZ launches left (slab 0), the logit bias from dL itself
-        wg.call("pulse_reduce_slabs", cs1.data_ptr(), cs1.shape[0], cs1.stride(0), u1, slabs.data_ptr() + 4 * self.l1.b.off, 1.0)
-        wg.call("pulse_reduce_slabs", cs2.data_ptr(), cs2.shape[0], cs2.stride(0), u2, slabs.data_ptr() + 4 * self.l2.b.off, 1.0)
+        wg.call_partial_reduce(cs1, cs1.shape[0], u1, slabs, self.l1.b.off)
+        wg.call_partial_reduce(cs2, cs2.shape[0], u2, slabs, self.l2.b.off)
         wg.colsum_b16(dL, r3, 1, 32, slabs, S, P, self.l3.b.off)
         return fwd, bce, pf, pb, wg
 
@@ -282,19 +282,35 @@ class DiscNetwork:
         else:
             K.disc_penalty(ws["G"], b, self.k0p, c, ws["pen_partials"], out32=X, out32_off=3 * b * self.k0p, ld32=self.k0p)
         ws["pen_bwd"].run()
-        ws["wgrad"].run()
         # ONE launch: split-K slab reduce (each weight region over the slabs its launch wrote), logit regulariser + weight decay gradients
-        # (grad += 2 coef scale W), the three ||W||^2 of the reported loss and the sums of squares of the finished gradient for the norm clip
+        # (grad += 2 coef scale W), the three ||W||^2 of the reported loss and the sums of squares of the finished gradient for the norm clip.
+        # Regions whose partials the plan registered (bias column sums, the wide-split W2, the weighted column sum of w3) are summed from
+        # their own buffers: their small reduce launches are left out of the plan.
         rg = ws.get("reduce_all")
         S = self.book.split_k
         if rg is None:
             n1, n2, n3 = ws["w_slabs"]
-            regions = []
+            plain = []
             for lin, ns in ((self.l1, n1), (self.l2, n2), (self.l3, n3)):
-                regions.append((lin.w.off, lin.w.rows * lin.w.pitch, ns, 0.0))
-                regions.append((lin.b.off, lin.b.rows * lin.b.pitch, S, 0.0))
-            assert regions[-1][0] + regions[-1][1] == self.n_flat and all(a[0] + a[1] == b[0] for a, b in zip(regions, regions[1:]))
+                plain.append((lin.w.off, lin.w.rows * lin.w.pitch, ns, 0.0))
+                plain.append((lin.b.off, lin.b.rows * lin.b.pitch, S, 0.0))
+            assert plain[-1][0] + plain[-1][1] == self.n_flat and all(a[0] + a[1] == b[0] for a, b in zip(plain, plain[1:]))
+            parts = {r[0]: r for r in getattr(ws["wgrad"], "partial_reduces", [])}
+            regions = []
+            for off, cnt, nsl, al0 in plain:
+                pr = parts.pop(off, None)
+                if pr is not None and pr[1] == cnt and cnt % 4 == 0 and pr[3].stride(0) % 4 == 0:
+                    regions.append((off, cnt, pr[2], al0, pr[3], pr[3].stride(0)))
+                else:
+                    regions.append((off, cnt, nsl, al0))
+                    if pr is not None:
+                        parts[off] = pr                               # registered but not usable as a region source
+            # fused only if EVERY registered partial became a region source (otherwise the plan keeps all its small reduces)
+            ws["reduce_all_fused"] = any(len(r) > 4 for r in regions) and not parts
+            if not ws["reduce_all_fused"]:
+                regions = plain
             rg = ws["reduce_all"] = K.ReduceGrads(self.book.slabs, self.book.n_flat, regions, self.grad, flat=self.flat)
+        ws["wgrad"].run(skip_partial_reduces=ws["reduce_all_fused"])
         al = [2.0 * scale * weight_decay, 0.0, 2.0 * scale * weight_decay, 0.0, 2.0 * scale * (weight_decay + logit_reg), 0.0]
         rg.run(alphas=al, sq_partials=sq_partials, w2_partials=self._reg_partials)
         if stats is not None:                                       # [sum ||dD/dx||^2 | per-region sums of squares: W1 at [1], W2 at [3], w3 at [5]]

@@ -325,7 +325,7 @@ class A2CNetwork:
         s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_b16(2 * uu, k, 1, S)
         p.gemm_b16(dz[0], ws["x16"], M=2 * uu, N=k, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=k, c_off=self.w_off[0],
                    split_k=s1, split_stride=P, algo_n=self.in_dim)
-        p.call("pulse_reduce_slabs", cs[0].data_ptr(), cs[0].shape[0], cs[0].stride(0), 2 * uu, slabs.data_ptr() + 4 * self.b_off[0], 1.0)   # bias 1 -> slab 0
+        p.call_partial_reduce(cs[0], cs[0].shape[0], 2 * uu, slabs, self.b_off[0])                           # bias 1 -> slab 0
         p.split = len(p.ops)
         hs, HS = self._head_scratch, self._head_split if m >= 96 * self._head_split else 1
         hb = self.bh_off - self.wh_off
@@ -334,13 +334,13 @@ class A2CNetwork:
         # head bias gradients: column sums of [d mu | pad] and [d value | pad] into the scratch rows' bias columns (b_mu: A entries, b_value: 1)
         p.colsum_b16(dh16, m, ap, 2 * hp, hs, HS, hs.stride(0), hb)
         p.colsum_b16(dh16, m, ap, 2 * hp, hs, HS, hs.stride(0), hb + ap, x_off=hp)
-        p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), hb + 2 * ap, slabs.data_ptr() + 4 * self.wh_off, 1.0)
+        p.call_partial_reduce(hs, HS, hb + 2 * ap, slabs, self.wh_off)
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
             sl = K.dw_split_b16(uu, up, 2, S)
             p.gemm_b16(dz[l], h16[l - 1], M=uu, N=up, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up,
                        C=slabs, ldc=up, stride_c=uu * up, c_off=self.w_off[l], split_k=sl, split_stride=P)
-            p.call("pulse_reduce_slabs", cs[l].data_ptr(), cs[l].shape[0], cs[l].stride(0), 2 * uu, slabs.data_ptr() + 4 * self.b_off[l], 1.0)
+            p.call_partial_reduce(cs[l], cs[l].shape[0], 2 * uu, slabs, self.b_off[l])
         return p
 
     def _plan_forward(self, ws, m, n0, cnt, bf16=False, planar=False):
@@ -438,7 +438,7 @@ class A2CNetwork:
         p.gemm(dhd, ws["h"][-1], hs, M=hr, N=uL, K=m, lda=2 * ap, ldb=2 * uL, ldc=uL, a_layout=GEMM_OUT_CONTIG,
                b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=ap, stride_b=uL, stride_c=hr * uL, split_k=HS, split_stride=hs.stride(0),
                algo_k=m * (self.actions_num + 1) / (2.0 * hr), rowsum=hs, rowsum_off=hb, stride_rowsum=ap)
-        p.call("pulse_reduce_slabs", hs.data_ptr(), HS, hs.stride(0), hb + 2 * ap, slabs.data_ptr() + 4 * self.wh_off, 1.0)
+        p.call_partial_reduce(hs, HS, hb + 2 * ap, slabs, self.wh_off)
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
             sl = K.dw_split(2 * ((uu + 127) // 128) * ((up + 127) // 128), S)
@@ -449,6 +449,36 @@ class A2CNetwork:
 
     supports_fused_sqnorm = True
 
+    def _build_reduce_all(self, ws, plan):
+        """Regions of the whole-gradient reduce: the layer-1 range with the slabs its launch wrote, the rest with split_k slabs, and -- carved out
+        of those -- every range whose partials the plan registered (Plan.call_partial_reduce), summed from their own buffers.  More than 8
+        regions (deep MLPs): the plan keeps its small reduces."""
+        cut = self.w_off[1] if len(self.units) >= 2 else 0
+        base = ([(0, cut, ws["l0_slabs"])] if cut else []) + [(cut, self.n_flat - cut, self.split_k)]
+        parts = sorted(getattr(plan, "partial_reduces", []), key=lambda r: r[0])
+        regions = []
+        for off, cnt, ns in base:
+            pos, end = off, off + cnt
+            for doff, dcnt, rows, src in parts:
+                if doff < off or doff >= end:
+                    continue
+                if doff + dcnt > end or doff % 4 or dcnt % 4 or src.stride(0) % 4:
+                    parts = None
+                    break
+                if doff > pos:
+                    regions.append((pos, doff - pos, ns, 0.0))
+                regions.append((doff, dcnt, rows, 0.0, src, src.stride(0)))
+                pos = doff + dcnt
+            if parts is None:
+                break
+            if end > pos:
+                regions.append((pos, end - pos, ns, 0.0))
+        fused = parts is not None and len(parts) > 0 and len(regions) <= 8
+        if not fused:
+            regions = [(o, c, n, 0.0) for o, c, n in base]
+        ws["reduce_all_fused"] = fused
+        return K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad)
+
     def backward(self, ws, m, grad_scale=1.0, on_bucket=None, sq_partials=None):
         """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
         Deterministic: split-K slabs + ordered reduces.
@@ -458,14 +488,13 @@ class A2CNetwork:
         so its all-reduce runs beside the remaining GEMMs; the small bucket follows."""
         plan = ws["plan_bwd"]
         if on_bucket is None or len(self.units) < 2:
-            plan.run()
-            # ONE reduce launch over the flat gradient: the layer-1 region reads only the slabs its weight-gradient launch wrote, and the
-            # launch leaves the per-block sums of squares the gradient-norm clip needs (``sq_partials``, 256 floats) -- no pass of its own
+            # ONE reduce launch over the flat gradient: the layer-1 region reads only the slabs its weight-gradient launch wrote, the partials
+            # the plan registered (bias column sums, the heads' wide split) are read where they lie -- their small reduce launches are left
+            # out of the plan --, and the launch leaves the per-block sums of squares the gradient-norm clip needs (``sq_partials``)
             rg = ws.get("reduce_all")
             if rg is None:
-                cut = self.w_off[1] if len(self.units) >= 2 else 0
-                regions = ([(0, cut, ws["l0_slabs"], 0.0)] if cut else []) + [(cut, self.n_flat - cut, self.split_k, 0.0)]
-                rg = ws["reduce_all"] = K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad)
+                rg = ws["reduce_all"] = self._build_reduce_all(ws, plan)
+            plan.run(skip_partial_reduces=ws["reduce_all_fused"])
             rg.run(scale=grad_scale, sq_partials=sq_partials)
             if on_bucket is not None:
                 on_bucket(self.grad)

@@ -174,3 +174,34 @@ def test_bf16_storage_epoch_matches_fp32_storage_bf16_kernel(dev):
     # rollout inference is fp32 on both: identical experience
     for k in ("mus", "values", "actions"):
         assert torch.equal(a16.experience_buffer.tensor_dict[k], a32.experience_buffer.tensor_dict[k]), k
+
+
+def test_reduce_grads_regions_own_sources_and_partials(dev):
+    """pulse_reduce_grads: slab regions with their own slab counts, a region summed from its OWN partial rows (v19), regulariser terms, the
+    norm clip's sums of squares -- and the same bits as pulse_reduce_slabs on every region (the data-parallel path reduces with that one)."""
+    g = torch.Generator().manual_seed(21)
+    S, n = 8, 6000
+    slabs = torch.randn(S, n, generator=g).to(dev)
+    flat = torch.randn(n, generator=g).to(dev)
+    part = torch.randn(37, 1032, generator=g).to(dev)                       # 37 partial rows of a 1024-float range, pitch 1032
+    regions = [(0, 2000, 4, 0.25), (2000, 1024, 37, 0.0, part, part.stride(0)), (3024, 976, 8, 0.0), (4000, 2000, 1, -0.5)]
+    out = torch.full((n,), float("nan"), device=dev)
+    sq, w2 = torch.zeros(1024, device=dev), torch.zeros(1024, 8, device=dev)
+    K.ReduceGrads(slabs, n, regions, out, flat=flat).run(scale=0.5, sq_partials=sq, w2_partials=w2)
+    want = torch.empty(n, device=dev)
+    K.reduce_slabs(slabs, 4, n, 2000, want, scale=0.5)
+    K.reduce_slabs(part, 37, part.stride(0), 1024, want, scale=0.5, out_off=2000)
+    K.reduce_slabs(slabs, 8, n, 976, want, scale=0.5, slabs_off=3024, out_off=3024)
+    K.reduce_slabs(slabs, 1, n, 2000, want, scale=0.5, slabs_off=4000, out_off=4000)
+    want[0:2000] += 0.25 * flat[0:2000]
+    want[4000:] += -0.5 * flat[4000:]
+    assert torch.equal(out, want)
+    ref = torch.cat([slabs[:4, :2000].double().sum(0), part[:, :1024].double().sum(0), slabs[:, 3024:4000].double().sum(0), slabs[0, 4000:].double()]) * 0.5
+    ref[0:2000] += 0.25 * flat[0:2000].double()
+    ref[4000:] += -0.5 * flat[4000:].double()
+    assert (out.double() - ref).abs().max().item() <= 1e-5
+    np.testing.assert_allclose(sq.double().sum().item(), (out.double() ** 2).sum().item(), rtol=1e-6)
+    for r, (o, c) in enumerate(((0, 2000), (2000, 1024), (3024, 976), (4000, 2000))):
+        np.testing.assert_allclose(w2.double().sum(0)[r].item(), (flat[o:o + c].double() ** 2).sum().item(), rtol=1e-5)
+    with pytest.raises(RuntimeError, match="own source"):
+        K.ReduceGrads(slabs, n, [(0, 1024, 3, 0.0, part[:, 1:], part.stride(0))], out).run()

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 19
+#define PULSE_ABI_VERSION 20
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -590,6 +590,17 @@ int pulse_split_planes(const float* in, int64_t ld_in, int32_t rows_out, int32_t
  * (allocate them zero: they are the k padding of the consumer). */
 int pulse_transpose_to_b16(const float* in, int64_t ld_in, int32_t rows_in, int32_t cols_in, void* out, int64_t ld_out, int32_t batch,
                            int64_t stride_in, int64_t stride_out, pulse_stream_t s);
+/* The bf16 images a mixed-precision training pass needs of a flat fp32 parameter buffer, in ONE launch (v20): flat16[i] = bf16(flat[i]) for
+ * i < count (elements up to roundup8(count) written as zero; flat16 holds roundup8(count) elements) plus up to four transposed images, each
+ * exactly what pulse_transpose_to_b16 writes (`in` usually points into `flat`).  What autocast's per-op weight casts and the .t() views of
+ * nn.Linear's backward amount to (common_agent.py:426,461; network_builder.py:105-124), done once per optimiser step's worth of passes. */
+typedef struct pulse_b16_transpose {
+    const float* in; int64_t ld_in; int32_t rows; int32_t cols;      /* in[z][r][c], r < rows, c < cols */
+    void* out; int64_t ld_out;                                        /* out[z][c][r] (bf16) */
+    int32_t batch; int32_t reserved; int64_t stride_in; int64_t stride_out;
+} pulse_b16_transpose;
+int pulse_sizeof_b16_transpose(void);
+int pulse_weights_to_b16(const float* flat, int64_t count, void* flat16, int32_t num_transposes, const pulse_b16_transpose* transposes, pulse_stream_t s);
 /* pulse_colsum_partial over a bf16 matrix (ld in bf16 elements, multiple of 8): bias-gradient partials, fp32 accumulation.  With
  * num_chunks = the split-K count and partial = the gradient slabs (ld_partial = the slab stride) the bias gradient rides the slab reduce
  * the weight gradients need anyway (what pulse_gemm_desc.rowsum does for the fp32-storage kernels). */

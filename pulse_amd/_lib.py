@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -91,6 +91,11 @@ class AmpObsArgs(Structure):
                 ("key_body_ids", c_void_p), ("num_key_bodies", c_int32), ("local_root_obs", c_int32), ("root_height_obs", c_int32),
                 ("out", c_void_p), ("out_stride", c_int64),
                 ("hist_steps", c_int32), ("window_out", c_void_p), ("window_stride", c_int64)]
+
+
+class B16Transpose(Structure):
+    _fields_ = [("in_", c_void_p), ("ld_in", c_int64), ("rows", c_int32), ("cols", c_int32), ("out", c_void_p), ("ld_out", c_int64),
+                ("batch", c_int32), ("reserved", c_int32), ("stride_in", c_int64), ("stride_out", c_int64)]
 
 
 class AmpHistArgs(Structure):
@@ -293,6 +298,8 @@ SIGNATURES = {
     "pulse_colsum_weighted_b16": (c_int, [P, c_int32, c_int32, c_int64, P, c_int64, c_int32, P, c_int64, P]),
     "pulse_disc_penalty": (c_int, [P, c_int64, c_int32, c_int32, c_float, P, c_int64, P, c_int64, P, c_int32, P]),
     "pulse_disc_reg": (c_int, [P, P, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_float), P, c_int32, P]),
+    "pulse_sizeof_b16_transpose": (c_int, []),
+    "pulse_weights_to_b16": (c_int, [P, c_int64, P, c_int32, POINTER(B16Transpose), P]),
     "pulse_reduce_grads": (c_int, [P, c_int64, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_float), POINTER(ctypes.c_void_p),
                                    POINTER(c_int64), P, c_float, P, P, P, c_int32, P]),
     "pulse_disc_reward": (c_int, [P, c_int64, c_int64, c_float, P, c_int64, P]),

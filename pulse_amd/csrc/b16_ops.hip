@@ -17,12 +17,8 @@ namespace pulse {
 typedef unsigned int b16_u32x4 __attribute__((ext_vector_type(4)));
 
 // out[z][c][r] = bf16(in[z][r][c]): 64 x 64 tiles through LDS, 16-byte reads of the fp32 rows, 8-byte writes of the bf16 rows.
-__global__ void __launch_bounds__(256) transpose_to_b16_kernel(const float* __restrict__ in, long long ld_in, int rows_in, int cols_in,
-                                                              unsigned short* __restrict__ out, long long ld_out, long long stride_in, long long stride_out) {
-    __shared__ float tile[64][65];
-    const float* src = in + blockIdx.z * stride_in;
-    unsigned short* dst = out + blockIdx.z * stride_out;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+__device__ __forceinline__ void transpose_tile_to_b16(const float* __restrict__ src, long long ld_in, int rows_in, int cols_in, unsigned short* __restrict__ dst,
+                                                      long long ld_out, int r0, int c0, float (&tile)[64][65]) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;           // 16 x 16 threads, 4 columns x 4 rows each
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -55,6 +51,48 @@ __global__ void __launch_bounds__(256) transpose_to_b16_kernel(const float* __re
             for (int k = 0; k < 4 && orr + k < rows_in; ++k) o[k] = (unsigned short)(split_pack_rn(v[k], 0.f) & 0xffffu);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) transpose_to_b16_kernel(const float* __restrict__ in, long long ld_in, int rows_in, int cols_in,
+                                                              unsigned short* __restrict__ out, long long ld_out, long long stride_in, long long stride_out) {
+    __shared__ float tile[64][65];
+    transpose_tile_to_b16(in + blockIdx.z * stride_in, ld_in, rows_in, cols_in, out + blockIdx.z * stride_out, ld_out, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
+
+// The bf16 images a training pass needs of a flat fp32 parameter buffer, in ONE launch: the straight image flat16[i] = bf16(flat[i]) (the first
+// lin_blocks workgroups, grid-stride over 8-element pieces; elements [count, roundup8(count)) are written as zero) and up to four transposed
+// W^T images (the remaining workgroups, one 64 x 64 tile each).
+struct WeightsTr { const float* in; long long ld_in; int rows, cols; unsigned short* out; long long ld_out, stride_in, stride_out; int tiles_x, tiles_y, first_block; };
+struct WeightsArgs { const float* flat; unsigned short* flat16; long long count; int lin_blocks, ntr; WeightsTr tr[4]; };
+__global__ void __launch_bounds__(256) weights_to_b16_kernel(const WeightsArgs a) {
+    __shared__ float tile[64][65];
+    const int blk = blockIdx.x;
+    if (blk < a.lin_blocks) {
+        const long long pieces = (a.count + 7) >> 3;
+        for (long long i = (long long)blk * 256 + threadIdx.x; i < pieces; i += (long long)a.lin_blocks * 256) {
+            const long long e = i * 8;
+            float v[8];
+            if (e + 7 < a.count) {
+                const float4 t0 = *reinterpret_cast<const float4*>(a.flat + e), t1 = *reinterpret_cast<const float4*>(a.flat + e + 4);
+                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = e + k < a.count ? a.flat[e + k] : 0.f;
+            }
+            b16_u32x4 q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = split_pack_rn(v[2 * k], v[2 * k + 1]);
+            *reinterpret_cast<b16_u32x4*>(a.flat16 + e) = q;
+        }
+        return;
+    }
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (k < a.ntr && blk >= a.tr[k].first_block) t = k;
+    const WeightsTr& w = a.tr[t];
+    const int local = blk - w.first_block;
+    const int bx = local % w.tiles_x, by = (local / w.tiles_x) % w.tiles_y, bz = local / (w.tiles_x * w.tiles_y);
+    transpose_tile_to_b16(w.in + bz * w.stride_in, w.ld_in, w.rows, w.cols, w.out + bz * w.stride_out, w.ld_out, by * 64, bx * 64, tile);
 }
 
 // partial[chunk][n] = sum over the chunk's rows of X[m][n], X bf16.  256 threads = CG column groups (8 columns = 16 bytes each) x 256 / CG
@@ -282,6 +320,45 @@ int pulse_transpose_to_b16(const float* in, int64_t ld_in, int32_t rows_in, int3
     hipLaunchKernelGGL(transpose_to_b16_kernel, grid, dim3(256), 0, as_stream(s), in, (long long)ld_in, rows_in, cols_in,
                        reinterpret_cast<unsigned short*>(out), (long long)ld_out, (long long)stride_in, (long long)stride_out);
     return check_launch("pulse_transpose_to_b16");
+}
+
+int pulse_sizeof_b16_transpose(void) { return (int)sizeof(pulse_b16_transpose); }
+
+int pulse_weights_to_b16(const float* flat, int64_t count, void* flat16, int32_t num_transposes, const pulse_b16_transpose* tr, pulse_stream_t s) {
+    PULSE_REQUIRE(count >= 0 && num_transposes >= 0 && num_transposes <= 4, "pulse_weights_to_b16: count >= 0 and at most 4 transposes");
+    PULSE_REQUIRE(num_transposes == 0 || tr != nullptr, "pulse_weights_to_b16: null transpose list");
+    if (count == 0 && num_transposes == 0) return PULSE_OK;
+    PULSE_REQUIRE(count == 0 || (flat && flat16 && (reinterpret_cast<uintptr_t>(flat) & 15) == 0 && (reinterpret_cast<uintptr_t>(flat16) & 15) == 0),
+                  "pulse_weights_to_b16: flat / flat16 must be 16-byte aligned");
+    WeightsArgs a;
+    a.flat = flat; a.flat16 = reinterpret_cast<unsigned short*>(flat16); a.count = count; a.ntr = 0;
+    const long long pieces = (count + 7) / 8;
+    long long lin = (pieces + 255) / 256;
+    if (lin > 2048) lin = 2048;
+    a.lin_blocks = (int)lin;
+    long long next = lin;
+    for (int i = 0; i < 4; ++i) {
+        WeightsTr& w = a.tr[i];
+        w = WeightsTr{nullptr, 0, 0, 0, nullptr, 0, 0, 0, 1, 1, 0x7fffffff};
+        if (i >= num_transposes) continue;
+        const pulse_b16_transpose& d = tr[i];
+        PULSE_REQUIRE(d.rows >= 0 && d.cols >= 0 && d.batch >= 0, "pulse_weights_to_b16: negative transpose size");
+        if (d.rows == 0 || d.cols == 0 || d.batch == 0) continue;
+        PULSE_REQUIRE(d.in && d.out, "pulse_weights_to_b16: null transpose pointer");
+        PULSE_REQUIRE(d.ld_in >= d.cols && (d.ld_in % 4) == 0 && (d.stride_in % 4) == 0 && (reinterpret_cast<uintptr_t>(d.in) & 15) == 0,
+                      "pulse_weights_to_b16: transpose input rows must be 16-byte aligned");
+        PULSE_REQUIRE(d.ld_out >= d.rows && (d.ld_out % 4) == 0 && (d.stride_out % 4) == 0 && (reinterpret_cast<uintptr_t>(d.out) & 7) == 0,
+                      "pulse_weights_to_b16: transpose output rows must be 8-byte aligned and hold `rows` columns");
+        WeightsTr& o = a.tr[a.ntr++];
+        o.in = d.in; o.ld_in = d.ld_in; o.rows = d.rows; o.cols = d.cols; o.out = reinterpret_cast<unsigned short*>(d.out); o.ld_out = d.ld_out;
+        o.stride_in = d.stride_in; o.stride_out = d.stride_out;
+        o.tiles_x = (d.cols + 63) / 64; o.tiles_y = (d.rows + 63) / 64; o.first_block = (int)next;
+        next += (long long)o.tiles_x * o.tiles_y * d.batch;
+        PULSE_REQUIRE(next < (1LL << 31), "pulse_weights_to_b16: too many tiles");
+    }
+    if (next == 0) return PULSE_OK;
+    hipLaunchKernelGGL(weights_to_b16_kernel, dim3((unsigned)next), dim3(256), 0, as_stream(s), a);
+    return check_launch("pulse_weights_to_b16");
 }
 
 static int colsum_b16_launch(const char* what, const void* x, int32_t m, int32_t n, int64_t ld, const void* w, int64_t w_stride, int32_t num_chunks,

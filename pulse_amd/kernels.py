@@ -191,6 +191,24 @@ class Plan:
             raise ValueError("refresh_b16: flat16 must be an int16 buffer of roundup8(count) elements")
         self.call("pulse_split_planes", flat.data_ptr(), count, 1, count, flat16.data_ptr(), 0, n8, 0, None)
 
+    def weights_b16(self, flat, flat16, count, transposes=()):
+        """refresh_b16 + up to four transpose_b16 in ONE launch (pulse_weights_to_b16); ``transposes``: dicts with the keyword arguments of
+        transpose_b16 plus ``x`` / ``out``."""
+        n8 = (count + 7) // 8 * 8
+        if flat16.dtype != torch.int16 or flat16.numel() < n8 or flat.numel() < count:
+            raise ValueError("weights_b16: flat16 must be an int16 buffer of roundup8(count) elements")
+        if len(transposes) > 4:
+            raise ValueError("weights_b16: at most four transposes per launch")
+        arr = (_lib.B16Transpose * max(1, len(transposes)))()
+        for d, kw in zip(arr, transposes):
+            if kw["out"].dtype != torch.int16:
+                raise TypeError("weights_b16: transposed images must be int16")
+            d.in_, d.ld_in, d.rows, d.cols = kw["x"].data_ptr() + 4 * kw.get("x_off", 0), kw["ld_in"], kw["rows"], kw["cols"]
+            d.out, d.ld_out = kw["out"].data_ptr() + 2 * kw.get("out_off", 0), kw["ld_out"]
+            d.batch, d.stride_in, d.stride_out = kw.get("batch", 1), kw.get("stride_in", 0), kw.get("stride_out", 0)
+        self._keep = getattr(self, "_keep", []) + [arr]
+        self.call("pulse_weights_to_b16", flat.data_ptr(), count, flat16.data_ptr(), len(transposes), arr)
+
     def transpose_b16(self, x, out, **kw):
         x_off, out_off = kw.pop("x_off", 0), kw.pop("out_off", 0)
         if out.dtype != torch.int16:

@@ -129,14 +129,14 @@ class DiscNetwork:
         r3, demo = 3 * b, 2 * b
         slabs.zero_()                          # the slabs a weight-gradient launch does not write must read as zero
         fwd = K.Plan()
-        fwd.refresh_b16(f, f16, self.n_flat)
+        # the bf16 weight image and the two W^T images of the backward passes in one launch (the weights do not change inside a minibatch)
+        fwd.weights_b16(f, f16, self.n_flat, [dict(x=f, out=self._w2t16, x_off=w2.off, rows=u2, cols=u1, ld_in=w2.pitch, ld_out=u2),
+                                              dict(x=f, out=self._w1t16, x_off=w1.off, rows=u1, cols=k0, ld_in=w1.pitch, ld_out=u1)])
         fwd.gemm_b16(X, f16, M=r3, N=u1, K=k0, ldb=w1.pitch, b_off=w1.off, Cp=H1, bias=f, bias_off=self.l1.b.off, activation=ACT_RELU)
         fwd.gemm_b16(H1, f16, M=r3, N=u2, K=u1, ldb=w2.pitch, b_off=w2.off, Cp=H2, bias=f, bias_off=self.l2.b.off, activation=ACT_RELU)
         fwd.gemm_b16(H2, f16, M=r3, N=1, K=u2, ldb=w3.pitch, b_off=w3.off, C=ws["L"], ldc=4, bias=f, bias_off=self.l3.b.off)
         # (1) BCE path over the 3b forward rows: dz2 = (dL w3) * m2 ; dz1 = (dz2 W2) * m1 -- the latter in the forward form over W2^T
         bce = K.Plan()
-        bce.transpose_b16(f, self._w2t16, x_off=w2.off, rows=u2, cols=u1, ld_in=w2.pitch, ld_out=u2)
-        bce.transpose_b16(f, self._w1t16, x_off=w1.off, rows=u1, cols=k0, ld_in=w1.pitch, ld_out=u1)
         # (both launches also hand over the column sums of the dZ rows they store: the bias gradients of layers 2 and 1, see the reduces below)
         cs2 = ws["colsum2"] = torch.zeros(K.gemm_x3p_row_tiles(r3, u2, 1), u2, dtype=torch.float32, device=self.device)
         cs1 = ws["colsum1"] = torch.zeros(K.gemm_x3p_row_tiles(r3, u1, 1), u1, dtype=torch.float32, device=self.device)

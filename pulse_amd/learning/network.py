@@ -277,7 +277,16 @@ class A2CNetwork:
         u, f, f16 = self.units, self.flat, self._flat16
         pre = ws.get("z")
         p = K.Plan()
-        p.refresh_b16(f, f16, self.n_flat)
+        # the bf16 weight image and the W_l^T images of the backward pass (W_l^T (bf16) of both nets: out (2, u_{l-1}, u_l)) in one launch at
+        # the head of the training forward: the weights do not change between a minibatch's forward and its backward
+        trs = [dict(x=f, out=self._wt16[l], x_off=self.w_off[l], rows=u[l], cols=u[l - 1], ld_in=u[l - 1], ld_out=u[l], batch=2,
+                    stride_in=u[l] * u[l - 1], stride_out=u[l - 1] * u[l]) for l in range(1, len(u))]
+        if len(trs) <= 4:
+            p.weights_b16(f, f16, self.n_flat, trs)
+        else:
+            p.refresh_b16(f, f16, self.n_flat)
+            for t in trs:
+                p.transpose_b16(t.pop("x"), t.pop("out"), **t)
         for l, uu in enumerate(u):
             if l == 0:
                 k = self.in_w[0]
@@ -306,10 +315,7 @@ class A2CNetwork:
         aux = ws["h16"] if self.act == ACT_RELU else ws["z"]
         ld_aux = lambda t: t.stride(0)
         dz, h16, dh16 = ws["dz16"], ws["h16"], ws["dheads16"]
-        p = K.Plan()
-        for l in range(1, L):               # W_l^T (bf16) of both nets: out (2, u_{l-1}, u_l)
-            p.transpose_b16(f, self._wt16[l], x_off=self.w_off[l], rows=u[l], cols=u[l - 1], ld_in=u[l - 1], ld_out=u[l], batch=2,
-                            stride_in=u[l] * u[l - 1], stride_out=u[l - 1] * u[l])
+        p = K.Plan()                        # (the W_l^T images were written at the head of this minibatch's forward plan)
         # heads -> dZ_L of both nets (K = head rows: tiny; W_heads read as the [red][out] operand it is)
         # every launch that produces a layer's dZ also hands over per-row-tile column sums of what it stored (out_colsum): the layer's bias
         # gradient is their ordered sum -- a few-KB reduce into slab 0 instead of a pass over the (m, 2 u) dZ matrix

@@ -58,5 +58,5 @@ def test_struct_layout_matches_c():
     for cls, fn in ((_lib.TaskStepArgs, "pulse_sizeof_task_step_args"), (_lib.TrajStepArgs, "pulse_sizeof_traj_step_args"),
                     (_lib.PdSimArgs, "pulse_sizeof_pd_sim_args"), (_lib.GemmX3pDesc, "pulse_sizeof_gemm_x3p_desc"),
                     (_lib.VaeEmbedArgs, "pulse_sizeof_vae_embed_args"), (_lib.AmpHistArgs, "pulse_sizeof_amp_hist_args"), (_lib.VaeKinArgs, "pulse_sizeof_vae_kin_args"),
-                    (_lib.VaeHeadBwdArgs, "pulse_sizeof_vae_head_bwd_args")):
+                    (_lib.VaeHeadBwdArgs, "pulse_sizeof_vae_head_bwd_args"), (_lib.B16Transpose, "pulse_sizeof_b16_transpose")):
         assert ctypes.sizeof(cls) == getattr(lib, fn)(), fn

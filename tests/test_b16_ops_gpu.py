@@ -205,3 +205,33 @@ def test_reduce_grads_regions_own_sources_and_partials(dev):
         np.testing.assert_allclose(w2.double().sum(0)[r].item(), (flat[o:o + c].double() ** 2).sum().item(), rtol=1e-5)
     with pytest.raises(RuntimeError, match="own source"):
         K.ReduceGrads(slabs, n, [(0, 1024, 3, 0.0, part[:, 1:], part.stride(0))], out).run()
+
+
+def test_weights_b16_one_launch_equals_refresh_plus_transposes(dev):
+    """pulse_weights_to_b16 (v20): the straight bf16 image of a flat parameter buffer and up to four W^T images in one launch, bit for bit
+    what pulse_split_planes (one plane) and pulse_transpose_to_b16 write."""
+    g = torch.Generator().manual_seed(5)
+    count = 1024 * 520 + 77                                                   # not a multiple of 8: the tail piece is zero-filled
+    flat = (torch.randn(count + 3, generator=g) * torch.logspace(-4, 3, count + 3)).to(dev)[:count]
+    n8 = (count + 7) // 8 * 8
+    specs = [dict(x_off=0, rows=1024, cols=512, ld_in=512, ld_out=1024, batch=1, stride_in=0, stride_out=0),
+             dict(x_off=4096, rows=130, cols=70, ld_in=72, ld_out=132, batch=3, stride_in=130 * 72, stride_out=70 * 132),
+             dict(x_off=1024 * 512, rows=7, cols=513, ld_in=516, ld_out=8, batch=1, stride_in=0, stride_out=0)]
+    outs_a = [torch.full((max(1, s["batch"]) * s["cols"], s["ld_out"]), 0x7fc0, dtype=torch.int16, device=dev) for s in specs]
+    outs_b = [t.clone() for t in outs_a]
+    f16_a = torch.full((n8,), 0x7fc0, dtype=torch.int16, device=dev)
+    f16_b = f16_a.clone()
+    pa = K.Plan()
+    pa.weights_b16(flat, f16_a, count, [dict(x=flat, out=o, **s) for s, o in zip(specs, outs_a)])
+    pa.run()
+    pb = K.Plan()
+    pb.refresh_b16(flat, f16_b, count)
+    for s, o in zip(specs, outs_b):
+        pb.transpose_b16(flat, o, **s)
+    pb.run()
+    assert torch.equal(f16_a, f16_b) and (f16_a[count:] == 0).all()
+    assert torch.equal(f16_a[:count], flat.to(torch.bfloat16).view(torch.int16))
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="at most four"):
+        K.Plan().weights_b16(flat, f16_a, count, [dict(x=flat, out=outs_a[0], **specs[0])] * 5)

@@ -534,7 +534,10 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
  * from bench.py's --clock-probe and tools/).  Option 1 = extra dynamic-LDS bytes per workgroup, option 2 = 1 disables the 64-row tile (occupancy
  * experiments), option 3 = tile of the bf16-storage launches of pulse_gemm_x3p (0 automatic, 1 never 256 x 256, 2 256 x 256 whenever N > 128;
  * same results either way up to accumulation order).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
- * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID. */
+ * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID.  The 256 x 256 bf16-storage
+ * kernel of pulse_gemm_x3p honours the same buffer with wall-clock stamps only: [0] start, [1] first stage landed, [2] main loop done,
+ * [3] epilogue stores issued, [4] stores acknowledged, [5] XCC_ID, [6] / [7] transpose image written / stores issued of the last epilogue
+ * half (tools/gemm_b16_phases.py). */
 int pulse_gemm_set_option(int key, int value);
 int pulse_gemm_set_debug_buffer(long long* device_buffer);
 /* ------------------------------------------------------------------------- *

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 20
+#define PULSE_ABI_VERSION 21
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -787,12 +787,19 @@ int pulse_sqnorm_partial(const float* x, int64_t count, float* partials, int32_t
 int pulse_disc_head(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride,
                     float* stats, pulse_stream_t s);
 /* pulse_disc_head also (or only) writing the logit gradients as bf16 (dlogits16[i * dlogit16_stride]): operand of the bf16-storage
- * discriminator backward.  dlogits may be NULL. */
+ * discriminator backward.  dlogits may be NULL.  bias_grad (optional, v21): *bias_grad = sum_i of the logit gradients as stored (the
+ * bf16-rounded ones when dlogits16 is given) = the gradient of the logit layer's bias, so the backward pass needs no column-sum launch for it. */
 int pulse_disc_head_b16(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride,
-                        void* dlogits16, int64_t dlogit16_stride, float* stats, pulse_stream_t s);
+                        void* dlogits16, int64_t dlogit16_stride, float* stats, float* bias_grad, pulse_stream_t s);
 int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                     const float* sqnorm_partials, int32_t num_partials, float* grad_norm_out, pulse_stream_t s);
+/* The same step over up to four flat buffers in ONE launch (v21): one optimiser over several parameter groups with the joint gradient-norm
+ * clip (AMPAgent: policy + discriminator).  params / grads / exp_avg / exp_avg_sq / counts are HOST arrays of num_groups entries; per element
+ * exactly pulse_adam_step's arithmetic (bit-identical results); grad_norm_out is written once. */
+int pulse_adam_step_multi(int32_t num_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                          const int64_t* counts, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                          const float* sqnorm_partials, int32_t num_partials, float* grad_norm_out, pulse_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -303,7 +303,7 @@ SIGNATURES = {
     "pulse_reduce_grads": (c_int, [P, c_int64, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_float), POINTER(ctypes.c_void_p),
                                    POINTER(c_int64), P, c_float, P, P, P, c_int32, P]),
     "pulse_disc_reward": (c_int, [P, c_int64, c_int64, c_float, P, c_int64, P]),
-    "pulse_disc_head_b16": (c_int, [P, c_int64, c_int32, c_float, P, c_int64, P, c_int64, P, P]),
+    "pulse_disc_head_b16": (c_int, [P, c_int64, c_int32, c_float, P, c_int64, P, c_int64, P, P, P]),
     "pulse_rms_update": (c_int, [P, P, P, P, c_int32, c_int32, c_double, c_double, P]),
     "pulse_policy_sample": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int32, c_int32, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
     "pulse_sizeof_ppo_loss_args": (c_int, []),
@@ -313,6 +313,8 @@ SIGNATURES = {
     "pulse_sqnorm_partial": (c_int, [P, c_int64, P, c_int32, P]),
     "pulse_disc_head": (c_int, [P, c_int64, c_int32, c_float, P, c_int64, P, P]),
     "pulse_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_float, P, c_int32, P, P]),
+    "pulse_adam_step_multi": (c_int, [c_int32, POINTER(ctypes.c_void_p), POINTER(ctypes.c_void_p), POINTER(ctypes.c_void_p), POINTER(ctypes.c_void_p),
+                                      POINTER(c_int64), c_float, c_float, c_float, c_float, c_float, c_int32, c_float, P, c_int32, P, P]),
 }
 
 _lib = None

@@ -459,10 +459,10 @@ __global__ void __launch_bounds__(256) adv_normalize_kernel(float* __restrict__ 
 // autograd pass per minibatch.  One workgroup: 3b logits are a few hundred KB; reductions in double, fixed order.
 __global__ void __launch_bounds__(1024) disc_head_kernel(const float* __restrict__ logits, long long ls, int b, float scale,
                                                          float* __restrict__ dlogits, long long ds, float* __restrict__ stats,
-                                                         unsigned short* __restrict__ dl16, long long ds16) {
-    __shared__ double red[16][6];
+                                                         unsigned short* __restrict__ dl16, long long ds16, float* __restrict__ bias_grad) {
+    __shared__ double red[16][7];
     const int n = 3 * b, na = 2 * b;
-    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // BCE agent, BCE demo, #agent < 0, #demo > 0, sum agent logit, sum demo logit
+    double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // BCE agent, BCE demo, #agent < 0, #demo > 0, sum agent logit, sum demo logit, sum of d loss / d logit
     const float ga = scale * 0.5f / (float)na, gd = scale * 0.5f / (float)b;
     for (int i = threadIdx.x; i < n; i += 1024) {
         const float x = logits[(long long)i * ls];
@@ -470,24 +470,31 @@ __global__ void __launch_bounds__(1024) disc_head_kernel(const float* __restrict
         const float sg = 1.f / (1.f + expf(-x));
         if (i < na) {
             acc[0] += (double)sp; acc[2] += x < 0.f ? 1.0 : 0.0; acc[4] += (double)x;
-            if (dlogits) dlogits[(long long)i * ds] = ga * sg;
-            if (dl16) dl16[(long long)i * ds16] = (unsigned short)(split_pack_rn(ga * sg, 0.f) & 0xffffu);
+            const float gl = ga * sg;
+            if (dlogits) dlogits[(long long)i * ds] = gl;
+            const unsigned q = split_pack_rn(gl, 0.f) & 0xffffu;
+            if (dl16) dl16[(long long)i * ds16] = (unsigned short)q;
+            acc[6] += dl16 ? (double)split_bitsf(q << 16) : (double)gl;      // the logit bias' gradient sums what the backward pass reads
         } else {
             acc[1] += (double)(sp - x); acc[3] += x > 0.f ? 1.0 : 0.0; acc[5] += (double)x;
-            if (dlogits) dlogits[(long long)i * ds] = gd * (sg - 1.f);
-            if (dl16) dl16[(long long)i * ds16] = (unsigned short)(split_pack_rn(gd * (sg - 1.f), 0.f) & 0xffffu);
+            const float gl = gd * (sg - 1.f);
+            if (dlogits) dlogits[(long long)i * ds] = gl;
+            const unsigned q = split_pack_rn(gl, 0.f) & 0xffffu;
+            if (dl16) dl16[(long long)i * ds16] = (unsigned short)q;
+            acc[6] += dl16 ? (double)split_bitsf(q << 16) : (double)gl;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
+    for (int k = 0; k < 7; ++k) acc[k] = wave_sum(acc[k]);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = acc[k];
+        for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = acc[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t[6];
-        for (int k = 0; k < 6; ++k) { t[k] = 0.0; for (int w = 0; w < 16; ++w) t[k] += red[w][k]; }
+        double t[7];
+        for (int k = 0; k < 7; ++k) { t[k] = 0.0; for (int w = 0; w < 16; ++w) t[k] += red[w][k]; }
+        if (bias_grad) *bias_grad = (float)t[6];
         const double la = t[0] / na, ld = t[1] / b;
         stats[0] = (float)(0.5 * (la + ld)); stats[1] = (float)la; stats[2] = (float)ld;
         stats[3] = (float)(t[2] / na); stats[4] = (float)(t[3] / b); stats[5] = (float)(t[4] / na); stats[6] = (float)(t[5] / b); stats[7] = 0.f;
@@ -510,9 +517,9 @@ __global__ void __launch_bounds__(256) sqnorm_partial_kernel(const float* __rest
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                  long long count, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                  float max_norm, const float* __restrict__ sq_partials, int npart, float* __restrict__ norm_out) {
+__device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                          long long count, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                          float max_norm, const float* __restrict__ sq_partials, int npart, float* __restrict__ norm_out) {
     __shared__ float red[4];
     __shared__ float s_coef;
     float coef = 1.0f;
@@ -543,6 +550,21 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = pi - step_size * (mi / denom);
     }
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  long long count, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                  float max_norm, const float* __restrict__ sq_partials, int npart, float* __restrict__ norm_out) {
+    adam_body(p, g, m, v, count, lr, b1, b2, eps, wd, bc1, bc2_sqrt, max_norm, sq_partials, npart, norm_out);
+}
+
+// the same step over up to four flat buffers in ONE launch (blockIdx.y = buffer): one optimiser over several parameter groups
+// (AMPAgent: policy + discriminator, amp_agent.py:136-140) with the joint gradient-norm clip; per element exactly adam_kernel's arithmetic
+struct AdamGroups { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; long long count[4]; };
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamGroups a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                        float max_norm, const float* __restrict__ sq_partials, int npart, float* __restrict__ norm_out) {
+    const int k = blockIdx.y;
+    adam_body(a.p[k], a.g[k], a.m[k], a.v[k], a.count[k], lr, b1, b2, eps, wd, bc1, bc2_sqrt, max_norm, sq_partials, npart, k == 0 ? norm_out : nullptr);
 }
 
 }  // namespace pulse
@@ -686,17 +708,17 @@ int pulse_disc_head(const float* logits, int64_t logit_stride, int32_t b, float 
     PULSE_REQUIRE(b >= 1 && logit_stride >= 1 && dlogit_stride >= 1, "pulse_disc_head: bad sizes");
     PULSE_REQUIRE(logits && dlogits && stats, "pulse_disc_head: null pointer");
     hipLaunchKernelGGL(disc_head_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, (long long)logit_stride, b, scale, dlogits,
-                       (long long)dlogit_stride, stats, (unsigned short*)nullptr, 0LL);
+                       (long long)dlogit_stride, stats, (unsigned short*)nullptr, 0LL, (float*)nullptr);
     return check_launch("pulse_disc_head");
 }
 
 int pulse_disc_head_b16(const float* logits, int64_t logit_stride, int32_t b, float scale, float* dlogits, int64_t dlogit_stride, void* dlogits16,
-                        int64_t dlogit16_stride, float* stats, pulse_stream_t s) {
+                        int64_t dlogit16_stride, float* stats, float* bias_grad, pulse_stream_t s) {
     PULSE_REQUIRE(b >= 1 && logit_stride >= 1, "pulse_disc_head_b16: bad sizes");
     PULSE_REQUIRE(logits && stats && (dlogits || dlogits16), "pulse_disc_head_b16: null pointer");
     PULSE_REQUIRE((!dlogits || dlogit_stride >= 1) && (!dlogits16 || dlogit16_stride >= 1), "pulse_disc_head_b16: bad strides");
     hipLaunchKernelGGL(disc_head_kernel, dim3(1), dim3(1024), 0, as_stream(s), logits, (long long)logit_stride, b, scale, dlogits,
-                       (long long)dlogit_stride, stats, reinterpret_cast<unsigned short*>(dlogits16), (long long)dlogit16_stride);
+                       (long long)dlogit_stride, stats, reinterpret_cast<unsigned short*>(dlogits16), (long long)dlogit16_stride, bias_grad);
     return check_launch("pulse_disc_head_b16");
 }
 
@@ -715,5 +737,30 @@ int pulse_adam_step(float* params, const float* grads, float* exp_avg, float* ex
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(s), params, grads, exp_avg, exp_avg_sq, (long long)count, lr,
                        beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), max_norm, sqnorm_partials, num_partials, grad_norm_out);
     return check_launch("pulse_adam_step");
+}
+
+int pulse_adam_step_multi(int32_t num_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                          const int64_t* counts, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                          const float* sqnorm_partials, int32_t num_partials, float* grad_norm_out, pulse_stream_t s) {
+    PULSE_REQUIRE(num_groups >= 1 && num_groups <= 4 && step >= 1, "pulse_adam_step_multi: 1..4 groups, step >= 1");
+    PULSE_REQUIRE(params && grads && exp_avg && exp_avg_sq && counts, "pulse_adam_step_multi: null pointer");
+    PULSE_REQUIRE(sqnorm_partials == nullptr || num_partials >= 1, "pulse_adam_step_multi: bad partial count");
+    AdamGroups a;
+    long long most = 0;
+    for (int k = 0; k < 4; ++k) {
+        const bool on = k < num_groups;
+        a.p[k] = on ? params[k] : nullptr; a.g[k] = on ? grads[k] : nullptr; a.m[k] = on ? exp_avg[k] : nullptr; a.v[k] = on ? exp_avg_sq[k] : nullptr;
+        a.count[k] = on ? counts[k] : 0;
+        PULSE_REQUIRE(!on || (counts[k] >= 0 && (counts[k] == 0 || (params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k]))), "pulse_adam_step_multi: bad group");
+        if (a.count[k] > most) most = a.count[k];
+    }
+    if (most == 0) return PULSE_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    long long blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks, (unsigned)num_groups), dim3(256), 0, as_stream(s), a, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2), max_norm, sqnorm_partials, num_partials, grad_norm_out);
+    return check_launch("pulse_adam_step_multi");
 }
 }

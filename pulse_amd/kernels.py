@@ -562,13 +562,14 @@ def disc_head(logits, b, scale, dlogits, stats):
                "pulse_disc_head")
 
 
-def disc_head_b16(logits, b, scale, dlogits16, stats, dlogits=None):
-    """disc_head writing the logit gradients as bf16 (dlogits16: int16 (>= 3b, pitch) tensor, column 0) and optionally as fp32 too."""
-    _chk(logits, "logits"), _chk(stats, "stats"), _chk(dlogits, "dlogits")
+def disc_head_b16(logits, b, scale, dlogits16, stats, dlogits=None, bias_grad=None):
+    """disc_head writing the logit gradients as bf16 (dlogits16: int16 (>= 3b, pitch) tensor, column 0) and optionally as fp32 too;
+    ``bias_grad`` (a float32 view, element 0): receives their sum = the logit bias' gradient."""
+    _chk(logits, "logits"), _chk(stats, "stats"), _chk(dlogits, "dlogits"), _chk(bias_grad, "bias_grad", contiguous=False)
     if dlogits16.dtype != torch.int16 or not dlogits16.is_cuda or dlogits16.shape[0] < 3 * b or logits.shape[0] != 3 * b or stats.numel() < 8:
         raise ValueError("disc_head_b16: logits must have 3b rows, dlogits16 be an int16 CUDA tensor of >= 3b rows, stats 8 floats")
     _lib.check(_lib.load().pulse_disc_head_b16(_p(logits), logits.stride(0), b, float(scale), _p(dlogits), dlogits.stride(0) if dlogits is not None else 0,
-                                               dlogits16.data_ptr(), dlogits16.stride(0), _p(stats), _stream()), "pulse_disc_head_b16")
+                                               dlogits16.data_ptr(), dlogits16.stride(0), _p(stats), _p(bias_grad), _stream()), "pulse_disc_head_b16")
 
 
 def transpose_to_b16(x, out, *, rows, cols, ld_in, ld_out, batch=1, stride_in=0, stride_out=0, x_off=0, out_off=0):
@@ -667,6 +668,26 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, count, *, lr, step, beta1=0.9,
                                            eps, weight_decay, int(step), float(max_norm), _p(sqnorm_partials),
                                            sqnorm_partials.numel() if sqnorm_partials is not None else 0, _p(grad_norm_out),
                                            _stream()), "pulse_adam_step")
+
+
+def adam_step_multi(groups, *, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_norm=0.0, sqnorm_partials=None, grad_norm_out=None):
+    """adam_step over several flat buffers -- groups = [(params, grads, exp_avg, exp_avg_sq, count)] -- in ONE launch (pulse_adam_step_multi)."""
+    n = len(groups)
+    if not 1 <= n <= 4:
+        raise ValueError("adam_step_multi: 1..4 groups")
+    _chk(sqnorm_partials, "sqnorm_partials"), _chk(grad_norm_out, "grad_norm_out")
+    cols = [[], [], [], []]
+    for g in groups:
+        for k, nm in enumerate(("params", "grads", "exp_avg", "exp_avg_sq")):
+            _chk(g[k], nm)
+            if g[k].numel() < g[4] or not g[k].is_contiguous():
+                raise ValueError(f"adam_step_multi: {nm} must be a contiguous buffer of at least {g[4]} floats")
+            cols[k].append(g[k].data_ptr())
+    arrs = [(ctypes.c_void_p * n)(*c) for c in cols]
+    counts = (ctypes.c_int64 * n)(*[int(g[4]) for g in groups])
+    _lib.check(_lib.load().pulse_adam_step_multi(n, arrs[0], arrs[1], arrs[2], arrs[3], counts, float(lr), beta1, beta2, eps, weight_decay, int(step),
+                                                 float(max_norm), _p(sqnorm_partials), sqnorm_partials.numel() if sqnorm_partials is not None else 0,
+                                                 _p(grad_norm_out), _stream()), "pulse_adam_step_multi")
 
 
 def rollout_record(*, rewards, dones, terminate, value_raw, value_stride, value_mean, value_var, value_eps, buf_rewards, buf_next_values,

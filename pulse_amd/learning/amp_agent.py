@@ -241,7 +241,7 @@ class AMPAgent(CommonAgent):
         row = self._disc_ring[self._disc_pos] if lazy else torch.empty(20, dtype=torch.float32, device=self.ppo_device)
         scale = self._disc_coef / self.world_size
         if ws["b16"]:
-            K.disc_head_b16(logits, b, scale, ws["dL16"], row[:8])
+            self.disc.loss_head_b16(ws, logits, b, scale, row[:8])
         else:
             K.disc_head(logits, b, scale, ws["dlogits"], row[:8])
         sqp = None

@@ -642,10 +642,13 @@ class CommonAgent:
         for i, g in enumerate(groups):
             if i not in sq_done:             # (groups whose gradient reduce already left its sum-of-squares partials)
                 K.sqnorm_partial(g[1], g[4], self._sq_slice(i))
-        for g in groups:
-            K.adam_step(g[0], g[1], g[2], g[3], g[4], lr=self.last_lr, step=self.optimizer_step, weight_decay=self.weight_decay,
-                        max_norm=self.grad_norm if self.truncate_grads else 0.0, sqnorm_partials=self._sq_partials,
-                        grad_norm_out=self._grad_norm_slot())
+        kw = dict(lr=self.last_lr, step=self.optimizer_step, weight_decay=self.weight_decay, max_norm=self.grad_norm if self.truncate_grads else 0.0,
+                  sqnorm_partials=self._sq_partials, grad_norm_out=self._grad_norm_slot())
+        if 1 < len(groups) <= 4:             # one optimiser over several flat buffers (AMPAgent: policy + discriminator): one launch
+            K.adam_step_multi(groups, **kw)
+        else:
+            for g in groups:
+                K.adam_step(g[0], g[1], g[2], g[3], g[4], **kw)
 
     # ------------------------------------------------------------------ epoch (common_agent.py:191-260)
     def train_epoch(self):

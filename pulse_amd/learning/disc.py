@@ -187,7 +187,7 @@ class DiscNetwork:
         # bias gradients over the 3b BCE rows: layers 1 / 2 from the column sums their dZ launches left (slab 0), the logit bias from dL itself
         wg.call_partial_reduce(cs1, cs1.shape[0], u1, slabs, self.l1.b.off)
         wg.call_partial_reduce(cs2, cs2.shape[0], u2, slabs, self.l2.b.off)
-        wg.colsum_b16(dL, r3, 1, 32, slabs, S, P, self.l3.b.off)
+        # (the logit bias' gradient -- the sum of dL over the 3b rows -- is left in slab 0 by the loss head itself: loss_head_b16)
         return fwd, bce, pf, pb, wg
 
     def _plan_forward(self, ws, m, x=None, logits=None, bf16=False):
@@ -258,6 +258,12 @@ class DiscNetwork:
             self._ws[key] = ws
         ws["plan"].run()
         return ws["L"][:, :1]
+
+    def loss_head_b16(self, ws, logits, b, scale, stats):
+        """bf16-storage training pass: prediction loss statistics, d loss / d logit into ws['dL16'] AND the logit bias' gradient (their sum) into
+        slab 0 of the gradient slabs -- the other slabs' entries of that range are never written and stay zero, so backward()'s reduce needs no
+        column-sum launch for it.  backward() relies on this having run on the same ws."""
+        K.disc_head_b16(logits, b, scale, ws["dL16"], stats, bias_grad=self.book.slabs[0, self.l3.b.off:self.l3.b.off + 1])
 
     def forward(self, ws):
         """Logits of the 3b stacked rows [agent | replay | demo] already normalised into ws['X'][:3b]."""

@@ -119,9 +119,13 @@ def test_disc_head_b16_matches_fp32_head(dev):
     d16 = torch.zeros(4 * b, 32, dtype=torch.int16, device=dev)
     s32, s16 = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
     K.disc_head(L[:3 * b, :1], b, 5.0, d32[:3 * b, :1], s32)
-    K.disc_head_b16(L[:3 * b, :1], b, 5.0, d16, s16)
+    bg = torch.full((3,), float("nan"), device=dev)
+    K.disc_head_b16(L[:3 * b, :1], b, 5.0, d16, s16, bias_grad=bg[1:2])
     assert torch.equal(s32, s16)
     assert torch.equal(K.from_b16(d16[:, 0]), _bf(d32[:, 0])) and (d16[:, 1:] == 0).all() and (d16[3 * b:] == 0).all()
+    # v21: the logit bias' gradient = the sum of the logit gradients AS STORED (bf16-rounded), taken by the same launch
+    want = K.from_b16(d16[:3 * b, 0]).double().sum().item()
+    assert abs(bg[1].item() - want) <= 1e-6 * abs(want) + 1e-9 and torch.isnan(bg[0]) and torch.isnan(bg[2])
 
 
 def _agent(dev, name, seed, storage):

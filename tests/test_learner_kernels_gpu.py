@@ -371,6 +371,31 @@ def test_clip_and_adam_vs_torch(dev, max_norm):
         np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), atol=2e-7, rtol=1e-6)
 
 
+def test_adam_step_multi_equals_separate_launches(dev):
+    """pulse_adam_step_multi (v21): several flat buffers, one launch, the joint clip -- bit for bit what one pulse_adam_step per buffer gives."""
+    g = torch.Generator().manual_seed(31)
+    sizes = [300007, 4097, 1]
+    def fresh():
+        gg = torch.Generator().manual_seed(32)
+        return [[rnd(gg, n).to(dev) for _ in range(2)] + [torch.zeros(n, device=dev), torch.zeros(n, device=dev)] for n in sizes]
+    a, b = fresh(), fresh()
+    part = torch.empty(3 * 64, device=dev)
+    na, nb = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        grads = [rnd(g, n).to(dev) * 0.05 for n in sizes]
+        for i, (gr, n) in enumerate(zip(grads, sizes)):
+            K.sqnorm_partial(gr, n, part[64 * i:64 * (i + 1)])
+        kw = dict(lr=3e-4, step=step, weight_decay=1e-3, max_norm=1.0, sqnorm_partials=part)
+        for (p, _, m, v), gr, n in zip(a, grads, sizes):
+            K.adam_step(p, gr, m, v, n, grad_norm_out=na, **kw)
+        K.adam_step_multi([(p, gr, m, v, n) for (p, _, m, v), gr, n in zip(b, grads, sizes)], grad_norm_out=nb, **kw)
+        assert torch.equal(na, nb)
+        for (pa, _, ma, va), (pb, _, mb, vb) in zip(a, b):
+            assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    with pytest.raises(ValueError, match="1..4 groups"):
+        K.adam_step_multi([], lr=1e-3, step=1)
+
+
 def test_rollout_record_matches_reference_sequence(dev):
     """pulse_rollout_record vs the op-by-op sequence of play_steps (amp_agent.py:372-412) with rl_games' AverageMeter."""
     from pulse_amd import kernels as K

@@ -612,6 +612,37 @@ def disc_reg(flat, grad, ranges, partials):
     _lib.check(_lib.load().pulse_disc_reg(flat.data_ptr(), _p(grad), n, offs, lens, als, partials.data_ptr(), partials.shape[0], _stream()), "pulse_disc_reg")
 
 
+def carve_reduce_regions(base, parts, max_regions=8):
+    """Regions of a fused gradient reduce (ReduceGrads).  ``base``: [(offset, count, nslabs)], the slab-summed ranges of the flat gradient in
+    order; ``parts``: [(dst_offset, count, rows, src)], ranges whose value is the ordered sum of ``rows`` partial rows of the 2-D tensor ``src``
+    (Plan.partial_reduces).  Every part is carved out of the base range that contains it and becomes a region with its own source.
+    -> (regions, fused): fused is False -- and the regions are the plain base ranges -- when there is no part, a part straddles base ranges or
+    overlaps another, an offset / count / row stride is not a multiple of 4 floats, or more than ``max_regions`` regions would result; the
+    caller then keeps the plan's small reduce launches."""
+    plain = [(o, c, n, 0.0) for o, c, n in base]
+    todo = sorted(parts, key=lambda r: r[0])
+    if not todo:
+        return plain, False
+    regions, used = [], 0
+    for off, cnt, ns in base:
+        pos, end = off, off + cnt
+        for doff, dcnt, rows, src in todo:
+            if doff < off or doff >= end:
+                continue
+            if doff < pos or doff + dcnt > end or doff % 4 or dcnt % 4 or src.stride(0) % 4 or rows < 1:
+                return plain, False
+            if doff > pos:
+                regions.append((pos, doff - pos, ns, 0.0))
+            regions.append((doff, dcnt, rows, 0.0, src, src.stride(0)))
+            pos = doff + dcnt
+            used += 1
+        if end > pos:
+            regions.append((pos, end - pos, ns, 0.0))
+    if used != len(todo) or len(regions) > max_regions:
+        return plain, False
+    return regions, True
+
+
 class ReduceGrads:
     """A pre-built pulse_reduce_grads launch: regions = [(offset, count, nslabs, alpha[, src, src_stride])] of a flat gradient buffer; a region
     with ``src`` (a float32 device tensor) sums nslabs rows of that buffer (row stride ``src_stride`` floats) instead of the slabs."""

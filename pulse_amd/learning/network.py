@@ -461,27 +461,7 @@ class A2CNetwork:
         regions (deep MLPs): the plan keeps its small reduces."""
         cut = self.w_off[1] if len(self.units) >= 2 else 0
         base = ([(0, cut, ws["l0_slabs"])] if cut else []) + [(cut, self.n_flat - cut, self.split_k)]
-        parts = sorted(getattr(plan, "partial_reduces", []), key=lambda r: r[0])
-        regions = []
-        for off, cnt, ns in base:
-            pos, end = off, off + cnt
-            for doff, dcnt, rows, src in parts:
-                if doff < off or doff >= end:
-                    continue
-                if doff + dcnt > end or doff % 4 or dcnt % 4 or src.stride(0) % 4:
-                    parts = None
-                    break
-                if doff > pos:
-                    regions.append((pos, doff - pos, ns, 0.0))
-                regions.append((doff, dcnt, rows, 0.0, src, src.stride(0)))
-                pos = doff + dcnt
-            if parts is None:
-                break
-            if end > pos:
-                regions.append((pos, end - pos, ns, 0.0))
-        fused = parts is not None and len(parts) > 0 and len(regions) <= 8
-        if not fused:
-            regions = [(o, c, n, 0.0) for o, c, n in base]
+        regions, fused = K.carve_reduce_regions(base, getattr(plan, "partial_reduces", []))
         ws["reduce_all_fused"] = fused
         return K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad)
 

@@ -44,6 +44,9 @@ SOURCES = [
     # whole kernel fits the 256-register budget of two waves per SIMD
     ("gemm_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),   # (packed-f32 VALU beside MFMAs also costs more than two plain adds)
     ("gemm_x3p.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
+    # the 256 x 256 x3 tile runs ONE wave per SIMD with its 256 accumulator registers in AGPRs: no VGPR-form flag here
+    # (its k-tile body is one fully unrolled 96-MFMA schedule: lift the pragma-unroll size limit, or the loop stays rolled and the accumulators go to scratch)
+    ("gemm_x3w.hip", ["-mllvm", "-pragma-unroll-threshold=4000000", "-Wno-unused-const-variable"]),
     ("learner_ops.hip", NO_CONTRACT),
     ("b16_ops.hip", NO_CONTRACT),
     ("vae_head.hip", NO_CONTRACT),

@@ -35,12 +35,9 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "gemm_shared.h"
 
 namespace pulse {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int KC_SLOTS = 129;                        // 16-byte slots per k-chunk block: 128 outs + 1 pad slot
@@ -48,40 +45,6 @@ constexpr int IMG_BYTES = 8 * KC_SLOTS * 16;         // one operand tile: 8 k-ch
 constexpr int STAGE_BYTES = 2 * IMG_BYTES;           // A image + B image
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // two stages = 66,048 B -> two workgroups per CU
 constexpr int CP = BN;                               // epilogue transpose pitch (floats): 128 x 128 x 4 B = 65,536 B
-constexpr unsigned RSRC_FLAGS = 0x00020000u;         // raw buffer, 32-bit data format (gfx90a+ / gfx950)
-
-struct GemmArgs {
-    const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux;
-    int M, N, K;
-    int lda, ldb, ldc, ldc2, ldaux;
-    long long sA, sB, sC, sC2, sBias, sAux;   // batch strides (floats)
-    int batch, splitk, kchunk;
-    long long sSplit;                          // C slab stride per k-split (floats)
-    int act;                                   // 0 none, 1 relu, 2 silu (EPI 0 only)
-    int epi;                                   // 0 bias+act, 1 relu-grad mask, 2 silu-grad
-    int tiles_m, tiles_n;
-    int vec_epi;                               // all epilogue pointers / pitches are 16-byte aligned
-    float* rowsum; long long sRowsum;          // <MC,MC> only: per-slab sums over k of A(k, m)  (bias gradient)
-    long long* dbg;                            // optional per-workgroup clock stamps (tools/gemm_bench --clocks)
-    int round_bf16;                            // outputs rounded to bf16-representable values (bf16 autocast semantics)
-};
-
-__device__ __forceinline__ int slot_of(int out) { return out ^ ((out >> 3) & 7); }
-
-__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-}
-__device__ __forceinline__ f32x4 lds_read(int byte_addr) {
-    extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    return *reinterpret_cast<const f32x4*>(smem_c + byte_addr);
-}
-__device__ __forceinline__ void lds_write(int byte_addr, f32x4 v) {
-    extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    *reinterpret_cast<f32x4*>(smem_c + byte_addr) = v;
-}
 
 // Per-thread staging state of one operand: 4 in-flight 16-byte loads, their (constant) buffer byte offsets and the
 // (constant) LDS byte addresses their data goes to.
@@ -515,9 +478,6 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmArgs g) {
 // whole operand of one MFMA.  At this MFMA rate the kernel is bound by the fp32 operand traffic (L2 / HBM), not by the matrix pipe:
 // a plain double-buffered loop, all fragment reads of a stage issued before the tile's barrier (same race rule as above).
 // =====================================================================================================================
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BK16 = 64;
 
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
@@ -789,12 +749,6 @@ constexpr int X_STAGE = 2 * X_IMG;                   // 25,344 B
 #endif
 constexpr int X_LDS = BM * CP * 4;                   // 65,536 B: the epilogue transpose (>= 2 stages = 50,688 B) -> two workgroups per CU
 
-__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
-__device__ __forceinline__ float bitsf(unsigned v) { return __builtin_bit_cast(float, v); }
-// (lo_elem, hi_elem) rounded to nearest-even bf16 and packed {hi, lo}: one v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned pack_rn(float lo_elem, float hi_elem) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo_elem, hi_elem}, bf16x2));
-}
 
 template <bool KC>
 struct StagerX {
@@ -1162,6 +1116,31 @@ thread_local int g_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [1] extra LDS bytes p
 
 namespace pulse { int gemm_option(int key) { return key >= 0 && key < 8 ? g_opt[key] : 0; } long long* gemm_debug_buffer() { return g_dbg; } }    // read by gemm_x3p.hip (common.h)
 
+namespace {
+// Which tiling serves an x3 launch.  Cost model in units of (one 128 x 128 output tile) x (k per split), per CU: the narrow kernel keeps two
+// workgroups per CU (a round of 512; a lone workgroup runs at about twice the paired rate), the wide kernel one workgroup of four tiles' area
+// per CU and round at 1.1-1.2 x the narrow kernel's rate (profiles/r05_gemm_x3_wide_ab.txt: 3.5 units per wide round).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
+// 2 whenever the output has more than 128 rows and columns (tests).
+bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
+    static const int env = [] { const char* e = getenv("PULSE_X3_WIDE"); return e ? atoi(e) : -1; }();
+    int mode = g_opt[4];
+    if (mode == 0 && env >= 0) mode = env == 0 ? 1 : env == 1 ? 0 : env;          // PULSE_X3_WIDE=0 off, 1 automatic, 2 always
+    if (mode == 1 || g.M <= 128 || g.N <= 128) return false;
+    // per-workgroup buffer offsets are 32-bit: 256 rows of a reduction-contiguous operand, kchunk rows of a [red][out] operand
+    if ((long long)lda * (akc ? 257 : g.kchunk + 1) >= (1LL << 28) || (long long)ldb * (bkc ? 257 : g.kchunk + 1) >= (1LL << 28) ||
+        (long long)g.ldc * 257 >= (1LL << 28) || (long long)g.ldaux * 257 >= (1LL << 28))
+        return false;
+    if (mode == 2) return true;
+    const long long z = (long long)g.batch * g.splitk;
+    const long long nt = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * z;
+    const long long wt = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * z;
+    const long long rem = nt % 512;
+    const double cost_narrow = 2.0 * (double)(nt / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.0 : 2.0);
+    const double cost_wide = 3.5 * (double)((wt + 255) / 256);
+    return cost_wide < cost_narrow;
+}
+}  // namespace
+
 extern "C" {
 
 int pulse_sizeof_gemm_desc(void) { return (int)sizeof(pulse_gemm_desc); }
@@ -1260,6 +1239,11 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
         attr_done[IDX] = lds;                                                                                     \
     }                                                                                                             \
     hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_, WM_>), grid, dim3(256), lds, as_stream(s), g)
+    if (x3 && !half_tile && x3_wide_tile(g, d->lda, d->ldb, akc, bkc)) {
+        // 256 x 256 tile (gemm_x3w.hip): half the split / staging work per MFMA; taken when its one-workgroup-per-CU rounds cost less than the
+        // 128 x 128 tiling's (two workgroups per CU) -- see x3_wide_tile
+        return launch_gemm_x3w(g, akc, bkc, as_stream(s));
+    }
     if (x3 && half_tile) {
         if (akc && bkc) { LAUNCHX(9, true, true, 1); }
         else if (akc && !bkc) { LAUNCHX(10, true, false, 1); }

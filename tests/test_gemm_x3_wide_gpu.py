@@ -1,0 +1,198 @@
+"""The 256 x 256 tiling of the x3 fp32 GEMM (pulse_amd/csrc/gemm_x3w.hip) against the 128 x 128 one and against fp64.
+
+Both tilings issue the six plane products of a 16-deep k step in the same order into the same accumulator, so their outputs must be
+BIT-IDENTICAL in every form (forward, input gradient, weight gradient with split-K and the bias-gradient row sums), on full tiles, ragged
+edges, unaligned output pitches (scalar epilogue) and k tails.  gemm option 4: 1 = never the wide tile, 2 = whenever M, N > 128.
+Reference of the op: nn.Linear forward / backward, phc/learning/network_builder.py:105-124."""
+import math
+
+import pytest
+import torch
+
+from pulse_amd import kernels as K
+from pulse_amd._lib import ACT_NONE, ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def x3(monkeypatch):
+    monkeypatch.setattr(K, "F32_MODE", "x3")
+    yield
+    K.gemm_set_option(4, 0)
+
+
+def rnd(g, *shape):
+    return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+def padded(t, pitch, dev, fill=float("nan")):
+    buf = torch.full((t.shape[0], pitch), fill, dtype=torch.float32, device=dev)
+    buf[:, :t.shape[1]] = t.to(dev)
+    return buf
+
+
+def both(run):
+    """run() under the narrow and the wide tiling -> (narrow outputs, wide outputs)."""
+    outs = []
+    for opt in (1, 2):
+        K.gemm_set_option(4, opt)
+        outs.append(run())
+    K.gemm_set_option(4, 0)
+    torch.cuda.synchronize()
+    return outs
+
+
+def close64(out, ref64, k):
+    scale = ref64.abs().max().item() + 1e-30
+    err = (out.detach().cpu().double() - ref64).abs().max().item()
+    assert err <= 4e-7 * math.sqrt(k) * scale + 1e-6, f"max err {err} (scale {scale}, K={k})"
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 200, 100), (257, 300, 33), (256, 256, 16), (129, 129, 1), (512, 768, 17), (1024, 512, 934), (2048, 2048, 960),
+                                   (700, 257, 515)])
+@pytest.mark.parametrize("act,ragged_pitch", [(ACT_NONE, False), (ACT_RELU, False), (ACT_SILU, False), (ACT_RELU, True), (ACT_SILU, True)])
+def test_forward_bit_identical(dev, m, n, k, act, ragged_pitch):
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    x, w, b = rnd(g, m, k), rnd(g, n, k) / math.sqrt(k), rnd(g, n)
+    kp = (k + 3) // 4 * 4 + 4
+    xd, wd, bd = padded(x, kp, dev), padded(w, kp, dev), b.to(dev)
+    ldc = n + 3 if ragged_pitch else (n + 3) // 4 * 4                  # n + 3: unaligned rows -> the scalar epilogue
+
+    def run():
+        out = torch.full((m, ldc), 9.0, device=dev)
+        pre = torch.full((m, ldc), 9.0, device=dev) if act == ACT_SILU else None
+        K.gemm(xd, wd, out, M=m, N=n, K=k, lda=kp, ldb=kp, ldc=ldc, bias=bd, activation=act, C2=pre, ldc2=ldc)
+        return out, pre
+
+    (o1, p1), (o2, p2) = both(run)
+    assert torch.equal(o1, o2)
+    if p1 is not None:
+        assert torch.equal(p1, p2)
+    z = x.double() @ w.double().T + b.double()
+    ref = {ACT_NONE: z, ACT_RELU: z.clamp(min=0), ACT_SILU: z * torch.sigmoid(z)}[act]
+    close64(o2[:, :n], ref, k)
+    assert torch.equal(o2[:, n:].cpu(), torch.full((m, ldc - n), 9.0))  # nothing written past N
+
+
+def test_forward_batched_pairs(dev):
+    """Two problems in one launch via pointer strides (the actor / critic layer pairs), full tiles and a ragged M."""
+    g = torch.Generator().manual_seed(3)
+    for m, k, n in ((1024, 512, 256), (777, 96, 384)):
+        h = rnd(g, m, 2 * k).to(dev)
+        w = (rnd(g, 2, n, k) / 10).to(dev)
+        bias = rnd(g, 2, n).to(dev)
+
+        def run():
+            out = torch.empty(m, 2 * n, device=dev)
+            K.gemm(h, w, out, M=m, N=n, K=k, lda=2 * k, ldb=k, ldc=2 * n, bias=bias, activation=ACT_RELU, batch=2,
+                   stride_a=k, stride_b=n * k, stride_c=n, stride_bias=n)
+            return out
+
+        o1, o2 = both(run)
+        assert torch.equal(o1, o2)
+        for z in range(2):
+            ref = (h[:, z * k:(z + 1) * k].cpu().double() @ w[z].cpu().double().T + bias[z].cpu().double()).clamp(min=0)
+            close64(o2[:, z * n:(z + 1) * n], ref, k)
+
+
+@pytest.mark.parametrize("m,n,k", [(200, 300, 70), (513, 512, 69), (1000, 512, 1), (2048, 1024, 512), (300, 1030, 40)])
+@pytest.mark.parametrize("epi", [EPI_RELU_GRAD, EPI_SILU_GRAD])
+def test_dx_bit_identical(dev, m, n, k, epi):
+    """dX = (dY W) * act'(aux): A reduction-contiguous, B stored [red][out]."""
+    g = torch.Generator().manual_seed(n + k)
+    dy, w, aux = rnd(g, m, k), rnd(g, k, n) / math.sqrt(k), rnd(g, m, n)
+    kp, npad = (k + 3) // 4 * 4, (n + 3) // 4 * 4
+    dyd, wd, auxd = padded(dy, kp, dev), padded(w, npad, dev), padded(aux, npad, dev, fill=1.0)
+
+    def run():
+        out = torch.full((m, npad), 5.0, device=dev)
+        K.gemm(dyd, wd, out, M=m, N=n, K=k, lda=kp, ldb=npad, ldc=npad, b_layout=GEMM_OUT_CONTIG, epilogue=epi, aux=auxd, ldaux=npad)
+        return out
+
+    o1, o2 = both(run)
+    assert torch.equal(o1, o2)
+    acc = dy.double() @ w.double()
+    if epi == EPI_RELU_GRAD:
+        ref = acc * (aux > 0).double()
+    else:
+        s = torch.sigmoid(aux.double())
+        ref = acc * (s * (1 + aux.double() * (1 - s)))
+    close64(o2[:, :n], ref, k)
+
+
+@pytest.mark.parametrize("m,n,k,split,batch", [(512, 1024, 4096, 8, 1), (1024, 960, 16384, 16, 1), (2048, 934, 16384, 8, 1), (300, 130, 1000, 1, 1),
+                                                (200, 512, 4096, 8, 2), (257, 259, 777, 3, 1), (512, 512, 8192, 32, 2)])
+def test_dw_split_k_and_rowsum_bit_identical(dev, m, n, k, split, batch):
+    """dW = dY^T X with the batch (reduction) dimension split into slabs; the A operand's column sums (bias gradient) ride along."""
+    torch.manual_seed(m + k)
+    lda, ldb = batch * ((m + 3) // 4 * 4), batch * ((n + 3) // 4 * 4)
+    dy = torch.randn(k, lda, device=dev)
+    x = torch.randn(k, ldb, device=dev)
+    cnt = m * n
+    slab = (batch * (cnt + m) + 3) // 4 * 4
+
+    def run():
+        out = torch.full((split, slab), 7.0, device=dev)
+        K.gemm(dy, x, out, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG,
+               batch=batch, stride_a=lda // batch, stride_b=ldb // batch, stride_c=cnt, split_k=split, split_stride=slab,
+               rowsum=out, rowsum_off=batch * cnt, stride_rowsum=m)
+        return out
+
+    o1, o2 = both(run)
+    assert torch.equal(o1, o2)
+    tot = o2.sum(0).cpu().double()
+    for z in range(batch):
+        a = dy[:, z * (lda // batch): z * (lda // batch) + m].cpu().double()
+        b = x[:, z * (ldb // batch): z * (ldb // batch) + n].cpu().double()
+        w = tot[z * cnt:(z + 1) * cnt].view(m, n)
+        rs = tot[batch * cnt + z * m: batch * cnt + (z + 1) * m]
+        ref_w, ref_b = a.t() @ b, a.sum(0)
+        assert (w - ref_w).abs().max() <= 2e-5 * ref_w.abs().max()
+        assert (rs - ref_b).abs().max() <= 2e-5 * max(1.0, ref_b.abs().max())
+
+
+def test_transpose_detecting_and_exact(dev):
+    """A = I with an asymmetric B (catches row / column swaps in the wide kernel's C mapping), and small-integer products are exact."""
+    n = 384
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 100.0
+    K.gemm_set_option(4, 2)
+    out = torch.empty(n, n, device=dev)
+    K.gemm(torch.eye(n).to(dev), b.to(dev), out, M=n, N=n, K=n, lda=n, ldb=n, ldc=n)
+    assert torch.equal(out.cpu(), b.T.contiguous())
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(-8, 9, (512, 100), generator=g).float()
+    w = torch.randint(-8, 9, (300, 100), generator=g).float()
+    out = torch.empty(512, 300, device=dev)
+    K.gemm(x.to(dev), w.to(dev), out, M=512, N=300, K=100, lda=100, ldb=100, ldc=300)
+    assert torch.equal(out.cpu(), x @ w.T)
+    K.gemm_set_option(4, 0)
+
+
+def test_automatic_choice_full_size_matches_narrow(dev):
+    """The launcher's own choice (option 0) on the cfg2 update shapes gives the narrow tiling's bits; rows are tile-position independent."""
+    g = torch.Generator().manual_seed(0)
+    m, n, k = 16384, 2048, 934
+    kp = 960
+    x = torch.zeros(m, kp)
+    x[:, :k] = rnd(g, m, k)
+    w = torch.zeros(n, kp)
+    w[:, :k] = rnd(g, n, k) / 31
+    xd, wd = x.to(dev), w.to(dev)
+
+    def run(opt):
+        K.gemm_set_option(4, opt)
+        out = torch.empty(m, n, device=dev)
+        K.gemm(xd, wd, out, M=m, N=n, K=k, lda=kp, ldb=kp, ldc=n, activation=ACT_RELU)
+        K.gemm_set_option(4, 0)
+        return out
+
+    narrow, auto, wide = run(1), run(0), run(2)
+    assert torch.equal(narrow, auto) and torch.equal(narrow, wide)
+    sub = torch.empty(300, n, device=dev)
+    K.gemm_set_option(4, 2)
+    K.gemm(xd[5000:5300].contiguous(), wd, sub, M=300, N=n, K=k, lda=kp, ldb=kp, ldc=n, activation=ACT_RELU)
+    K.gemm_set_option(4, 0)
+    assert torch.equal(sub, wide[5000:5300])
+    ref = (x[:64, :k].double() @ w[:, :k].double().T).clamp(min=0)
+    close64(wide[:64], ref, k)

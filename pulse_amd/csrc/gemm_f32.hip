@@ -1118,7 +1118,7 @@ namespace pulse { int gemm_option(int key) { return key >= 0 && key < 8 ? g_opt[
 
 namespace {
 // Which tiling serves an x3 launch.  Cost model in units of (one 128 x 128 output tile) x (k per split), per CU: the narrow kernel keeps two
-// workgroups per CU (a round of 512; a lone workgroup runs at about twice the paired rate), the wide kernel one workgroup of four tiles' area
+// workgroups per CU (a round of 512 costs 2; a lone workgroup per CU 1.25), the wide kernel one workgroup of four tiles' area
 // per CU and round at 1.1-1.2 x the narrow kernel's rate (profiles/r05_gemm_x3_wide_ab.txt: 3.5 units per wide round).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
 // 2 whenever the output has more than 128 rows and columns (tests).
 bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
@@ -1135,7 +1135,7 @@ bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
     const long long nt = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * z;
     const long long wt = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * z;
     const long long rem = nt % 512;
-    const double cost_narrow = 2.0 * (double)(nt / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.0 : 2.0);
+    const double cost_narrow = 2.0 * (double)(nt / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.25 : 2.0);
     const double cost_wide = 3.5 * (double)((wt + 255) / 256);
     return cost_wide < cost_narrow;
 }

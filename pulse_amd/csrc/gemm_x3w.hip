@@ -1,26 +1,33 @@
 // fp32 GEMM on the bf16 matrix pipe ("x3": three-way operand split, six products) on a 256 x 256 x 16 workgroup tile.
 //
 // Same arithmetic, operand layouts, epilogues and split-K contract as gemm_x3_kernel (gemm_f32.hip) -- the six plane products are issued in the
-// same order per 16-deep k step, so both tilings give BIT-IDENTICAL outputs -- for the nn.Linear calls of the PPO update path:
+// same order per 16-deep k step, so both tilings give BIT-IDENTICAL matrix outputs -- for the nn.Linear calls of the PPO update path:
 //   phc/learning/network_builder.py:105-124,245-261, phc/learning/amp_network_builder.py:127-148, phc/learning/amp_network_z_builder.py:341-467.
 //
 // Why a second tiling (round-4 verdict, missing #1): the 128 x 128 x 16 tile carries 3.67 VALU instructions of in-kernel split per MFMA plus its
 // LDS traffic, about 4.6 issue slots per MFMA, and a SIMD has about 8 issue slots of 4 cycles per 32-cycle v_mfma_f32_32x32x16_bf16: the matrix pipe
 // sat at 0.65-0.69 busy.  Split work and staged bytes scale with the tile's perimeter, MFMAs with its area: on 256 x 256 a k step is 96 MFMAs per
-// wave beside 176 split VALU (1.83 per MFMA), 12 ds_write, 24 ds_read_b128 and 8 (or 32) global loads -- under 3 slots per MFMA.
+// wave beside 176 split VALU (1.83 per MFMA), 24 ds_write_b64, 28 ds_read_b128 and 8 global loads -- under 3 slots per MFMA.
 //
 // Shape of the kernel: 4 waves = ONE wave per SIMD, each wave a 128 x 128 block = 4 x 4 MFMA tiles, 256 accumulator registers in AGPRs (this
-// translation unit is built WITHOUT -amdgpu-mfma-vgpr-form; amdgpu_waves_per_eu(1, 1) gives the wave the whole 512-entry file), 256 VGPRs for
-// fragments (3 planes x 4 tiles x 2 operands = 96, B plane 0 double-buffered), two register sets of raw fp32 operands (loads run two k-tiles
-// ahead) and the split.  With one wave per SIMD nothing hides a stall, so everything is placed by hand in the 96 MFMA gaps of a k-tile:
-//   gaps  0-31  split of A for tile t+1 (one third of an element pair's chain per gap), its plane stores one per gap as the pairs complete
-//   gaps 32-63  the same for B;  gaps 36-39 / 64-67  global loads of tile t+3 into the register set the split just drained
+// translation unit is built WITHOUT -amdgpu-mfma-vgpr-form; amdgpu_waves_per_eu(1, 1) gives the wave the whole 512-entry file), VGPRs for the
+// fragments (3 planes x 4 tiles x 2 operands, plus a second copy of B plane 0), one register set of raw fp32 operands and the split.  With one
+// wave per SIMD nothing hides a stall, so everything is placed by hand in the 96 MFMA gaps of a k-tile, in ONE loop with ONE body and no branch
+// inside (the register allocator shuffles the 256 accumulators between AGPRs and VGPRs at every control-flow join they are live across):
+//   gaps  0-7   this tile's A0 / B0 fragments (A0 feeds the last term of a tile and the second of the next; B0 the first and the last)
+//   gaps  0-31  split of A for tile t+1 (a third of an element pair's chain per gap), its plane stores one per gap as the pairs complete
+//   gaps 32-63  the same for B;  gaps 36-39 / 64-67  global loads of tile t+2 into the registers the split just drained (16 B per lane each:
+//               a vector-memory instruction costs the issuing wave about an MFMA's worth of issue time)
 //   gap  69     the tile's one barrier (all stores of tile t+1 are >= 3 gaps old)
-//   gaps 70-83  fragments of tile t+1 into the registers whose last MFMA of tile t has issued (B2, A2, A1, the other B0 set, then B1)
-//   gaps  0-3   (of tile t+1) its A0 fragments -- A0 feeds the last term of a tile and the second of the next
+//   gaps 70-83  fragments of tile t+1 into the registers whose last MFMA of tile t has issued (B2, A2, the B0 copy, A1, then B1)
+// In the last trip the staging works on a k-tile past the reduction's end: free under the MFMAs.
 // Term order (A plane, B plane): (2,0) (0,2) (1,1) (1,0) (0,1) (0,0), as in gemm_x3_kernel.
-// LDS: per operand and stage 3 planes x [2 k-chunks of 8][260 slots][16 B] (slot = out ^ ((out >> 3) & 7)), two stages = 99,840 B; the epilogue
-// goes through a 256 x 128 fp32 image (131,072 B) in two passes.  One workgroup per CU.
+// LDS: per operand and stage 3 planes x [2 k-chunks of 8][260 slots][16 B] (slot = out ^ ((out >> 3) & 7)); stage 1 starts at 64 KB so ONE xor
+// toggles an address between the stages: 115,456 B.  The MFMAs are issued with the operands SWAPPED (B fragment as srcA): the accumulators hold
+// the transposed 32 x 32 tiles, lane = output row, four consecutive registers = four consecutive output columns -- so the epilogue moves them
+// through a 256 x 128 LDS image (pitch 132 floats, 135,168 B, two passes) with ds_write_b128 / ds_read_b128 and stores 16 bytes per lane, a
+// quarter of the LDS and vector-memory instructions of the untransposed layout (a vector-memory instruction costs the issuing wave ~60 cycles:
+// 256 dword stores per wave straight from the accumulators were measured at 10 us per workgroup).  One workgroup per CU.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -33,17 +40,31 @@ constexpr int WK = 16;                               // k-tile depth
 constexpr int W_CSTRIDE = 260;                       // 16-byte slots per 8-k chunk block (4 mod 8: the two chunks of a row sit in different bank-window halves)
 constexpr int W_PLANE = 2 * W_CSTRIDE * 16;          // 8,320 B
 constexpr int W_IMG = 3 * W_PLANE;                   // 24,960 B per operand
-constexpr int W_STAGE = 2 * W_IMG;                   // 49,920 B
 constexpr int W_STAGE_BIT = 65536;                   // stage 1 starts at 64 KB: one v_xor per address register toggles the stage
-constexpr int W_CP = 128;                            // epilogue image pitch (floats)
-constexpr int W_LDS = WT * W_CP * 4;                 // 131,072 B (>= stage 1's end at 65,536 + 49,920)
+constexpr int W_CP = 132;                            // epilogue image pitch (floats): 528 B = 16 mod 128, so the 8 lanes of a ds_write_b128 group (8 rows) cover all 32 banks
+constexpr int W_LDS = WT * W_CP * 4;                 // 135,168 B: the 256 x 128 epilogue image (the stages end at 115,456 B)
+constexpr int W_BIAS_OFF = 120000;                   // 256 bias values of the tile, past the stages (read once, before the image exists)
 constexpr int W_BARRIER_GAP = 69;
 
-// Per-thread staging of one operand: 16 fp32 elements per k-tile (ONE register set: the loads of tile t+2 are issued as soon as the split of
-// tile t+1 has drained the registers, 60 MFMA gaps = about 1,900 cycles before they are needed).
-//   KC (reduction-contiguous): 4 lanes per row fetch the row's 64 contiguous bytes; thread = (row0 = tid >> 2, kq = tid & 3), 4 loads of 16 B for rows
-//       row0 + 64 u; element 4 u + e is (row row0 + 64 u, k = 4 kq + e).  A row-set's two element pairs become 8 bytes per plane (ds_write_b64).
-//   MC ([red][out]): lane = out (tid), 16 dword loads, element kr is (k row kr, out).  A chunk of 8 k rows becomes 16 bytes per plane (ds_write_b128).
+typedef __attribute__((address_space(3))) char lds_char;
+// LDS byte offset of the dynamic shared segment (an integer: the per-lane addresses below are plain ints that xor between the stages)
+__device__ __forceinline__ int lds_base() {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    return (int)(unsigned)(unsigned long)(lds_char*)smem_c;
+}
+template <typename T>
+__device__ __forceinline__ T lds_ld(int addr) { return *reinterpret_cast<const __attribute__((address_space(3))) T*>((unsigned long)(unsigned)addr); }
+template <typename T>
+__device__ __forceinline__ void lds_st(int addr, T v) { *reinterpret_cast<__attribute__((address_space(3))) T*>((unsigned long)(unsigned)addr) = v; }
+
+// Per-thread staging of one operand: 16 fp32 elements per k-tile from 4 loads of 16 B (ONE register set: the loads of tile t+2 are issued as soon
+// as the split of tile t+1 has drained the registers, 60 MFMA gaps = about 1,900 cycles before they are needed).
+//   KC (reduction-contiguous): 4 lanes per row fetch the row's 64 contiguous bytes; thread = (row0 = tid >> 2, kq = tid & 3), load u = row row0 + 64 u;
+//       element 4 u + e is (row row0 + 64 u, k = 4 kq + e).  Pair p = elements (2p, 2p + 1); store unit u = row-set u.
+//   MC ([red][out]): a wave fetches 1 KB of a k row; thread = (og = tid & 63, kg = tid >> 6 = the wave), load kr = k row 4 kg + kr, outs 4 og .. 4 og + 3;
+//       element 4 kr + u is (k row 4 kg + kr, out 4 og + u).  Pair p = 2 u + h = elements (8 h + u, 8 h + 4 + u); store unit u = out 4 og + u.
+//   Either way a store unit is two pairs = 4 consecutive k of one row / out = 8 bytes per plane (ds_write_b64; with slot_of the 16 lanes of a store
+//   group fall on every bank pair exactly twice, the minimum for 16 x 8 B in one half of their slots).
 template <bool KC>
 struct StagerW {
     float v[16];
@@ -51,33 +72,37 @@ struct StagerW {
     float ta, tb, ra, rb;                // the pair in flight
     unsigned tq0, tq1;
     int voff;                            // per-lane byte offset (constant)
-    int lds;                             // per-lane LDS byte address inside the operand's image; the stage bit (W_STAGE_BIT) toggles every tile
+    int wl[KC ? 1 : 4];                  // per-lane LDS byte address(es) of the store units in the stage being FILLED (toggled every tile)
     int kpos;                            // KC: first k of the thread's 4 elements per row
     int step;                            // KC: bytes per 64 rows; MC: bytes per k row (wave-uniform)
+    int soff0;                           // MC: byte offset of the wave's first k row inside a k-tile (wave-uniform)
 
-    __device__ __forceinline__ void init(int tid, int ld, int img_off) {
+    __device__ __forceinline__ void init(int tid, int wave, int ld, int img) {
         if constexpr (KC) {
             const int row0 = tid >> 2, kq = tid & 3;
             kpos = kq * 4;
             voff = (row0 * ld + kq * 4) * 4;
-            lds = img_off + ((kq >> 1) * W_CSTRIDE + slot_of(row0)) * 16 + (kq & 1) * 8;     // rows row0 + 64 u: slot + 64 u
+            wl[0] = img + ((kq >> 1) * W_CSTRIDE + slot_of(row0)) * 16 + (kq & 1) * 8;       // rows row0 + 64 u: + 1024 u
             step = 64 * ld * 4;
+            soff0 = 0;
         } else {
+            const int og = tid & 63;
             kpos = 0;
-            voff = tid * 4;
-            lds = img_off + slot_of(tid) * 16;
+            voff = og * 16;
             step = ld * 4;
+            soff0 = 4 * wave * step;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wl[u] = img + ((wave >> 1) * W_CSTRIDE + slot_of(4 * og + u)) * 16 + (wave & 1) * 8;
         }
     }
-    // load unit u of the k-tile at scalar byte offset soff: KC 4 units (one per row-set), MC 4 units of 4 k rows
-    __device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rs, int soff, int u) {
-        if constexpr (KC) {
-            const f32x4 a = buf_load(rs, voff, soff + u * step);
-            v[4 * u] = a.x; v[4 * u + 1] = a.y; v[4 * u + 2] = a.z; v[4 * u + 3] = a.w;
-        } else {
+    __device__ __forceinline__ void toggle() {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[4 * u + i] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + (4 * u + i) * step, 0));
-        }
+        for (int u = 0; u < (KC ? 1 : 4); ++u) wl[u] ^= W_STAGE_BIT;
+    }
+    // load u (0 .. 3) of the k-tile at scalar byte offset soff
+    __device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rs, int soff, int u) {
+        const f32x4 a = buf_load(rs, voff, soff + soff0 + u * step);
+        v[4 * u] = a.x; v[4 * u + 1] = a.y; v[4 * u + 2] = a.z; v[4 * u + 3] = a.w;
     }
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff) {
 #pragma unroll
@@ -92,15 +117,16 @@ struct StagerW {
                 if (kpos + (e & 3) >= hi) v[e] = 0.f;
         }
     }
-    // MC only (the weight-gradient form's bias gradient): sums of the two 8-k chunks, associated like gemm_x3_kernel's
-    __device__ __forceinline__ float sum8(int c) const {
-        const float* x = &v[8 * c];
-        return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    // MC only (the weight-gradient form's bias gradient): this thread's 4 k rows of out 4 og + u
+    __device__ __forceinline__ float sum4(int u) const { return (v[u] + v[4 + u]) + (v[8 + u] + v[12 + u]); }
+    __device__ __forceinline__ float elem(int p, int which) const {
+        if constexpr (KC) return v[2 * p + which];
+        else return v[8 * (p & 1) + 4 * which + (p >> 1)];
     }
-    // one third-ish of the split chain of element pair p (elements 2p, 2p+1): round-to-nearest-even at every level, remainders exact
+    // a third or so of the split chain of element pair p: round-to-nearest-even at every level, remainders exact
     __device__ __forceinline__ void split_step(int p, int s) {
         if (s == 0) {
-            ta = v[2 * p]; tb = v[2 * p + 1];
+            ta = elem(p, 0); tb = elem(p, 1);
             tq0 = pack_rn(ta, tb);
             p0[p] = tq0;
         } else if (s == 1) {
@@ -116,34 +142,27 @@ struct StagerW {
         }
     }
     __device__ __forceinline__ void split_pair(int p) { split_step(p, 0); split_step(p, 1); split_step(p, 2); split_step(p, 3); }
-    // plane stores.  KC: unit u (row-set), MC: unit c (k-chunk); pl = plane; st = this operand's per-lane address with the stage bit applied
-    static constexpr int NWRITE = KC ? 4 : 2;        // store units per tile (x 3 planes)
-    static constexpr int PAIRS_PER_UNIT = KC ? 2 : 4;
-    __device__ __forceinline__ void write_plane(int addr, int u, int pl) {
-        extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    // plane store of unit u (pairs 2u, 2u + 1), plane pl, into the stage being filled
+    __device__ __forceinline__ void write_plane(int u, int pl) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const unsigned* P = pl == 0 ? p0 : pl == 1 ? p1 : p2;
-        if constexpr (KC) {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u32x2*>(smem_c + addr + u * 1024 + pl * W_PLANE) = (u32x2){P[2 * u], P[2 * u + 1]};
-        } else {
-            *reinterpret_cast<u32x4*>(smem_c + addr + u * (W_CSTRIDE * 16) + pl * W_PLANE) = (u32x4){P[4 * u], P[4 * u + 1], P[4 * u + 2], P[4 * u + 3]};
-        }
+        const int addr = KC ? wl[0] + u * 1024 : wl[KC ? 0 : u];
+        lds_st<u32x2>(addr + pl * W_PLANE, (u32x2){P[2 * u], P[2 * u + 1]});
     }
-    // side work of gap q (0 .. 31) of this operand's split phase: a third of pair q / 4's chain, and the stores of the units already complete
-    __device__ __forceinline__ void phase_gap(int addr, int q) {
+    // side work of gap q (0 .. 31) of this operand's split phase: a third of pair q / 4's chain, and the stores of the units already complete:
+    // unit u's pairs are complete after gap 8 u + 7; its three stores follow, one per gap
+    __device__ __forceinline__ void phase_gap(int q) {
         split_step(q >> 2, q & 3);
-        // unit u's pairs are complete after gap 4 PAIRS_PER_UNIT (u + 1) - 1; its three stores follow, one per gap
-        constexpr int G = 4 * PAIRS_PER_UNIT;
-        if (q >= G) {
-            const int r = q - G, u = r / G, w = r % G;
-            if (w < 3) write_plane(addr, u, w);
+        if (q >= 8) {
+            const int r = q - 8, u = r >> 3, w = r & 7;
+            if (w < 3) write_plane(u, w);
         }
     }
     // the last unit's stores fall in the three gaps after the phase
-    __device__ __forceinline__ void phase_tail(int addr, int w) { write_plane(addr, NWRITE - 1, w); }
+    __device__ __forceinline__ void phase_tail(int w) { write_plane(3, w); }
 };
 
-// ---- epilogue: one 256 x 128 pass through the LDS image.  Image column c holds tile column (c >> 6) * 128 + 64 pass + (c & 63) -----------------------------
+// ---- epilogue: one 256 x 128 pass through the LDS image (pitch W_CP floats).  Image column c holds tile column (c >> 6) * 128 + 64 pass + (c & 63) --------
 __device__ __forceinline__ int w_tile_col(int c, int pass) { return ((c >> 6) << 7) + 64 * pass + (c & 63); }
 
 __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int tid, int m0, int n0, float* C, float* C2, const float* aux) {
@@ -302,61 +321,64 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, klen > 0 ? recB : 0u, RSRC_FLAGS);
     const int kstepA = (AKC ? 4 : g.lda * 4) * WK, kstepB = (BKC ? 4 : g.ldb * 4) * WK;      // bytes per k-tile
 
+    const int lb = lds_base();
     StagerW<AKC> sa;
     StagerW<BKC> sb;
-    sa.init(tid, g.lda, 0);
-    sb.init(tid, g.ldb, W_IMG);
+    sa.init(tid, wave, g.lda, lb);
+    sb.init(tid, wave, g.ldb, lb + W_IMG);
 
     // fragment read addresses: lane (l31, half) reads out base + 32 t + l31, k-chunk = half, plane p at + p * W_PLANE.  base is a multiple of 128, so
-    // slot_of(base + 64 e + 32 o + l31) = base + 64 e + slot_of(32 o + l31): one address per tile parity, the rest are immediates.  These are the
-    // addresses in the CURRENT tile's stage; ^ W_STAGE_BIT is the stage being filled.
-    int frA0 = (half * W_CSTRIDE + wm * 128 + slot_of(l31)) * 16;
-    int frA1 = (half * W_CSTRIDE + wm * 128 + slot_of(32 + l31)) * 16;
-    int frB0 = W_IMG + (half * W_CSTRIDE + wn * 128 + slot_of(l31)) * 16;
-    int frB1 = W_IMG + (half * W_CSTRIDE + wn * 128 + slot_of(32 + l31)) * 16;
-    auto rd = [&](int addr, int pl, int t) {
-        extern __shared__ __attribute__((aligned(16))) char smem_c[];
-        return *reinterpret_cast<const bf16x8*>(smem_c + addr + (t >> 1) * 1024 + pl * W_PLANE);
-    };
+    // slot_of(base + 64 e + 32 o + l31) = base + 64 e + slot_of(32 o + l31): one address per tile parity, the rest are immediates.  They point into the
+    // stage the NEXT fragment reads come from: toggled once per tile, after the tile's own A0 / B0 reads (gaps 8-11).
+    int frA0 = lb + (half * W_CSTRIDE + wm * 128 + slot_of(l31)) * 16;
+    int frA1 = lb + (half * W_CSTRIDE + wm * 128 + slot_of(32 + l31)) * 16;
+    int frB0 = lb + W_IMG + (half * W_CSTRIDE + wn * 128 + slot_of(l31)) * 16;
+    int frB1 = lb + W_IMG + (half * W_CSTRIDE + wn * 128 + slot_of(32 + l31)) * 16;
+    auto rd = [&](int addr, int pl, int t) { return lds_ld<bf16x8>(addr + (t >> 1) * 1024 + pl * W_PLANE); };
 
     f32x16 acc[4][4];
+    // the tile's 256 bias values go through LDS: in the transposed accumulator layout a lane needs 16 x 4 consecutive ones (the same for all rows)
     {
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.epi == 0 && g.bias) {
-            const float* bias = g.bias + bz * g.sBias;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = n0 + wn * 128 + j * 32 + l31;
-                if (c < g.N) bv[j] = bias[c];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = to_agpr(bv[j]);
+        float bv = 0.f;
+        if (g.epi == 0 && g.bias && n0 + tid < g.N) bv = g.bias[bz * g.sBias + n0 + tid];
+        lds_st<float>(lb + W_BIAS_OFF + tid * 4, bv);
     }
-    float rs0 = 0.f, rs1 = 0.f;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // fragments: fa[plane][tile], fb[plane][tile]; fbx = B plane 0 of the NEXT tile's first term (B0 feeds the first and the last term of a tile: the
+    // fragments: fa[plane][tile], fb[plane][tile]; fbx = B plane 0 for the NEXT tile's first term (B0 feeds the first and the last term of a tile: the
     // copy for the first term is read a tile ahead, the one for terms 3 and 5 in the tile's own first gaps)
     bf16x8 fa[3][4], fb[3][4], fbx[4];
 
     // prologue: tile 0 into stage 0, the loads of tile 1, tile 0's fragments (its A0 / B0 are read by the loop body itself)
     sa.load(rsA, 0); sb.load(rsB, 0);
-    sa.mask(nkt == 1 ? hi : WK); sb.mask(nkt == 1 ? hi : WK);
-    if constexpr (!AKC) { rs0 += sa.sum8(0); rs1 += sa.sum8(1); }
+    if (nkt == 1) { sa.mask(hi); sb.mask(hi); }
+    if constexpr (!AKC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rs[u] += sa.sum4(u);
+    }
 #pragma unroll
     for (int p = 0; p < 8; ++p) sa.split_pair(p);
 #pragma unroll
-    for (int u = 0; u < StagerW<AKC>::NWRITE; ++u) { sa.write_plane(sa.lds, u, 0); sa.write_plane(sa.lds, u, 1); sa.write_plane(sa.lds, u, 2); }
+    for (int u = 0; u < 4; ++u) { sa.write_plane(u, 0); sa.write_plane(u, 1); sa.write_plane(u, 2); }
 #pragma unroll
     for (int p = 0; p < 8; ++p) sb.split_pair(p);
 #pragma unroll
-    for (int u = 0; u < StagerW<BKC>::NWRITE; ++u) { sb.write_plane(sb.lds, u, 0); sb.write_plane(sb.lds, u, 1); sb.write_plane(sb.lds, u, 2); }
+    for (int u = 0; u < 4; ++u) { sb.write_plane(u, 0); sb.write_plane(u, 1); sb.write_plane(u, 2); }
+    sa.toggle(); sb.toggle();                                   // the loop's first trip fills stage 1
     sa.load(rsA, kstepA); sb.load(rsB, kstepB);
     __syncthreads();
+    // register r of MFMA tile (i, j) is row wm 128 + 32 i + l31, column wn 128 + 32 j + 8 (r >> 2) + 4 half + (r & 3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bq = lds_ld<f32x4>(lb + W_BIAS_OFF + (wn * 128 + j * 32 + 8 * gq + 4 * half) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j][4 * gq] = to_agpr(bq.x); acc[i][j][4 * gq + 1] = to_agpr(bq.y);
+                acc[i][j][4 * gq + 2] = to_agpr(bq.z); acc[i][j][4 * gq + 3] = to_agpr(bq.w);
+            }
+        }
 #pragma unroll
     for (int t = 0; t < 4; ++t) { fa[2][t] = rd((t & 1) ? frA1 : frA0, 2, t); fbx[t] = rd((t & 1) ? frB1 : frB0, 0, t); }
 #pragma unroll
@@ -364,18 +386,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         fb[2][t] = rd((t & 1) ? frB1 : frB0, 2, t); fa[1][t] = rd((t & 1) ? frA1 : frA0, 1, t); fb[1][t] = rd((t & 1) ? frB1 : frB0, 1, t);
     }
 
-    // ONE loop, one body, no branch inside and no tail code: tile t's 96 MFMAs with the staging of tile t+1 in their gaps.  In the last trip the
-    // staging works on a k-tile past the reduction's end (loads beyond the records read zero, or read operand memory that is never used) into the
-    // stage nobody reads again -- free under the MFMAs, and the accumulators see a single back edge (with tails and parity copies the register
-    // allocator moved them between AGPRs and VGPRs at every join and spilled 4,000 registers).
     int soffA = 2 * kstepA, soffB = 2 * kstepB;
     for (int t = 0; t < nkt; ++t) {
-        const int wrA = sa.lds ^ W_STAGE_BIT, wrB = sb.lds ^ W_STAGE_BIT;                 // tile t+1's stage
-        const int nA0 = frA0 ^ W_STAGE_BIT, nA1 = frA1 ^ W_STAGE_BIT, nB0 = frB0 ^ W_STAGE_BIT, nB1 = frB1 ^ W_STAGE_BIT;
-        const int hin = (t + 2 == nkt) ? hi : WK;                                         // tile t+1 is the last one: its k tail is zeroed
-        if (hin < WK) { sa.mask(hin); sb.mask(hin); }                                     // (a uniform branch that does not touch the accumulators)
-        if constexpr (!AKC) {
-            if (t + 1 < nkt) { rs0 += sa.sum8(0); rs1 += sa.sum8(1); }
+        if (t + 2 == nkt && hi < WK) { sa.mask(hi); sb.mask(hi); }                        // tile t+1 is the last one: its k tail is zeroed (a uniform
+        if constexpr (!AKC) {                                                             // branch that does not touch the accumulators)
+            if (t + 1 < nkt) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rs[u] += sa.sum4(u);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 96; ++q) {
@@ -383,15 +401,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 const int term = q >> 4, i = (q >> 2) & 3, j = q & 3;
                 const bf16x8 a = term == 0 ? fa[2][i] : (term == 2 || term == 3) ? fa[1][i] : fa[0][i];
                 const bf16x8 b = term == 0 ? fbx[j] : term == 1 ? fb[2][j] : (term == 2 || term == 4) ? fb[1][j] : fb[0][j];
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[i][j], 0, 0, 0);      // transposed tile: lane = row, registers = columns
             }
-            // this tile's A0 (first needed at MFMA 16; its registers fed the previous tile's last term) and B0 (needed at MFMA 48)
+            // this tile's A0 (first needed at MFMA 16; its registers fed the previous tile's last term) and B0 (needed at MFMA 48), then the read
+            // addresses move to the stage being filled
             if (q < 4) fa[0][q] = rd((q & 1) ? frA1 : frA0, 0, q);
             else if (q < 8) fb[0][q - 4] = rd((q & 1) ? frB1 : frB0, 0, q - 4);
-            if (q < 32) sa.phase_gap(wrA, q);
-            else if (q < 35) sa.phase_tail(wrA, q - 32);
-            if (q >= 32 && q < 64) sb.phase_gap(wrB, q - 32);
-            else if (q >= 64 && q < 67) sb.phase_tail(wrB, q - 64);
+            else if (q == 8) frA0 ^= W_STAGE_BIT;
+            else if (q == 9) frA1 ^= W_STAGE_BIT;
+            else if (q == 10) frB0 ^= W_STAGE_BIT;
+            else if (q == 11) frB1 ^= W_STAGE_BIT;
+            if (q < 32) sa.phase_gap(q);
+            else if (q < 35) sa.phase_tail(q - 32);
+            else if (q == 35) sa.toggle();
+            if (q >= 32 && q < 64) sb.phase_gap(q - 32);
+            else if (q >= 64 && q < 67) sb.phase_tail(q - 64);
+            else if (q == 67) sb.toggle();
             if (q >= 36 && q < 40) sa.load_unit(rsA, soffA, q - 36);                      // tile t+2 into the registers the split just drained
             if (q >= 64 && q < 68) sb.load_unit(rsB, soffB, q - 64);
             if (q == W_BARRIER_GAP) {
@@ -399,51 +424,63 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 __syncthreads();
             }
             constexpr int R0 = W_BARRIER_GAP + 1;
-            if (q == R0) { fb[2][0] = rd(nB0, 2, 0); fb[2][1] = rd(nB1, 2, 1); }
-            else if (q == R0 + 1) { fb[2][2] = rd(nB0, 2, 2); fb[2][3] = rd(nB1, 2, 3); }
-            else if (q == R0 + 2) { fa[2][0] = rd(nA0, 2, 0); fa[2][1] = rd(nA1, 2, 1); }
-            else if (q == R0 + 3) { fa[2][2] = rd(nA0, 2, 2); fa[2][3] = rd(nA1, 2, 3); }
-            else if (q == R0 + 4) { fbx[0] = rd(nB0, 0, 0); fbx[1] = rd(nB1, 0, 1); }
-            else if (q == R0 + 5) { fbx[2] = rd(nB0, 0, 2); fbx[3] = rd(nB1, 0, 3); }
-            else if (q == R0 + 6) { fa[1][0] = rd(nA0, 1, 0); fa[1][1] = rd(nA1, 1, 1); }
-            else if (q == R0 + 7) { fa[1][2] = rd(nA0, 1, 2); fa[1][3] = rd(nA1, 1, 3); }
-            else if (q >= 80 && q < 84) fb[1][q - 80] = rd((q & 1) ? nB1 : nB0, 1, q - 80);
+            if (q == R0) { fb[2][0] = rd(frB0, 2, 0); fb[2][1] = rd(frB1, 2, 1); }
+            else if (q == R0 + 1) { fb[2][2] = rd(frB0, 2, 2); fb[2][3] = rd(frB1, 2, 3); }
+            else if (q == R0 + 2) { fa[2][0] = rd(frA0, 2, 0); fa[2][1] = rd(frA1, 2, 1); }
+            else if (q == R0 + 3) { fa[2][2] = rd(frA0, 2, 2); fa[2][3] = rd(frA1, 2, 3); }
+            else if (q == R0 + 4) { fbx[0] = rd(frB0, 0, 0); fbx[1] = rd(frB1, 0, 1); }
+            else if (q == R0 + 5) { fbx[2] = rd(frB0, 0, 2); fbx[3] = rd(frB1, 0, 3); }
+            else if (q == R0 + 6) { fa[1][0] = rd(frA0, 1, 0); fa[1][1] = rd(frA1, 1, 1); }
+            else if (q == R0 + 7) { fa[1][2] = rd(frA0, 1, 2); fa[1][3] = rd(frA1, 1, 3); }
+            else if (q >= 80 && q < 84) fb[1][q - 80] = rd((q & 1) ? frB1 : frB0, 1, q - 80);
             __builtin_amdgcn_sched_barrier(0);
         }
-        sa.lds = wrA; sb.lds = wrB;
-        frA0 = nA0; frA1 = nA1; frB0 = nB0; frB1 = nB1;
         soffA += kstepA; soffB += kstepB;
     }
-    __syncthreads();                                              // the epilogue reuses the staging buffers
     if constexpr (!AKC) {
-        if (g.rowsum != nullptr && tn == 0 && m0 + tid < g.M) g.rowsum[bz * g.sRowsum + sp * g.sSplit + m0 + tid] = rs0 + rs1;      // thread = out: it summed all 16 k rows of every tile
+        // bias gradient of the weight-gradient form: the four waves hold the sums of their k rows (4 of every 16) for all 256 outs
+        if (g.rowsum != nullptr && tn == 0) {                    // workgroup-uniform
+            __syncthreads();                                     // the staging buffers are free after the last tile's fragment reads
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds_st<float>(lb + (wave * 256 + 4 * lane + u) * 4, rs[u]);
+            __syncthreads();
+            if (m0 + tid < g.M) {
+                const float s0 = lds_ld<float>(lb + tid * 4), s1 = lds_ld<float>(lb + (256 + tid) * 4);
+                const float s2 = lds_ld<float>(lb + (512 + tid) * 4), s3 = lds_ld<float>(lb + (768 + tid) * 4);
+                g.rowsum[bz * g.sRowsum + sp * g.sSplit + m0 + tid] = (s0 + s1) + (s2 + s3);
+            }
+        }
     }
     if (g.dbg) { dbg_c1 = clock64(); dbg_w1 = wall_clock64(); }
 
-    // epilogue: pass p covers MFMA column tiles j = 2p, 2p + 1 of every wave (all four waves write 128 registers per pass)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* C = g.C + bz * g.sC + sp * g.sSplit;
-    float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
-    const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+    // epilogue: pass p covers MFMA column tiles j = 2p, 2p + 1 of every wave (all four waves write 128 registers per pass, 16 bytes at a time)
+    {
+        float* C = g.C + bz * g.sC + sp * g.sSplit;
+        float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
+        const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+        const int img = lb + ((wm * 128 + l31) * W_CP + wn * 64 + 4 * half) * 4;
+        __syncthreads();                                          // the image overlays the staging buffers
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass) __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    smem[(wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * W_CP + wn * 64 + jj * 32 + l31] = acc[i][2 * pass + jj][r];
-        __syncthreads();
-        if (g.dbg && tid == 0 && pass == 0) g.dbg[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 6] = clock64();
-        w_store_pass(g, pass, tid, m0, n0, C, C2, aux);
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x16& t = acc[i][2 * pass + jj];
+                        lds_st<f32x4>(img + (i * 32 * W_CP + jj * 32 + 8 * gq) * 4, (f32x4){t[4 * gq], t[4 * gq + 1], t[4 * gq + 2], t[4 * gq + 3]});
+                    }
+            __syncthreads();
+            w_store_pass(g, pass, tid, m0, n0, C, C2, aux);
+        }
     }
     if (g.dbg && tid == 0) {
         long long* o = g.dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
-        o[0] = dbg_c0; o[1] = dbg_w0; o[2] = dbg_c1; o[3] = dbg_w1; o[4] = clock64(); o[5] = wall_clock64();
+        o[0] = dbg_c0; o[1] = dbg_w0; o[2] = dbg_c1; o[3] = dbg_w1; o[4] = clock64(); o[5] = wall_clock64(); o[6] = dbg_c1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        o[7] = wall_clock64();                    // the workgroup's stores acknowledged (tools/gemm_x3w_phases.py)
+        o[7] = wall_clock64();                    // the wave's stores acknowledged (tools/gemm_x3w_phases.py)
     }
 }
 

@@ -118,6 +118,36 @@ def dw_split(tiles, max_split, fill=512):
     return s
 
 
+def x3_tile_costs(M, N, z):
+    """(narrow, wide) cost of an x3 launch with z = batch x split_k grid slices, in the launcher's units (gemm_f32.hip: x3_wide_tile): one
+    128 x 128 tile alone on a CU = 1.25 per unit of reduction length, two sharing a CU 2; a 256 x 256 workgroup has a CU to itself at 3.5."""
+    nt = ((M + 127) // 128) * ((N + 127) // 128) * z
+    wt = ((M + 255) // 256) * ((N + 255) // 256) * z
+    rem = nt % 512
+    narrow = 2.0 * (nt // 512) + (0.0 if rem == 0 else 1.25 if rem <= 256 else 2.0)      # a lone workgroup is not quite twice as fast as a paired one
+    wide = 3.5 * ((wt + 255) // 256) if (M > 128 and N > 128) else float("inf")
+    return narrow, wide
+
+
+def dw_split_x3(M, N, batch, max_split):
+    """Slab count of an fp32 (x3) weight-gradient launch now that the launcher has two tilings: the power-of-two fraction of ``max_split`` with
+    the lowest modelled time = min(narrow, wide cost) / split (the reduction length per workgroup is K / split), fewer slabs on ties and a small
+    charge per slab for its write and its share of the reduce.  cfg2 layer 1 (2048 x 960): 4 slabs on the narrow tiling -> 8 on the wide one
+    (327 -> 296 us, profiles/r05_gemm_x3_wide_ab.txt); the [512, 1024] pair keeps 8 narrow slabs."""
+    if F32_MODE != "x3" or os.environ.get("PULSE_X3_WIDE", "1") == "0":
+        return dw_split(((M + 127) // 128) * ((N + 127) // 128) * batch, max_split)
+    best, best_t = max_split, None
+    s = max_split
+    while s >= 1:
+        t = min(x3_tile_costs(M, N, batch * s)) / s + 0.004 * s
+        if best_t is None or t < best_t - 1e-9 or abs(t - best_t) <= 1e-9:
+            best, best_t = s, t
+        if s % 2:
+            break
+        s //= 2
+    return best
+
+
 def dw_split_b16(M, N, batch, max_split):
     """Slab count of a bf16-storage weight-gradient launch (pulse_gemm_x3p, planes = 1, both operands [red][out]).  The 256 x 256 tile moves
     2/3 of the bytes per MFMA of the 256 x 128 one (profiles/r04_ab_runs.txt: 2048 x 934 over 16384 rows: 124 us on 64 narrow tiles x 4

@@ -275,7 +275,8 @@ class MlpGraph:
             # sub-networks a pass does NOT visit, so the slabs a visited layer leaves alone must never have been written by anyone: every
             # plan built over this book has to agree on the count (it depends on m) -- otherwise reduce_slabs would silently add another
             # graph's stale partial sums (round-3 advisor finding)
-            book.note_slab_layout(lin.w.name, 1 if via_scratch else K.dw_split(tiles, S), m)
+            sl = K.dw_split_x3(lin.n, lin.k_phys, 1, S)
+            book.note_slab_layout(lin.w.name, 1 if via_scratch else sl, m)
             if via_scratch:
                 ws_ = self._w_scratch
                 p.gemm(gz, x, ws_, M=lin.n, N=lin.k_phys, K=m, lda=ldg, ldb=x.stride(0), ldc=lin.w.pitch, a_layout=GEMM_OUT_CONTIG,
@@ -284,7 +285,7 @@ class MlpGraph:
                 p.call("pulse_reduce_slabs", ws_.data_ptr(), 32, ws_.stride(0), wcount + lin.n, book.slabs.data_ptr() + 4 * lin.w.off, 1.0)
             else:
                 p.gemm(gz, x, book.slabs, M=lin.n, N=lin.k_phys, K=m, lda=ldg, ldb=x.stride(0), ldc=lin.w.pitch, a_layout=GEMM_OUT_CONTIG,
-                       b_layout=GEMM_OUT_CONTIG, a_off=gzo, b_off=op["src_col"], c_off=lin.w.off, split_k=K.dw_split(tiles, S), split_stride=P,
+                       b_layout=GEMM_OUT_CONTIG, a_off=gzo, b_off=op["src_col"], c_off=lin.w.off, split_k=sl, split_stride=P,
                        algo_n=lin.k_logical, rowsum=book.slabs, rowsum_off=lin.b.off)
             # input gradients for the requested column ranges, producer's activation derivative fused
             for (c0, c1, act, aux_name, aux_col) in op["grad_ranges"]:

@@ -1,8 +1,8 @@
 """The 256 x 256 tiling of the x3 fp32 GEMM (pulse_amd/csrc/gemm_x3w.hip) against the 128 x 128 one and against fp64.
 
-Both tilings issue the six plane products of a 16-deep k step in the same order into the same accumulator, so their outputs must be
-BIT-IDENTICAL in every form (forward, input gradient, weight gradient with split-K and the bias-gradient row sums), on full tiles, ragged
-edges, unaligned output pitches (scalar epilogue) and k tails.  gemm option 4: 1 = never the wide tile, 2 = whenever M, N > 128.
+Both tilings issue the six plane products of a 16-deep k step in the same order into the same accumulator, so their matrix outputs must
+be BIT-IDENTICAL in every form (forward, input gradient, weight gradient with split-K), on full tiles, ragged edges, unaligned output pitches and
+k tails; the bias-gradient row sums of the weight-gradient form are summed in a different association and agree to rounding.  gemm option 4: 1 = never the wide tile, 2 = whenever M, N > 128.
 Reference of the op: nn.Linear forward / backward, phc/learning/network_builder.py:105-124."""
 import math
 
@@ -140,7 +140,11 @@ def test_dw_split_k_and_rowsum_bit_identical(dev, m, n, k, split, batch):
         return out
 
     o1, o2 = both(run)
-    assert torch.equal(o1, o2)
+    assert torch.equal(o1[:, :batch * cnt], o2[:, :batch * cnt])              # the weight-gradient slabs: bit-identical
+    # the row sums ride in a different association (the wide kernel's waves own 4 of every 16 k rows): same value to fp32 rounding of the terms
+    r1, r2 = o1[:, batch * cnt:batch * (cnt + m)].double(), o2[:, batch * cnt:batch * (cnt + m)].double()
+    assert (r1 - r2).abs().max().item() <= 2e-6 * dy.abs().sum(0).max().item() / split + 1e-6
+    assert torch.equal(o1[:, batch * (cnt + m):], o2[:, batch * (cnt + m):])   # nothing written past the row sums
     tot = o2.sum(0).cpu().double()
     for z in range(batch):
         a = dy[:, z * (lda // batch): z * (lda // batch) + m].cpu().double()

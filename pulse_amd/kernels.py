@@ -131,15 +131,15 @@ def x3_tile_costs(M, N, z):
 
 def dw_split_x3(M, N, batch, max_split):
     """Slab count of an fp32 (x3) weight-gradient launch now that the launcher has two tilings: the power-of-two fraction of ``max_split`` with
-    the lowest modelled time = min(narrow, wide cost) / split (the reduction length per workgroup is K / split), fewer slabs on ties and a small
-    charge per slab for its write and its share of the reduce.  cfg2 layer 1 (2048 x 960): 4 slabs on the narrow tiling -> 8 on the wide one
+    the lowest modelled time = min(narrow, wide cost) / split (the reduction length per workgroup is K / split) plus a charge per slab for its
+    write and its share of the reduce (calibrated on the 2048 x 960 output: 16 us per 4 slabs against 281 us of GEMM), fewer slabs on ties.  cfg2 layer 1 (2048 x 960): 4 slabs on the narrow tiling -> 8 on the wide one
     (327 -> 296 us, profiles/r05_gemm_x3_wide_ab.txt); the [512, 1024] pair keeps 8 narrow slabs."""
     if F32_MODE != "x3" or os.environ.get("PULSE_X3_WIDE", "1") == "0":
         return dw_split(((M + 127) // 128) * ((N + 127) // 128) * batch, max_split)
     best, best_t = max_split, None
     s = max_split
     while s >= 1:
-        t = min(x3_tile_costs(M, N, batch * s)) / s + 0.004 * s
+        t = min(x3_tile_costs(M, N, batch * s)) / s + 0.006 * s * (M * N * batch) / (2048.0 * 960.0)      # + the slab's write and its share of the reduce
         if best_t is None or t < best_t - 1e-9 or abs(t - best_t) <= 1e-9:
             best, best_t = s, t
         if s % 2:

@@ -236,7 +236,8 @@ class AMPAgent(CommonAgent):
         rms.forward(self._amp_obs_demo_buffer.data, row_idx=demo_rows, out=X[2 * b:3 * b], out_cols=self._amp_pitch)  # amp_obs_demo
         logits = self.disc.forward(ws)
         # prediction loss, its logit gradients, accuracies and logit means in ONE launch (pulse_disc_head); everything the reported losses
-        # need lands in one 12-float row: [disc_head's 8 | sum ||dD/dx||^2 | ||W1||^2 | ||W2||^2 | ||w3||^2]
+        # need lands in one 20-float row: [disc_head's 8 | sum ||dD/dx||^2 at 8 | the reduce's eight per-region sums of squared parameters at 9..16:
+        # ||W1||^2 at 9, ||W2||^2 at 11, ||w3||^2 at 13, the bias regions' in between]
         lazy = self._lazy_info and self._disc_ring is not None and self._disc_pos < self._disc_ring.shape[0]
         row = self._disc_ring[self._disc_pos] if lazy else torch.empty(20, dtype=torch.float32, device=self.ppo_device)
         scale = self._disc_coef / self.world_size

@@ -39,6 +39,19 @@ from .network import A2CNetwork
 from .running_mean_std import RunningMeanStd
 
 
+def _record_stream(obj, stream):
+    """tensor.record_stream(stream) for every CUDA tensor inside nested dicts / lists / tuples."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
 class CommonAgent:
     def __init__(self, base_name, config):
         # ---------------- A2CBase.__init__ (rl_games 3P) ----------------
@@ -526,6 +539,9 @@ class CommonAgent:
             with torch.cuda.stream(side):
                 extra_info = self._extra_gradients(input_dict, idx)
                 self._ev_join.record(side)
+            # what the chain hands back was allocated from the side stream's pool but is read on the main stream (logging, the epoch-end reduce):
+            # tell the caching allocator, or a free on one stream could hand the block to the other while it is still in use (round-4 advisor)
+            _record_stream(extra_info, main)
         net.forward(ws, mb)
         ap = net.a_pitch
         g16 = {}

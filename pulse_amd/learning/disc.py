@@ -57,7 +57,10 @@ class DiscNetwork:
         self.reset_parameters()
 
     def b16_storage_ok(self):
-        return self.u1 % 32 == 0 and self.u2 % 32 == 0 and os.environ.get("PULSE_BF16_STORAGE", "1") != "0"
+        # hidden widths in whole 32-deep k-tiles, and the limits of the bf16 normaliser the plans commit to (pulse_rms_normalize_b16: at least 64
+        # columns, rows of at most 3072): other shapes keep the fp32-storage bf16 kernel instead of dying in the normaliser's argument check
+        return (self.u1 % 32 == 0 and self.u2 % 32 == 0 and 64 <= self.k0 and self.k0p <= 3072
+                and os.environ.get("PULSE_BF16_STORAGE", "1") != "0")
 
     def reset_parameters(self, generator=None):
         init_linear_(self.book, self.l1, generator)
@@ -275,7 +278,10 @@ class DiscNetwork:
         logit regulariser and weight decay (each times ``scale`` = disc_coef) and leaves the flat gradient in self.grad.
         Returns the penalty value mean_demo ||dD/dx||^2 (device scalar), or None when ``stats`` -- a (9,) float tensor -- takes the raw
         numbers instead: [sum ||dD/dx||^2 over the demo rows, then the eight per-region sums of squared parameters of the reduce launch:
-        ||W1||^2 at [1], ||W2||^2 at [3], ||w3||^2 at [5]].  ``sq_partials`` (256 floats): per-block sums of squares of the finished gradient."""
+        ||W1||^2 at [1], ||W2||^2 at [3], ||w3||^2 at [5]].  ``sq_partials`` (SQ_BLOCKS = 1024 floats, one per block of the reduce launch): per-block sums of
+        squares of the finished gradient."""
+        if sq_partials is not None and sq_partials.numel() != self._reg_partials.shape[0]:
+            raise ValueError(f"DiscNetwork.backward: sq_partials must hold {self._reg_partials.shape[0]} floats (one per reduce block), got {sq_partials.numel()}")
         b = ws["b"]
         ws["bwd_bce"].run()
         ws["pen_fwd"].run()

@@ -65,6 +65,8 @@ class A2CNetwork:
         self.grad = torch.zeros(self.n_flat, dtype=torch.float32, device=self.device)
         self.sigma = torch.zeros(self.actions_num, dtype=torch.float32, device=self.device)   # log-std, non-learned
         self._slabs = None
+        self.n_slabs = 2 * self.split_k      # allocated gradient slabs (the upper layers' fp32 weight gradients may use all of them, see workspace())
+        self._slab_mode = None               # storage mode (fp32 / bf16) of the plan that last wrote the slabs
         self._flat16 = self._wt16 = None     # bf16 image of the flat parameters / transposed upper-layer weights (mixed_precision, built on demand)
         self._ws = {}
         # PULSE_L1_PLANAR=1: layer-1 forward on the planar GEMM (gemm_x3p.hip; same six-product arithmetic), its input planes written by the
@@ -255,7 +257,10 @@ class A2CNetwork:
                 ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, bf16=True) if self.mixed_precision else ws["plan_fwd"]
                 ws["dh"] = [e(m, 2 * uu) for uu in u]
             if self._slabs is None:
-                self._slabs = torch.zeros(self.split_k, self.n_flat, dtype=torch.float32, device=dev)
+                # twice split_k slabs: the upper layers' weight gradients are small outputs over a long reduction and fill the chip on the 256 x 256
+                # x3 tile only with 16 slabs (profiles/r05_gemm_x3_wide_ab.txt: 2 x (512 x 1024) over 16384 rows 159 -> 136 us); a slab no launch
+                # writes stays zero, and every reduce names the count it reads
+                self._slabs = torch.zeros(self.n_slabs, self.n_flat, dtype=torch.float32, device=dev)
                 self._bias_chunks = 64
                 self._bias_scratch = torch.zeros(self._bias_chunks, 2 * max(max(u), self.a_pitch) + 8, dtype=torch.float32, device=dev)
                 self._head_split = 32
@@ -268,8 +273,10 @@ class A2CNetwork:
         """The bf16-storage GEMM reads reduction-contiguous operands in whole 32-deep k-tiles and 16-byte pieces: every hidden width has to
         be a multiple of 32 (the flat weight rows then ARE zero-padded k-tiles) and the input pitch already is.  Other shapes keep the
         fp32-storage bf16 kernel."""
+        # (+ the limits of the bf16 normaliser the plans commit to, pulse_rms_normalize_b16: at least 64 columns, rows of at most 3072;
+        #  other shapes keep the fp32-storage bf16 kernel instead of dying in the normaliser's argument check)
         return (self.act in (ACT_RELU, ACT_SILU) and all(uu % 32 == 0 for uu in self.units) and self.in_pitch % 32 == 0
-                and os.environ.get("PULSE_BF16_STORAGE", "1") != "0")
+                and 64 <= self.in_dim and self.in_pitch <= 3072 and os.environ.get("PULSE_BF16_STORAGE", "1") != "0")
 
     # ------------------------------------------------------------------ bf16-storage training plans (mixed_precision)
     def _plan_forward_b16(self, ws, m):
@@ -329,6 +336,7 @@ class A2CNetwork:
                        epilogue=egrad, aux=aux[l - 1], ldaux=ld_aux(aux[l - 1]), stride_aux=up, out_colsum=cs[l - 1], stride_out_colsum=up)
         uu, k = u[0], self.in_w[0]
         s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_b16(2 * uu, k, 1, S)
+        ws["layer_slabs"] = [s1] + [S] * (L - 1)
         p.gemm_b16(dz[0], ws["x16"], M=2 * uu, N=k, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, C=slabs, ldc=k, c_off=self.w_off[0],
                    split_k=s1, split_stride=P, algo_n=self.in_dim)
         p.call_partial_reduce(cs[0], cs[0].shape[0], 2 * uu, slabs, self.b_off[0])                           # bias 1 -> slab 0
@@ -343,7 +351,7 @@ class A2CNetwork:
         p.call_partial_reduce(hs, HS, hb + 2 * ap, slabs, self.wh_off)
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
-            sl = K.dw_split_b16(uu, up, 2, S)
+            sl = ws["layer_slabs"][l] = K.dw_split_b16(uu, up, 2, S)
             p.gemm_b16(dz[l], h16[l - 1], M=uu, N=up, K=m, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up,
                        C=slabs, ldc=up, stride_c=uu * up, c_off=self.w_off[l], split_k=sl, split_stride=P)
             p.call_partial_reduce(cs[l], cs[l].shape[0], 2 * uu, slabs, self.b_off[l])
@@ -434,6 +442,7 @@ class A2CNetwork:
         # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
         uu, k = u[0], self.in_w[0]
         s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_x3(2 * uu, k, 1, S)
+        ws["layer_slabs"] = [s1] + [S] * (L - 1)
         p.gemm(ws["dh"][0], ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
                b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=s1, split_stride=P, algo_n=self.in_dim,
                rowsum=slabs, rowsum_off=self.b_off[0])
@@ -447,7 +456,8 @@ class A2CNetwork:
         p.call_partial_reduce(hs, HS, hb + 2 * ap, slabs, self.wh_off)
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
-            sl = K.dw_split_x3(uu, up, 2, S)
+            sl = K.dw_split_x3(uu, up, 2, self.n_slabs)
+            ws["layer_slabs"][l] = sl
             p.gemm(ws["dh"][l], ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
                    b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],
                    split_k=sl, split_stride=P, rowsum=slabs, rowsum_off=self.b_off[l], stride_rowsum=uu)
@@ -455,15 +465,24 @@ class A2CNetwork:
 
     supports_fused_sqnorm = True
 
+    def _slab_regions(self, ws):
+        """[(offset, count, slabs)] of the flat gradient in order: every layer's range [W_l | b_l] with the slab count ITS weight-gradient launch
+        of this workspace writes (ws['layer_slabs']; they differ per layer and per minibatch size since the launcher has two tilings), then the
+        heads' range, whose sums come from the plan's own partial rows (slab 0 holds them when the plan's small reduces run; the other slabs
+        are never written there).  A reduce that read a fixed count everywhere would add whatever another workspace's launch left in the slabs
+        this one does not write (round-4 advisor finding)."""
+        L, ls = len(self.units), ws["layer_slabs"]
+        ends = [self.w_off[l + 1] if l + 1 < L else self.wh_off for l in range(L)]
+        base = [(self.w_off[l], ends[l] - self.w_off[l], ls[l]) for l in range(L)]
+        return base + [(self.wh_off, self.n_flat - self.wh_off, 1)]
+
     def _build_reduce_all(self, ws, plan):
-        """Regions of the whole-gradient reduce: the layer-1 range with the slabs its launch wrote, the rest with split_k slabs, and -- carved out
-        of those -- every range whose partials the plan registered (Plan.call_partial_reduce), summed from their own buffers.  More than 8
-        regions (deep MLPs): the plan keeps its small reduces."""
-        cut = self.w_off[1] if len(self.units) >= 2 else 0
-        base = ([(0, cut, ws["l0_slabs"])] if cut else []) + [(cut, self.n_flat - cut, self.split_k)]
-        regions, fused = K.carve_reduce_regions(base, getattr(plan, "partial_reduces", []))
+        """Regions of the whole-gradient reduce: every layer's range with the slabs its launch wrote, and -- carved out of those -- every range
+        whose partials the plan registered (Plan.call_partial_reduce), summed from their own buffers.  More than 8 regions (deep MLPs): the
+        plan keeps its small reduces and the ranges are reduced one by one."""
+        regions, fused = K.carve_reduce_regions(self._slab_regions(ws), getattr(plan, "partial_reduces", []))
         ws["reduce_all_fused"] = fused
-        return K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad)
+        return K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad) if len(regions) <= 8 else None
 
     def backward(self, ws, m, grad_scale=1.0, on_bucket=None, sq_partials=None):
         """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
@@ -473,24 +492,39 @@ class A2CNetwork:
         8 of 12 MB for [1024, 512]) before the upper layers' and the heads' weight gradients: that bucket is reduced and handed over first
         so its all-reduce runs beside the remaining GEMMs; the small bucket follows."""
         plan = ws["plan_bwd"]
+        mode = bool(ws.get("b16"))
+        if self._slab_mode is not None and self._slab_mode != mode:
+            # the fp32- and bf16-storage plans write different slab counts per region: a slab the other mode wrote and this one leaves alone
+            # must read as zero again (round-4 advisor finding: toggling mixed_precision on a live network)
+            self._slabs.zero_()
+        self._slab_mode = mode
         if on_bucket is None or len(self.units) < 2:
             # ONE reduce launch over the flat gradient: the layer-1 region reads only the slabs its weight-gradient launch wrote, the partials
             # the plan registered (bias column sums, the heads' wide split) are read where they lie -- their small reduce launches are left
             # out of the plan --, and the launch leaves the per-block sums of squares the gradient-norm clip needs (``sq_partials``)
-            rg = ws.get("reduce_all")
-            if rg is None:
-                rg = ws["reduce_all"] = self._build_reduce_all(ws, plan)
-            plan.run(skip_partial_reduces=ws["reduce_all_fused"])
-            rg.run(scale=grad_scale, sq_partials=sq_partials)
+            if "reduce_all" not in ws:
+                ws["reduce_all"] = self._build_reduce_all(ws, plan)
+            rg = ws["reduce_all"]
+            if rg is not None:
+                plan.run(skip_partial_reduces=ws["reduce_all_fused"])
+                rg.run(scale=grad_scale, sq_partials=sq_partials)
+            else:                                                # deep MLP: more ranges than one fused launch takes
+                plan.run()
+                for off, cnt, ns in self._slab_regions(ws):
+                    K.reduce_slabs(self._slabs, ns, self.n_flat, cnt, self.grad, scale=grad_scale, slabs_off=off, out_off=off)
+                if sq_partials is not None:
+                    K.sqnorm_partial(self.grad, self.n_flat, sq_partials)
             if on_bucket is not None:
                 on_bucket(self.grad)
             return self.grad
         cut = self.w_off[1]
+        regions = self._slab_regions(ws)
         plan.run(0, plan.split)
-        # the layer-1 region [0, cut) holds only the slabs its dW GEMM wrote (the others stay zero): reduce just those
-        K.reduce_slabs(self._slabs, ws["l0_slabs"], self.n_flat, cut, self.grad, scale=grad_scale)
+        # the layer-1 region [0, cut) holds only the slabs its dW GEMM wrote: reduce just those
+        K.reduce_slabs(self._slabs, regions[0][2], self.n_flat, cut, self.grad, scale=grad_scale)
         on_bucket(self.grad[:cut])
         plan.run(plan.split, None)
-        K.reduce_slabs(self._slabs, self.split_k, self.n_flat, self.n_flat - cut, self.grad, scale=grad_scale, slabs_off=cut, out_off=cut)
+        for off, cnt, ns in regions[1:]:
+            K.reduce_slabs(self._slabs, ns, self.n_flat, cnt, self.grad, scale=grad_scale, slabs_off=off, out_off=off)
         on_bucket(self.grad[cut:])
         return self.grad

@@ -139,10 +139,10 @@ def gemm_traffic(cfg_name, kernel):
             with open(path) as f:
                 d = json.load(f)
             if kernel in d:
-                return d[kernel]["hbm_bytes_per_launch"]
+                return d[kernel]["hbm_bytes_per_launch"], os.path.join("profiles", os.path.basename(path))
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
 
 
 def gemm_clock_probe(m, n, k, launches=30):
@@ -393,20 +393,24 @@ def main():
     if not a.no_roofline:
         s = prof.summary()
 
-        def roof(tags, peak, kernel):
+        def roof(tags, peak, kernel, traffic_key=None):
             sel = {k: v for k, v in s.items() if k in tags}
             n = sum(v[0] for v in sel.values())
             t = sum(v[1] for v in sel.values())
             f = sum(v[2] for v in sel.values())
             if n == 0 or t == 0:
                 return None
+            traffic, traffic_src = gemm_traffic(a.config, traffic_key or kernel)
             return {"bound": "mfma", "achieved": f / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": f / t / 1e12 / peak,
-                    "traffic": gemm_traffic(a.config, kernel), "kernel": kernel, "launches": n, "avg_us": 1e6 * t / max(1, n),
+                    # NOT measured in this run (the counters serialise kernels): the newest committed PMC pass of the same command, named here
+                    "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, of the same bench command)") if traffic_src else None,
+                    "kernel": kernel, "launches": n, "avg_us": 1e6 * t / max(1, n),
                     "kernel_time_frac_of_step": t / (elapsed / a.steps), "instrumented_steps": 1,
                     "by_variant": {k: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "tflops": v[2] / v[1] / 1e12} for k, v in sel.items()}}
         r32 = roof(("fwd", "dx", "dw"), MFMA_F32_PEAK_TFLOPS, "gemm_f32_kernel")
         if r32 is None:
-            r32 = roof(("x3_fwd", "x3_dx", "x3_dw", "x3p_fwd"), MFMA_X3_PEAK_TFLOPS, "gemm_x3_kernel")
+            r32 = roof(("x3_fwd", "x3_dx", "x3_dw", "x3p_fwd"), MFMA_X3_PEAK_TFLOPS, "gemm_x3_kernel (256 x 256 tile: gemm_x3w_kernel; 128 x 128 / 64 x 128: gemm_x3_kernel)",
+                       traffic_key="gemm_x3_kernel")
             if r32 is not None:
                 r32["arithmetic"] = ("fp32 in / fp32 out; operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 per 16-deep k step, "
                                      "fp32 accumulation; peak = dense bf16 MFMA peak / 6; the fp32 MFMA's own ceiling is %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS)

@@ -16,6 +16,10 @@ from pulse_amd._lib import ACT_RELU, EPI_RELU_GRAD, GEMM_OUT_CONTIG
 
 pytestmark = pytest.mark.gpu
 
+# floor of the first-step bound, relative to the quantity: 2 x the largest first-step |device - oracle16| / scale observed on MI355X over the six
+# reported quantities (printed by the tests; round-4 verdict, weak #8: the old 4e-3 floor told little)
+BF16_FLOOR = 1e-4          # (grad_norm 1.9e-5 here, 4.1e-5 at cfg5 full size: profiles/r05_bf16_parity_errors.txt; was 4e-3)
+
 
 def bf(x):
     return x.bfloat16().double()
@@ -114,7 +118,9 @@ def test_amp_agent_bf16_epoch_vs_autocast_oracle(dev):
         err = np.abs(dev_v - a16)                                 # device bf16 vs CPU bf16 autocast
         scale = np.abs(a16) + 1e-6
         # first step: same weights on both sides -- the device must sit within the bf16 rounding noise of the autocast oracle
-        assert err[0] <= max(2.0 * gap[0], 4e-3 * scale[0]), (key, err[0], gap[0], scale[0])
+        print(f"[bf16 parity, 64-env agent] {key}: first step |device - oracle16| / scale = {err[0] / scale[0]:.2e}, |oracle16 - oracle32| / scale = "
+              f"{gap[0] / scale[0]:.2e}; epoch max {float((err / scale).max()):.2e} (gap {float((gap / scale).max()):.2e})")
+        assert err[0] <= max(2.0 * gap[0], BF16_FLOOR * scale[0]), (key, err[0], gap[0], scale[0])
         # whole epoch (weights drift through 24 Adam steps): stay within a few percent of the autocast oracle
         assert (err <= np.maximum(4.0 * gap, 3e-2 * scale)).all(), (key, float((err / scale).max()))
     # bf16 really was used: the device differs from the fp32 oracle where bf16 matters

@@ -23,6 +23,9 @@ from pulse_amd import configs
 
 pytestmark = pytest.mark.gpu
 
+BF16_FLOOR = 1e-4     # relative floor of the bf16 first-step bound: 2 x the largest |device - oracle16| / scale observed where the floor binds
+                      # (grad_norm 4.1e-5 at cfg5 full size, MI355X, profiles/r05_bf16_parity_errors.txt; the old 4e-3 told little)
+
 
 def _rel(a, b):
     return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
@@ -189,4 +192,5 @@ def test_cfg5_full_size_first_minibatch_bf16(dev):
         a16, a32, d = float(o16[key]), float(o32[key]), float(res[key])
         gap, err, scale = abs(a16 - a32), abs(d - a16), abs(a16) + 1e-6
         # same weights on both sides: the device must sit within the bf16 rounding noise of the autocast oracle
-        assert err <= max(2.0 * gap, 4e-3 * scale), (key, d, a16, a32)
+        print(f"[bf16 parity, cfg5 full size] {key}: |device - oracle16| / scale = {err / scale:.2e}, |oracle16 - oracle32| / scale = {gap / scale:.2e}")
+        assert err <= max(2.0 * gap, BF16_FLOOR * scale), (key, d, a16, a32)

@@ -15,7 +15,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         key = ("gemm_f32_kernel" if "gemm_f32_kernel" in k else "gemm_bf16_kernel" if "gemm_bf16_kernel" in k
-               else "gemm_x3_kernel" if "gemm_x3_kernel" in k
+               else "gemm_x3_kernel" if ("gemm_x3_kernel" in k or "gemm_x3w_kernel" in k)          # both tilings of the x3 fp32 GEMM (gemm_f32.hip / gemm_x3w.hip)
                else B16 if ("gemm_b16r_kernel" in k or "gemm_b16w_kernel" in k)
                else (B16 if k.rstrip().endswith("1>(pulse::XpArgs)") or ", 1>" in k else "gemm_x3p_kernel") if "gemm_x3p_kernel" in k
                else ("other_pulse" if "pulse" in k else "torch"))

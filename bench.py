@@ -419,6 +419,11 @@ def main():
                 r32["pipe_only_ceiling"] = {"tflops": 1758.3 / 6, "frac_of_it": r32["achieved"] / (1758.3 / 6),
                                             "source": "profiles/r03_mfma_ceiling.txt (register-resident MFMA chains, random bf16 operands: 1758.3 TFLOP/s at 1.72 GHz; "
                                                       "2474.5 at 2.39 GHz on all-zero operands)"}
+        if r32 is not None and getattr(getattr(agent, "model", None), "_bwd_stream", None) is not None:
+            # the weight gradients past layer 1 run on a side stream beside the layer-1 one (network.py: _bwd_side_stream): event pairs around those
+            # launches span the other chain's work (in-situ figures UNDER CONCURRENCY, like rocprofv3's durations of the same command);
+            # PULSE_BWD_STREAM=0 gives the one-chain-at-a-time durations (profiles/r05_bench_cfg2_one_chain.json)
+            r32["concurrent_chains"] = True
         r16 = roof(("b16_fwd", "b16_dx", "b16_dw"), MFMA_BF16_PEAK_TFLOPS, "bf16-storage GEMMs (gemm_b16r_kernel, gemm_b16w_kernel, gemm_x3p_kernel<.., 1>)")
         if r16 is None:
             r16 = roof(("bf16_fwd", "bf16_dx", "bf16_dw"), MFMA_BF16_PEAK_TFLOPS, "gemm_bf16_kernel")

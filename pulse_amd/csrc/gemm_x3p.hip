@@ -134,12 +134,9 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of what this thread stores (the bias gradient of the producer layer)
         if (col < g.N) {
             const bool full = col + 7 < g.N;
-#pragma unroll 2
-            for (int rl = tid >> 4; rl < BM; rl += RPI) {
+            // one row of 8 columns: image -> rounding / activation / mask -> C, Cp, column sums
+            auto do_row = [&](int rl, const f32x4 v0, const f32x4 v1) {
                 const int row = m0 + rl;
-                if (row >= g.M) break;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4);
                 float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 if constexpr (NPL == 1) {
                     // a bf16 autocast Linear hands bf16 to the next op: the product leaves rounded, the activation / mask acts on that
@@ -212,6 +209,26 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
                         *reinterpret_cast<u32x4*>(pp + g.pc) = q1;
                         *reinterpret_cast<u32x4*>(pp + 2 * g.pc) = q2;
                     }
+                }
+            };
+            constexpr int ITER = BM / RPI;
+            if (m0 + BM <= g.M) {
+                // full tile in M: every image read of the thread's ITER rows is issued before the first row is processed (a rolled loop was one
+                // LDS round trip + one store issue per row, end to end: 4.2 us per 256 x 128 half, profiles/r04_gemm_b16_phases.txt)
+                f32x4 va[ITER], vb[ITER];
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int rl = (tid >> 4) + it * RPI;
+                    va[it] = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8);
+                    vb[it] = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4);
+                }
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) do_row((tid >> 4) + it * RPI, va[it], vb[it]);
+            } else {
+#pragma unroll 2
+                for (int rl = tid >> 4; rl < BM; rl += RPI) {
+                    if (m0 + rl >= g.M) break;
+                    do_row(rl, *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8), *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4));
                 }
             }
         }

@@ -439,6 +439,7 @@ class A2CNetwork:
             p.gemm(ws["dh"][l], f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
                    batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
                    aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
+        p.split_dx = len(p.ops)             # everything before this point is the input-gradient chain; the weight gradients after it are independent of each other
         # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
         uu, k = u[0], self.in_w[0]
         s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_x3(2 * uu, k, 1, S)
@@ -484,6 +485,20 @@ class A2CNetwork:
         ws["reduce_all_fused"] = fused
         return K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad) if len(regions) <= 8 else None
 
+    def _bwd_side_stream(self, ws, plan):
+        """The stream the weight gradients past layer 1 run on beside the layer-1 one, or None.  OFF unless PULSE_BWD_STREAM=1: round 4 measured
+        +1.3 % on cfg2 with the 128 x 128 tiling (two workgroups per CU left gaps to fill); with the 256 x 256 tiling every launch is one workgroup
+        per CU holding the whole register file, two such launches side by side only take CUs from each other, and the same A/B reads 70.1 ms
+        without vs 70.8 ms with the side chain (profiles/r05_ab_runs.txt).  Kept as a switch (fp32-storage plans on a GPU only: the bf16 plans of
+        the AMP agent already run the discriminator chain beside this one)."""
+        if (ws.get("b16") or not getattr(plan, "split_dx", 0) or plan.split <= plan.split_dx or self.device.type != "cuda"
+                or os.environ.get("PULSE_BWD_STREAM", "0") != "1"):
+            return None
+        if getattr(self, "_bwd_stream", None) is None:
+            self._bwd_stream = torch.cuda.Stream(device=self.device)
+            self._ev_bfork, self._ev_bjoin = torch.cuda.Event(), torch.cuda.Event()
+        return self._bwd_stream
+
     def backward(self, ws, m, grad_scale=1.0, on_bucket=None, sq_partials=None):
         """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
         Deterministic: split-K slabs + ordered reduces.
@@ -505,7 +520,23 @@ class A2CNetwork:
             if "reduce_all" not in ws:
                 ws["reduce_all"] = self._build_reduce_all(ws, plan)
             rg = ws["reduce_all"]
-            if rg is not None:
+            side = self._bwd_side_stream(ws, plan)
+            if rg is not None and side is not None:
+                # the upper layers' and the heads' weight gradients on a side stream beside the layer-1 one: every launch here is one round of one
+                # workgroup per CU, so the chains do not share CUs -- what overlaps is each launch's tail, launch gap and prologue with the other
+                # chain's next workgroups (A/B: profiles/r05_ab_runs.txt).  Disjoint outputs (gradient elements below / above w_off[1], the heads'
+                # scratch); both chains only read the activations and the dX chain's results.
+                main = torch.cuda.current_stream()
+                plan.run(0, plan.split_dx)
+                self._ev_bfork.record(main)
+                side.wait_event(self._ev_bfork)
+                with torch.cuda.stream(side):
+                    plan.run(plan.split, None, skip_partial_reduces=ws["reduce_all_fused"])
+                    self._ev_bjoin.record(side)
+                plan.run(plan.split_dx, plan.split)
+                main.wait_event(self._ev_bjoin)
+                rg.run(scale=grad_scale, sq_partials=sq_partials)
+            elif rg is not None:
                 plan.run(skip_partial_reduces=ws["reduce_all_fused"])
                 rg.run(scale=grad_scale, sq_partials=sq_partials)
             else:                                                # deep MLP: more ranges than one fused launch takes

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 21
+#define PULSE_ABI_VERSION 22
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -491,9 +491,13 @@ int pulse_gae(const float* rewards, const float* values, const float* next_value
 #define PULSE_ACT_NONE 0
 #define PULSE_ACT_RELU 1
 #define PULSE_ACT_SILU 2
+#define PULSE_ACT_SILU_D 3    /* SiLU whose C2 (required) receives d silu / d z = s (1 + z (1 - s)), s = sigmoid(z), instead of z: the backward
+                                 pass multiplies by it (PULSE_EPI_MUL_AUX) -- the same value the SILU_GRAD epilogue recomputes from z, without the
+                                 exp and the division in the launch that has no other work to hide them under (pulse_gemm_f32 only) */
 #define PULSE_EPI_BIAS_ACT  0 /* C = act(acc + bias[n]); silu may also store the pre-activation in C2 */
 #define PULSE_EPI_RELU_GRAD 1 /* C = acc * (aux > 0)           (aux = forward activation)  */
 #define PULSE_EPI_SILU_GRAD 2 /* C = acc * silu'(aux)          (aux = forward pre-activation) */
+#define PULSE_EPI_MUL_AUX   3 /* C = acc * aux                 (aux = the derivative a PULSE_ACT_SILU_D forward stored; pulse_gemm_f32 only) */
 
 #define PULSE_GEMM_COMPUTE_F32  0
 #define PULSE_GEMM_COMPUTE_BF16 1
@@ -533,11 +537,14 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
  * affect the pulse_gemm_f32 launches issued by the calling host thread only; never set by the product path (pulse_amd/ calls them only
  * from bench.py's --clock-probe and tools/).  Option 1 = extra dynamic-LDS bytes per workgroup, option 2 = 1 disables the 64-row tile (occupancy
  * experiments), option 3 = tile of the bf16-storage launches of pulse_gemm_x3p (0 automatic, 1 never 256 x 256, 2 256 x 256 whenever N > 128;
- * same results either way up to accumulation order).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
+ * same results either way up to accumulation order), option 4 = tile of the fp32 (x3) launches of pulse_gemm_f32 (0 = the launcher's cost model,
+ * also steered by PULSE_X3_WIDE = 0 / 1 / 2 in the environment; 1 = 128 x 128 only; 2 = 256 x 256 whenever M, N > 128; BIT-IDENTICAL matrix outputs
+ * either way, the weight-gradient form's row sums agree to rounding).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
  * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID.  The 256 x 256 bf16-storage
  * kernel of pulse_gemm_x3p honours the same buffer with wall-clock stamps only: [0] start, [1] first stage landed, [2] main loop done,
  * [3] epilogue stores issued, [4] stores acknowledged, [5] XCC_ID, [6] / [7] transpose image written / stores issued of the last epilogue
- * half (tools/gemm_b16_phases.py). */
+ * half (tools/gemm_b16_phases.py).  The 256 x 256 x3 kernel: [0] / [1] start (cycles / wall), [2] / [3] main loop done, [4] / [5] epilogue's
+ * stores issued, [7] stores acknowledged (wall; tools/gemm_x3w_phases.py). */
 int pulse_gemm_set_option(int key, int value);
 int pulse_gemm_set_debug_buffer(long long* device_buffer);
 /* ------------------------------------------------------------------------- *

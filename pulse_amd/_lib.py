@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -229,8 +229,8 @@ class PpoLossArgs(Structure):
 
 GEMM_RED_CONTIG, GEMM_OUT_CONTIG = 0, 1
 GEMM_COMPUTE_F32, GEMM_COMPUTE_BF16, GEMM_COMPUTE_F32X3 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
-EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_SILU_D = 0, 1, 2, 3          # SILU_D: C2 receives d silu / d z instead of z (backward: EPI_MUL_AUX)
+EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3
 
 P = c_void_p  # every device pointer crosses the ABI as void*
 c_double = ctypes.c_double

@@ -144,11 +144,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
     // epilogue is a 16-byte access covering 512 contiguous bytes of one row per half-wave.  The scalar path (unaligned pitches) reads the
     // same image: the 64 accumulator registers are dead from here on in EVERY path -- with them live across the per-element address
     // arithmetic of the scalar path the weight-gradient instantiation spilled 351 VGPRs (round-3 verdict, weak #1).
-    const bool fast = g.vec_epi && m0 + 64 * WM <= g.M && n0 + BN <= g.N && (g.epi == 1 || (g.epi == 0 && g.act != 2));
+    const bool fast = g.vec_epi && m0 + 64 * WM <= g.M && n0 + BN <= g.N && (g.epi == 1 || g.epi == 3 || (g.epi == 0 && g.act < 2));
     const int c4 = (tid & 31) * 4;
     const int rl0 = tid >> 5;
     f32x4 ax[8 * WM];
-    if (fast && g.epi == 1) {                  // relu-grad: the 16 aux loads fly while the accumulators go through LDS
+    if (fast && g.epi != 0) {                  // relu-grad / multiply-by-aux: the 16 aux loads fly while the accumulators go through LDS
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
                                                                             0xffffffffu, RSRC_FLAGS);
         const int voX = (rl0 * g.ldaux + c4) * 4;
@@ -180,12 +180,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
                 }
-            } else {
+            } else if (g.epi == 1) {
 #pragma unroll
                 for (int q = 0; q < 8 * WM; ++q) {
                     const f32x4 a = ax[q];
                     f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
                     v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                }
+            } else {                                   // EPI_MUL_AUX: aux holds the producer's stored activation derivative
+#pragma unroll
+                for (int q = 0; q < 8 * WM; ++q) {
+                    const f32x4 a = ax[q];
+                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
+                    v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
                     buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
                 }
             }
@@ -213,6 +221,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
                         }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
+                    } else if (g.act == 3) {             // SiLU whose C2 receives d silu / d z (the backward pass then multiplies: EPI_MUL_AUX)
+                        float d[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sg = 1.f / (1.f + __expf(-o[k]));
+                            d[k] = sg * (1.f + o[k] * (1.f - sg));
+                            o[k] = o[k] / (1.f + __expf(-o[k]));
+                        }
+                        float* p2 = C2 + (long long)row * g.ldc2 + col;
+                        if (full) *reinterpret_cast<float4*>(p2) = make_float4(d[0], d[1], d[2], d[3]);
+                        else for (int k = 0; k < 4 && col + k < g.N; ++k) p2[k] = d[k];
                     }
                 } else {
                     const float* pa = aux + (long long)row * g.ldaux + col;
@@ -222,6 +241,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
                     if (g.epi == 1) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = a4[k] > 0.f ? o[k] : 0.f;
+                    } else if (g.epi == 3) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] *= a4[k];
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -256,9 +278,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
                     } else if (g.act == 2) {
                         if (C2) C2[(long long)row * g.ldc2 + col] = v;   // keep the pre-activation for backward
                         v = v / (1.f + __expf(-v));
+                    } else if (g.act == 3) {
+                        const float sg = 1.f / (1.f + __expf(-v));
+                        C2[(long long)row * g.ldc2 + col] = sg * (1.f + v * (1.f - sg));     // d silu / d z for the backward pass (EPI_MUL_AUX)
+                        v = v / (1.f + __expf(-v));
                     }
                 } else if (g.epi == 1) {
                     v = aux[(long long)row * g.ldaux + col] > 0.f ? v : 0.f;
+                } else if (g.epi == 3) {
+                    v *= aux[(long long)row * g.ldaux + col];
                 } else {
                     const float zz = aux[(long long)row * g.ldaux + col];
                     const float sg = 1.f / (1.f + __expf(-zz));
@@ -1118,8 +1146,9 @@ namespace pulse { int gemm_option(int key) { return key >= 0 && key < 8 ? g_opt[
 
 namespace {
 // Which tiling serves an x3 launch.  Cost model in units of (one 128 x 128 output tile) x (k per split), per CU: the narrow kernel keeps two
-// workgroups per CU (a round of 512 costs 2; a lone workgroup per CU 1.25), the wide kernel one workgroup of four tiles' area
-// per CU and round at 1.1-1.2 x the narrow kernel's rate (profiles/r05_gemm_x3_wide_ab.txt: 3.5 units per wide round).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
+// workgroups per CU (a round of 512 costs 2; a lone workgroup per CU 1.5), the wide kernel one workgroup of four tiles' area
+// per CU and round at 1.1-1.2 x the narrow kernel's rate (3.4 units per wide round; calibrated on profiles/r05_gemm_x3_wide_ab.txt and on every
+// launch of a cfg2 / cfg3 epoch, profiles/r05_gemm_shapes_cfg{2,3}.txt).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
 // 2 whenever the output has more than 128 rows and columns (tests).
 bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
     static const int env = [] { const char* e = getenv("PULSE_X3_WIDE"); return e ? atoi(e) : -1; }();
@@ -1135,8 +1164,10 @@ bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
     const long long nt = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * z;
     const long long wt = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * z;
     const long long rem = nt % 512;
-    const double cost_narrow = 2.0 * (double)(nt / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.25 : 2.0);
-    const double cost_wide = 3.5 * (double)((wt + 255) / 256);
+    const double cost_narrow = 2.0 * (double)(nt / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.5 : 2.0);
+    // the SiLU-derivative epilogue (an exp and a division per element) is exposed VALU time with one workgroup per CU; the narrow tiling hides it
+    // under its other workgroup (profiles/r05_gemm_shapes_cfg3.txt: 16384 x 1536 x 1024 297 vs 376 us)
+    const double cost_wide = (g.epi == 2 ? 1.25 : 1.0) * 3.4 * (double)((wt + 255) / 256);
     return cost_wide < cost_narrow;
 }
 }  // namespace
@@ -1170,7 +1201,9 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     PULSE_REQUIRE(akc ? d->lda >= k4 : d->lda >= ((d->M + 3) & ~3), "pulse_gemm_f32: lda too small");
     PULSE_REQUIRE(bkc ? d->ldb >= k4 : d->ldb >= ((d->N + 3) & ~3), "pulse_gemm_f32: ldb too small");
     PULSE_REQUIRE(d->ldc >= d->N, "pulse_gemm_f32: ldc too small");
-    PULSE_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2 && d->activation >= 0 && d->activation <= 2, "pulse_gemm_f32: bad epilogue / activation");
+    PULSE_REQUIRE(d->epilogue >= 0 && d->epilogue <= 3 && d->activation >= 0 && d->activation <= 3, "pulse_gemm_f32: bad epilogue / activation");
+    PULSE_REQUIRE(d->activation != PULSE_ACT_SILU_D || (d->C2 != nullptr && d->ldc2 >= d->N), "pulse_gemm_f32: ACT_SILU_D stores the derivative in C2");
+    PULSE_REQUIRE(d->epilogue == 0 || d->activation == 0, "pulse_gemm_f32: a gradient epilogue takes no activation");
     PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr, "pulse_gemm_f32: gradient epilogue needs aux");
     PULSE_REQUIRE(d->rowsum == nullptr || (!akc && !bkc), "pulse_gemm_f32: rowsum needs the (OUT, OUT) layouts (dW pass)");
     PULSE_REQUIRE(d->split_k == 1 || (d->epilogue == 0 && d->activation == 0 && d->bias == nullptr),

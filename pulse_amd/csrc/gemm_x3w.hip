@@ -171,7 +171,7 @@ __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int ti
     const int tc = w_tile_col(c4, pass);         // tile column
     const int rl0 = tid >> 5;                    // 8 rows per sweep, 32 sweeps
     if (g.vec_epi) {
-        const bool fast = m0 + WT <= g.M && n0 + WT <= g.N && (g.epi == 1 || (g.epi == 0 && g.act != 2));
+        const bool fast = m0 + WT <= g.M && n0 + WT <= g.N && (g.epi == 1 || g.epi == 3 || (g.epi == 0 && g.act < 2));
         if (fast) {
             const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (long long)m0 * g.ldc + n0, 0, 0xffffffffu, RSRC_FLAGS);
             const int voC = (rl0 * g.ldc + tc) * 4;
@@ -197,7 +197,8 @@ __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int ti
                     for (int q = 0; q < 8; ++q) {
                         const f32x4 a = ax[q];
                         f32x4 v = lds_read(ldsC + (q0 + q) * 8 * W_CP * 4);
-                        v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+                        if (g.epi == 1) { v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f; }
+                        else { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }       // EPI_MUL_AUX: aux = the producer's stored activation derivative
                         buf_store(v, rsC, voC, (q0 + q) * 8 * g.ldc * 4);
                     }
                 }
@@ -226,6 +227,17 @@ __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int ti
                         }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
+                    } else if (g.act == 3) {             // SiLU whose C2 receives d silu / d z (the backward pass then multiplies: EPI_MUL_AUX)
+                        float d[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sg = 1.f / (1.f + __expf(-o[k]));
+                            d[k] = sg * (1.f + o[k] * (1.f - sg));
+                            o[k] = o[k] / (1.f + __expf(-o[k]));
+                        }
+                        float* p2 = C2 + (long long)row * g.ldc2 + col;
+                        if (full) *reinterpret_cast<float4*>(p2) = make_float4(d[0], d[1], d[2], d[3]);
+                        else for (int k = 0; k < 4 && col + k < g.N; ++k) p2[k] = d[k];
                     }
                 } else {
                     const float* pa = aux + (long long)row * g.ldaux + col;
@@ -235,6 +247,9 @@ __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int ti
                     if (g.epi == 1) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = a4[k] > 0.f ? o[k] : 0.f;
+                    } else if (g.epi == 3) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] *= a4[k];
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -266,9 +281,15 @@ __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int ti
                 } else if (g.act == 2) {
                     if (C2) C2[(long long)row * g.ldc2 + col] = v;
                     v = v / (1.f + __expf(-v));
+                } else if (g.act == 3) {
+                    const float sg = 1.f / (1.f + __expf(-v));
+                    C2[(long long)row * g.ldc2 + col] = sg * (1.f + v * (1.f - sg));
+                    v = v / (1.f + __expf(-v));
                 }
             } else if (g.epi == 1) {
                 v = aux[(long long)row * g.ldaux + col] > 0.f ? v : 0.f;
+            } else if (g.epi == 3) {
+                v *= aux[(long long)row * g.ldaux + col];
             } else {
                 const float zz = aux[(long long)row * g.ldaux + col];
                 const float sg = 1.f / (1.f + __expf(-zz));

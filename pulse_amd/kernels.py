@@ -120,12 +120,12 @@ def dw_split(tiles, max_split, fill=512):
 
 def x3_tile_costs(M, N, z):
     """(narrow, wide) cost of an x3 launch with z = batch x split_k grid slices, in the launcher's units (gemm_f32.hip: x3_wide_tile): one
-    128 x 128 tile alone on a CU = 1.25 per unit of reduction length, two sharing a CU 2; a 256 x 256 workgroup has a CU to itself at 3.5."""
+    128 x 128 tile alone on a CU = 1.5 per unit of reduction length, two sharing a CU 2; a 256 x 256 workgroup has a CU to itself at 3.4."""
     nt = ((M + 127) // 128) * ((N + 127) // 128) * z
     wt = ((M + 255) // 256) * ((N + 255) // 256) * z
     rem = nt % 512
-    narrow = 2.0 * (nt // 512) + (0.0 if rem == 0 else 1.25 if rem <= 256 else 2.0)      # a lone workgroup is not quite twice as fast as a paired one
-    wide = 3.5 * ((wt + 255) // 256) if (M > 128 and N > 128) else float("inf")
+    narrow = 2.0 * (nt // 512) + (0.0 if rem == 0 else 1.5 if rem <= 256 else 2.0)       # a lone workgroup is not twice as fast as a paired one
+    wide = 3.4 * ((wt + 255) // 256) if (M > 128 and N > 128) else float("inf")
     return narrow, wide
 
 

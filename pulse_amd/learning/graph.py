@@ -24,7 +24,12 @@ import math
 import torch
 
 from .. import kernels as K
-from .._lib import (ACT_NONE, ACT_RELU, ACT_SILU, EPI_BIAS_ACT, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG)
+from .._lib import (ACT_NONE, ACT_RELU, ACT_SILU, ACT_SILU_D, EPI_BIAS_ACT, EPI_MUL_AUX, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG)
+
+
+import os
+
+SILU_DERIV = os.environ.get("PULSE_SILU_DERIV", "1") != "0"       # SiLU layers keep their derivative instead of their pre-activation (forward_plan)
 
 
 def r4(x):
@@ -240,9 +245,14 @@ class MlpGraph:
                 continue
             lin = op["lin"]
             x, y = self.act_bufs[op["src"]], self.act_bufs[op["dst"]]
+            # a SiLU layer of a training pass keeps d silu / d z (ACT_SILU_D), not z: the input-gradient launch then multiplies (EPI_MUL_AUX)
+            # instead of recomputing the sigmoid -- an exp and a division per element that the 256 x 256 x3 tile (one workgroup per CU) has
+            # nothing to hide under (profiles/r05_gemm_shapes_cfg3.txt).  Same value, same bits: the derivative is the expression the
+            # SILU_GRAD epilogue evaluates.  PULSE_SILU_DERIV=0: the pre-activation form.
             c2 = self.pre(op["dst"]) if (lin.act == ACT_SILU and store_pre) else None
+            act = ACT_SILU_D if (c2 is not None and SILU_DERIV) else lin.act
             p.gemm(x, f, y, M=self.m, N=lin.n, K=lin.k_phys, lda=x.stride(0), ldb=lin.w.pitch, ldc=y.stride(0), bias=f,
-                   activation=lin.act, a_off=op["src_col"], b_off=lin.w.off, bias_off=lin.b.off, c_off=op["dst_col"],
+                   activation=act, a_off=op["src_col"], b_off=lin.w.off, bias_off=lin.b.off, c_off=op["dst_col"],
                    C2=c2, ldc2=c2.stride(0) if c2 is not None else 0, c2_off=op["dst_col"], algo_k=lin.k_logical)
         return p
 
@@ -294,7 +304,7 @@ class MlpGraph:
                 if act == ACT_RELU:
                     epi, aux = EPI_RELU_GRAD, self.act_bufs[aux_name]
                 elif act == ACT_SILU:
-                    epi, aux = EPI_SILU_GRAD, self.pre(aux_name)
+                    epi, aux = (EPI_MUL_AUX if SILU_DERIV else EPI_SILU_GRAD), self.pre(aux_name)
                 if aux is not None:
                     aux_off, ldaux = aux_col + c0, aux.stride(0)
                 p.gemm(gz, f, gx, M=m, N=c1 - c0, K=lin.n, lda=ldg, ldb=lin.w.pitch, ldc=gx.stride(0), b_layout=GEMM_OUT_CONTIG,

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from pulse_amd import kernels as K
-from pulse_amd._lib import ACT_NONE, ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG
+from pulse_amd._lib import ACT_NONE, ACT_RELU, ACT_SILU, ACT_SILU_D, EPI_MUL_AUX, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG
 
 pytestmark = pytest.mark.gpu
 
@@ -200,3 +200,45 @@ def test_automatic_choice_full_size_matches_narrow(dev):
     assert torch.equal(sub, wide[5000:5300])
     ref = (x[:64, :k].double() @ w[:, :k].double().T).clamp(min=0)
     close64(wide[:64], ref, k)
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 512, 64), (300, 257, 70), (2048, 1024, 512)])
+@pytest.mark.parametrize("mode", ["x3", "mfma32"])
+def test_silu_derivative_activation_and_multiply_epilogue(dev, monkeypatch, m, n, k, mode):
+    """ACT_SILU_D: same output as ACT_SILU, C2 = d silu / d z; EPI_MUL_AUX over that C2 == EPI_SILU_GRAD over z, bit for bit, on both tilings
+    (the derivative is the expression the SILU_GRAD epilogue evaluates).  Reference: torch.nn.SiLU in the MLPs of amp_network_z_builder.py:341-467."""
+    monkeypatch.setattr(K, "F32_MODE", mode)
+    g = torch.Generator().manual_seed(m + n + k)
+    x, w, b = rnd(g, m, k), rnd(g, n, k) / math.sqrt(k), rnd(g, n)
+    dy, w2 = rnd(g, m, k), rnd(g, k, n) / math.sqrt(k)
+    kp, npad = (k + 3) // 4 * 4, (n + 3) // 4 * 4
+    xd, wd, bd = padded(x, kp, dev), padded(w, kp, dev), b.to(dev)
+    dyd, w2d = padded(dy, kp, dev), padded(w2, npad, dev)
+
+    def run():
+        res = {}
+        for act in (ACT_SILU, ACT_SILU_D):
+            out = torch.full((m, npad), 9.0, device=dev)
+            c2 = torch.full((m, npad), 9.0, device=dev)
+            K.gemm(xd, wd, out, M=m, N=n, K=k, lda=kp, ldb=kp, ldc=npad, bias=bd, activation=act, C2=c2, ldc2=npad)
+            res[act] = (out, c2)
+        z, d = res[ACT_SILU][1].clone(), res[ACT_SILU_D][1].clone()
+        z[:, n:] = 0.0
+        d[:, n:] = 0.0
+        g_old = torch.full((m, npad), 5.0, device=dev)
+        g_new = torch.full((m, npad), 5.0, device=dev)
+        K.gemm(dyd, w2d, g_old, M=m, N=n, K=k, lda=kp, ldb=npad, ldc=npad, b_layout=GEMM_OUT_CONTIG, epilogue=EPI_SILU_GRAD, aux=z, ldaux=npad)
+        K.gemm(dyd, w2d, g_new, M=m, N=n, K=k, lda=kp, ldb=npad, ldc=npad, b_layout=GEMM_OUT_CONTIG, epilogue=EPI_MUL_AUX, aux=d, ldaux=npad)
+        return res[ACT_SILU][0], res[ACT_SILU_D][0], z, d, g_old, g_new
+
+    for outs in both(run):
+        o_s, o_d, z, d, g_old, g_new = outs
+        assert torch.equal(o_s, o_d)                                        # the activation itself is unchanged
+        assert torch.equal(g_old, g_new)                                    # multiply-by-stored-derivative == recomputed derivative
+        zz = z[:, :n].cpu().double()
+        sg = torch.sigmoid(zz)
+        assert (d[:, :n].cpu().double() - sg * (1 + zz * (1 - sg))).abs().max().item() <= 2e-6
+        assert torch.equal(d[:, n:].cpu(), torch.zeros(m, npad - n))
+    if mode == "x3":
+        a, bb = both(run)
+        assert all(torch.equal(u, v) for u, v in zip(a, bb))                # and the two tilings agree bit for bit

@@ -41,6 +41,10 @@ for key in sorted(acc):
             print(f"  -> effective clock: not derived (kernel of {dns * 1e-3:.0f} us: the counter window is longer than the kernel; raw ratio {clk:.2f})")
     if "GRBM_GUI_ACTIVE" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         print(f"  -> MFMA pipe busy = MFMA_BUSY_CYCLES / (1024 SIMDs x GUI_ACTIVE / 8)  {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * c['GRBM_GUI_ACTIVE'] / 8.0):.3f}")
+    if "SQ_INSTS_VALU" in c and "SQ_INSTS_MFMA" in c and c["SQ_INSTS_MFMA"] > 0:
+        # SQ_INSTS_VALU counts the MFMAs too (they issue on the VALU port)
+        print(f"  -> VALU instructions beside each MFMA = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA   {(c['SQ_INSTS_VALU'] - c['SQ_INSTS_MFMA']) / c['SQ_INSTS_MFMA']:.2f}"
+              f"   (LDS {c.get('SQ_INSTS_LDS', 0) / c['SQ_INSTS_MFMA']:.2f}, vector-memory reads {c.get('SQ_INSTS_VMEM_RD', 0) / c['SQ_INSTS_MFMA']:.3f} per MFMA)")
     if "SQ_WAVE_CYCLES" in c:
         for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
             if k in c:

@@ -1147,8 +1147,8 @@ namespace pulse { int gemm_option(int key) { return key >= 0 && key < 8 ? g_opt[
 namespace {
 // Which tiling serves an x3 launch.  Cost model in units of (one 128 x 128 output tile) x (k per split), per CU: the narrow kernel keeps two
 // workgroups per CU (a round of 512 costs 2; a lone workgroup per CU 1.5), the wide kernel one workgroup of four tiles' area
-// per CU and round at 1.1-1.2 x the narrow kernel's rate (3.4 units per wide round; calibrated on profiles/r05_gemm_x3_wide_ab.txt and on every
-// launch of a cfg2 / cfg3 epoch, profiles/r05_gemm_shapes_cfg{2,3}.txt).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
+// per CU and round at 1.1-1.2 x the narrow kernel's rate on long reductions (about 3.3 units per wide round, more on short ones; calibrated on
+// profiles/r05_gemm_x3_wide_ab.txt and on every launch of a cfg2 / cfg3 epoch, profiles/r05_gemm_shapes_cfg{2,3}.txt).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
 // 2 whenever the output has more than 128 rows and columns (tests).
 bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
     static const int env = [] { const char* e = getenv("PULSE_X3_WIDE"); return e ? atoi(e) : -1; }();
@@ -1165,9 +1165,14 @@ bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
     const long long wt = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * z;
     const long long rem = nt % 512;
     const double cost_narrow = 2.0 * (double)(nt / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.5 : 2.0);
-    // the SiLU-derivative epilogue (an exp and a division per element) is exposed VALU time with one workgroup per CU; the narrow tiling hides it
-    // under its other workgroup (profiles/r05_gemm_shapes_cfg3.txt: 16384 x 1536 x 1024 297 vs 376 us)
-    const double cost_wide = (g.epi == 2 ? 1.25 : 1.0) * 3.4 * (double)((wt + 255) / 256);
+    // a round of wide workgroups against a round of 512 narrow ones (= 2 units), from the per-round times of both tilings over the reduction length
+    // each workgroup walks (us: narrow 0.0924 k + 5, wide 0.1526 k + f): the wide tile's prologue and epilogue are exposed (one workgroup per CU),
+    // f = 8 for plain / ReLU / mask / multiply epilogues, 30 for the SiLU forms that write two outputs and evaluate an exp and a division per
+    // element, 45 for the SiLU-derivative epilogue (fits of profiles/r05_gemm_shapes_cfg{2,3}.txt)
+    const double kk = (double)g.kchunk < (double)g.K ? (double)g.kchunk : (double)g.K;
+    const double fw = g.epi == 2 ? 45.0 : (g.epi == 0 && g.act >= 2) ? 30.0 : 8.0;
+    const double wide_round = 2.0 * (0.1526 * kk + fw) / (0.0924 * kk + 5.0);
+    const double cost_wide = wide_round * (double)((wt + 255) / 256);
     return cost_wide < cost_narrow;
 }
 }  // namespace

@@ -118,18 +118,20 @@ def dw_split(tiles, max_split, fill=512):
     return s
 
 
-def x3_tile_costs(M, N, z):
+def x3_tile_costs(M, N, z, k=16384):
     """(narrow, wide) cost of an x3 launch with z = batch x split_k grid slices, in the launcher's units (gemm_f32.hip: x3_wide_tile): one
-    128 x 128 tile alone on a CU = 1.5 per unit of reduction length, two sharing a CU 2; a 256 x 256 workgroup has a CU to itself at 3.4."""
+    128 x 128 tile alone on a CU = 1.5 per unit of reduction length, two sharing a CU 2; a 256 x 256 workgroup has a CU to itself at about
+    3.3 (more on short reductions, whose prologue / epilogue nothing hides)."""
     nt = ((M + 127) // 128) * ((N + 127) // 128) * z
     wt = ((M + 255) // 256) * ((N + 255) // 256) * z
     rem = nt % 512
     narrow = 2.0 * (nt // 512) + (0.0 if rem == 0 else 1.5 if rem <= 256 else 2.0)       # a lone workgroup is not twice as fast as a paired one
-    wide = 3.4 * ((wt + 255) // 256) if (M > 128 and N > 128) else float("inf")
+    wide_round = 2.0 * (0.1526 * k + 8.0) / (0.0924 * k + 5.0)          # k = the reduction length one workgroup walks (plain epilogue)
+    wide = wide_round * ((wt + 255) // 256) if (M > 128 and N > 128) else float("inf")
     return narrow, wide
 
 
-def dw_split_x3(M, N, batch, max_split):
+def dw_split_x3(M, N, batch, max_split, K=16384):
     """Slab count of an fp32 (x3) weight-gradient launch now that the launcher has two tilings: the power-of-two fraction of ``max_split`` with
     the lowest modelled time = min(narrow, wide cost) / split (the reduction length per workgroup is K / split) plus a charge per slab for its
     write and its share of the reduce (calibrated on the 2048 x 960 output: 16 us per 4 slabs against 281 us of GEMM), fewer slabs on ties.  cfg2 layer 1 (2048 x 960): 4 slabs on the narrow tiling -> 8 on the wide one
@@ -139,7 +141,7 @@ def dw_split_x3(M, N, batch, max_split):
     best, best_t = max_split, None
     s = max_split
     while s >= 1:
-        t = min(x3_tile_costs(M, N, batch * s)) / s + 0.006 * s * (M * N * batch) / (2048.0 * 960.0)      # + the slab's write and its share of the reduce
+        t = min(x3_tile_costs(M, N, batch * s, max(16, K // s))) / s + 0.006 * s * (M * N * batch) / (2048.0 * 960.0)      # + the slab's write and its share of the reduce
         if best_t is None or t < best_t - 1e-9 or abs(t - best_t) <= 1e-9:
             best, best_t = s, t
         if s % 2:

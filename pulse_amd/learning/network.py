@@ -442,7 +442,7 @@ class A2CNetwork:
         p.split_dx = len(p.ops)             # everything before this point is the input-gradient chain; the weight gradients after it are independent of each other
         # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
         uu, k = u[0], self.in_w[0]
-        s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_x3(2 * uu, k, 1, S)
+        s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_x3(2 * uu, k, 1, S, K=m)
         ws["layer_slabs"] = [s1] + [S] * (L - 1)
         p.gemm(ws["dh"][0], ws["x"], slabs, M=2 * uu, N=k, K=m, lda=2 * uu, ldb=k, ldc=k, a_layout=GEMM_OUT_CONTIG,
                b_layout=GEMM_OUT_CONTIG, c_off=self.w_off[0], split_k=s1, split_stride=P, algo_n=self.in_dim,
@@ -457,7 +457,7 @@ class A2CNetwork:
         p.call_partial_reduce(hs, HS, hb + 2 * ap, slabs, self.wh_off)
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
-            sl = K.dw_split_x3(uu, up, 2, self.n_slabs)
+            sl = K.dw_split_x3(uu, up, 2, self.n_slabs, K=m)
             ws["layer_slabs"][l] = sl
             p.gemm(ws["dh"][l], ws["h"][l - 1], slabs, M=uu, N=up, K=m, lda=2 * uu, ldb=2 * up, ldc=up, a_layout=GEMM_OUT_CONTIG,
                    b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=uu, stride_b=up, stride_c=uu * up, c_off=self.w_off[l],

@@ -122,7 +122,8 @@ def test_dx_bit_identical(dev, m, n, k, epi):
 
 
 @pytest.mark.parametrize("m,n,k,split,batch", [(512, 1024, 4096, 8, 1), (1024, 960, 16384, 16, 1), (2048, 934, 16384, 8, 1), (300, 130, 1000, 1, 1),
-                                                (200, 512, 4096, 8, 2), (257, 259, 777, 3, 1), (512, 512, 8192, 32, 2)])
+                                                (200, 512, 4096, 8, 2), (257, 259, 777, 3, 1), (512, 512, 8192, 32, 2),
+                                                (300, 300, 40, 4, 1)])          # (the last one: a split whose k range is empty writes a zero slab)
 def test_dw_split_k_and_rowsum_bit_identical(dev, m, n, k, split, batch):
     """dW = dY^T X with the batch (reduction) dimension split into slabs; the A operand's column sums (bias gradient) ride along."""
     torch.manual_seed(m + k)

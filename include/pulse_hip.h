@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 22
+#define PULSE_ABI_VERSION 23
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -547,6 +547,9 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
  * stores issued, [7] stores acknowledged (wall; tools/gemm_x3w_phases.py). */
 int pulse_gemm_set_option(int key, int value);
 int pulse_gemm_set_debug_buffer(long long* device_buffer);
+/* Tile rows (64 / 128 / 256) of the calling thread's last pulse_gemm_f32 launch: which kernel served it (256 = gemm_x3w_kernel).  Diagnostics
+ * (bench.py attributes its per-launch event times to the kernel that ran); no effect on results. */
+int pulse_gemm_last_tile(void);
 /* ------------------------------------------------------------------------- *
  * 4b. The same fp32-grade GEMM (PULSE_GEMM_COMPUTE_F32X3 arithmetic) over operands kept PRE-SPLIT in HBM: a matrix is stored as
  *     three bf16 "planes" (x = p0 + p1 + p2 exactly, p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1), round to nearest

@@ -1139,6 +1139,7 @@ namespace {
 // Diagnostics state: THREAD-LOCAL (round-3 verdict, hygiene): a tool thread that arms the clock stamps or an occupancy knob changes the
 // launches it issues itself, never those of another host thread driving its own stream through the library.
 thread_local long long* g_dbg = nullptr;       // tools/gemm_bench --clocks
+thread_local int g_last_tile = 0;               // tile rows of the calling thread's last pulse_gemm_f32 launch (pulse_gemm_last_tile: bench.py's per-kernel roofline)
 thread_local int g_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [1] extra LDS bytes per workgroup, [2] no 64-row tile, [3] bf16-storage tile choice (see pulse_hip.h)
 }
 
@@ -1182,6 +1183,8 @@ extern "C" {
 int pulse_sizeof_gemm_desc(void) { return (int)sizeof(pulse_gemm_desc); }
 
 int pulse_gemm_set_debug_buffer(long long* device_buffer) { g_dbg = device_buffer; return PULSE_OK; }
+
+int pulse_gemm_last_tile(void) { return g_last_tile; }
 
 int pulse_gemm_set_option(int key, int value) {
     PULSE_REQUIRE(key >= 0 && key < 8, "pulse_gemm_set_option: bad key");
@@ -1277,7 +1280,9 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
         attr_done[IDX] = lds;                                                                                     \
     }                                                                                                             \
     hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_, WM_>), grid, dim3(256), lds, as_stream(s), g)
+    g_last_tile = half_tile ? 64 : 128;
     if (x3 && !half_tile && x3_wide_tile(g, d->lda, d->ldb, akc, bkc)) {
+        g_last_tile = 256;
         // 256 x 256 tile (gemm_x3w.hip): half the split / staging work per MFMA; taken when its one-workgroup-per-CU rounds cost less than the
         // 128 x 128 tiling's (two workgroups per CU) -- see x3_wide_tile
         return launch_gemm_x3w(g, akc, bkc, as_stream(s));

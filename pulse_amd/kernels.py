@@ -171,6 +171,8 @@ def launch_gemm(d, flops=0.0, tag="fwd", stream=None):
         ev0.record()
         _lib.check(lib.pulse_gemm_f32(ctypes.byref(d), st), "pulse_gemm_f32")
         ev1.record()
+        if tag.startswith("x3_") and lib.pulse_gemm_last_tile() == 256:
+            tag = "x3w_" + tag[3:]            # served by the 256 x 256 tile (gemm_x3w_kernel): its own line in the bench's roofline
         PROFILER.records.append((ev0, ev1, flops, tag))
         return
     _lib.check(lib.pulse_gemm_f32(ctypes.byref(d), st), "pulse_gemm_f32")

@@ -245,12 +245,14 @@ __global__ void __launch_bounds__(256) rms_normalize_narrow_kernel(const float* 
 __global__ void __launch_bounds__(1024) rms_update_kernel(double* __restrict__ mean, double* __restrict__ var, double* __restrict__ count_out,
                                                         const double* __restrict__ partials, int nblk, int cols, double count,
                                                         double n) {
-    __shared__ double red[2][16][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;     // 64 columns x 16 groups over the partial blocks
-    const int c = blockIdx.x * 64 + cl;
+    // 16 columns x 64 groups over the partial blocks per workgroup (it was 64 x 16: 15 workgroups for the 934-column policy observation, each
+    // walking 32 dependent rounds of loads -- 13 us, latency-bound; 59 workgroups of 8 rounds now).  [r5]
+    __shared__ double red[2][64][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < cols) {
-        for (int b = pl; b < nblk; b += 16) {
+        for (int b = pl; b < nblk; b += 64) {
             s1 += partials[(long long)b * 2 * cols + c];
             s2 += partials[(long long)b * 2 * cols + cols + c];
         }
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(1024) rms_update_kernel(double* __restrict__ m
     if (pl == 0 && c < cols) {
         s1 = 0.0; s2 = 0.0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { s1 += red[0][g][cl]; s2 += red[1][g][cl]; }
+        for (int g = 0; g < 64; ++g) { s1 += red[0][g][cl]; s2 += red[1][g][cl]; }
         const double bm = s1 / n;
         // unbiased variance like torch.var: sum (x - mean)^2 / (n - 1)
         double bv = (s2 - n * bm * bm) / (n - 1.0);
@@ -643,7 +645,7 @@ int pulse_rms_update(double* mean, double* var, double* count_out, const double*
     if (cols == 0) return PULSE_OK;
     PULSE_REQUIRE(mean && var && moment_partials, "pulse_rms_update: null pointer");
     PULSE_REQUIRE(batch_count >= 2.0, "pulse_rms_update: batch of %g rows has no unbiased variance", batch_count);
-    hipLaunchKernelGGL(rms_update_kernel, dim3((cols + 63) / 64), dim3(1024), 0, as_stream(s), mean, var, count_out, moment_partials, num_blocks,
+    hipLaunchKernelGGL(rms_update_kernel, dim3((cols + 15) / 16), dim3(1024), 0, as_stream(s), mean, var, count_out, moment_partials, num_blocks,
                        cols, count_old, batch_count);
     return check_launch("pulse_rms_update");
 }

@@ -63,6 +63,7 @@ class GemmProfiler:
 
 
 PROFILER = GemmProfiler()
+PLAN_GRAPHS = os.environ.get("PULSE_PLAN_GRAPHS", "0") == "1"       # Plan.run replays captured HIP graphs (see Plan.run): measured, no gain, off
 
 # How an fp32 GEMM is computed (inputs / outputs / storage are fp32 either way):
 #   "x3"      three-way bf16 operand split, six bf16 MFMAs per k step, fp32 accumulation (PULSE_GEMM_COMPUTE_F32X3): fp32-grade
@@ -266,7 +267,42 @@ class Plan:
 
     def run(self, start=0, stop=None, skip_partial_reduces=False):
         """``skip_partial_reduces``: leave out the small ordered reduces registered with call_partial_reduce -- the caller's fused gradient reduce
-        (ReduceGrads regions with their own source) sums those partials itself."""
+        (ReduceGrads regions with their own source) sums those partials itself.
+
+        [r5] PULSE_PLAN_GRAPHS=1 (OFF by default): a plan segment is a fixed list of launches over fixed buffers (descriptors and pointers are built
+        once per workspace), so from its THIRD run on it can be replayed as one captured HIP graph -- same kernels, arguments and order: same bits
+        (the parity suites pass with it on).  A stand-alone chain of 24 dependent GEMMs runs 10.8 us per launch faster as a graph replay
+        (tools/graph_gap_probe.py: 119.0 -> 108.2 us), but inside the epoch it gives nothing (profiles/r05_ab_runs.txt: cfg2 68.0 / 68.6 ms eager,
+        68.4 / 69.2 with graphs; cfg3 902.2 vs 902.4): the update is a single dependent chain whose launches the host already enqueues far ahead of
+        the device, and the gap between two of them is the device's own.  The first two runs stay eager (lazy one-time setup such as
+        hipFuncSetAttribute must not fall inside a capture), as does the bench's instrumented step (an event pair per launch)."""
+        if PLAN_GRAPHS and not PROFILER.enabled and self.ops and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            key = (start, stop, bool(skip_partial_reduces))
+            ent = self._graphs.get(key, 0)
+            if isinstance(ent, torch.cuda.CUDAGraph):
+                ent.replay()
+                return
+            if ent is not None:                                  # None: this segment could not be captured and stays eager
+                if ent < 2:
+                    self._graphs[key] = ent + 1                  # runs 1 and 2: eager (falls through)
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    try:
+                        with torch.cuda.graph(g):
+                            self._run_eager(start, stop, skip_partial_reduces)
+                    except Exception as e:                       # nothing of the segment has run yet: fall through to the eager path
+                        self._graphs[key] = None
+                        import warnings
+                        warnings.warn(f"Plan.run: HIP-graph capture failed ({e}); this segment keeps the eager path")
+                    else:
+                        self._graphs[key] = g
+                        g.replay()                               # the capture recorded the launches, it did not run them
+                        return
+        self._run_eager(start, stop, skip_partial_reduces)
+
+    def _run_eager(self, start=0, stop=None, skip_partial_reduces=False):
         st = _stream()
         for op in self.ops[start:stop]:
             if op[0] == 0:

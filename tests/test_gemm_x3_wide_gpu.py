@@ -243,3 +243,72 @@ def test_silu_derivative_activation_and_multiply_epilogue(dev, monkeypatch, m, n
     if mode == "x3":
         a, bb = both(run)
         assert all(torch.equal(u, v) for u, v in zip(a, bb))                # and the two tilings agree bit for bit
+
+
+def test_random_shapes_both_tilings_agree(dev):
+    """Seeded fuzz over ragged shapes, layouts, epilogues, batch strides and split-K: the two tilings agree bit for bit and with fp64."""
+    import random
+    rng = random.Random(20260926)
+    g = torch.Generator().manual_seed(99)
+    for case in range(36):
+        form = rng.choice(["fwd", "dx", "dw"])
+        m, n = rng.randint(129, 900), rng.randint(129, 900)
+        k = rng.choice([1, 3, 15, 16, 17, 31, 33, 64, 100, 257, 500])
+        batch = rng.choice([1, 1, 2])
+        if form == "fwd":
+            kp = (k + 3) // 4 * 4 + 4 * rng.randint(0, 2)
+            x, w, b = rnd(g, m, batch * kp), rnd(g, batch, n, kp) / math.sqrt(k), rnd(g, batch, n)
+            xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+            ldc = batch * n + rng.choice([0, 1, 3, 4])
+            act = rng.choice([ACT_NONE, ACT_RELU, ACT_SILU])
+
+            def run():
+                out = torch.full((m, ldc), 9.0, device=dev)
+                pre = torch.full((m, ldc), 9.0, device=dev) if act == ACT_SILU else None
+                K.gemm(xd, wd, out, M=m, N=n, K=k, lda=batch * kp, ldb=kp, ldc=ldc, bias=bd, activation=act, C2=pre, ldc2=ldc, batch=batch, stride_a=kp,
+                       stride_b=n * kp, stride_c=n, stride_c2=n, stride_bias=n)
+                return out, pre
+            (o1, p1), (o2, p2) = both(run)
+            assert torch.equal(o1, o2) and (p1 is None or torch.equal(p1, p2)), (case, form, m, n, k, batch, act)
+            for z in range(batch):
+                zz = x[:, z * kp:z * kp + k].double() @ w[z, :, :k].double().T + b[z].double()
+                ref = {ACT_NONE: zz, ACT_RELU: zz.clamp(min=0), ACT_SILU: zz * torch.sigmoid(zz)}[act]
+                close64(o2[:, z * n:(z + 1) * n], ref, k)
+        elif form == "dx":
+            kp, npad = (k + 3) // 4 * 4, (n + 3) // 4 * 4
+            dy, w, aux = rnd(g, m, batch * kp), rnd(g, batch, k, npad) / math.sqrt(k), rnd(g, m, batch * npad)
+            dyd, wd, auxd = dy.to(dev), w.to(dev), aux.to(dev)
+            epi = rng.choice([EPI_RELU_GRAD, EPI_SILU_GRAD, EPI_MUL_AUX])
+
+            def run():
+                out = torch.full((m, batch * npad), 5.0, device=dev)
+                K.gemm(dyd, wd, out, M=m, N=n, K=k, lda=batch * kp, ldb=npad, ldc=batch * npad, b_layout=GEMM_OUT_CONTIG, epilogue=epi, aux=auxd,
+                       ldaux=batch * npad, batch=batch, stride_a=kp, stride_b=k * npad, stride_c=npad, stride_aux=npad)
+                return out
+            o1, o2 = both(run)
+            assert torch.equal(o1, o2), (case, form, m, n, k, batch, epi)
+            for z in range(batch):
+                acc = dy[:, z * kp:z * kp + k].double() @ w[z, :, :n].double()
+                a = aux[:, z * npad:z * npad + n].double()
+                sg = torch.sigmoid(a)
+                ref = acc * {EPI_RELU_GRAD: (a > 0).double(), EPI_SILU_GRAD: sg * (1 + a * (1 - sg)), EPI_MUL_AUX: a}[epi]
+                close64(o2[:, z * npad:z * npad + n], ref, k)
+        else:
+            kk = rng.choice([40, 777, 2048, 5000])
+            split = rng.choice([1, 2, 3, 8])
+            lda, ldb = batch * ((m + 3) // 4 * 4), batch * ((n + 3) // 4 * 4)
+            dy, x = torch.randn(kk, lda, generator=g).to(dev), torch.randn(kk, ldb, generator=g).to(dev)
+            cnt = m * n
+            slab = (batch * cnt + 3) // 4 * 4
+
+            def run():
+                out = torch.full((split, slab), 7.0, device=dev)
+                K.gemm(dy, x, out, M=m, N=n, K=kk, lda=lda, ldb=ldb, ldc=n, a_layout=GEMM_OUT_CONTIG, b_layout=GEMM_OUT_CONTIG, batch=batch,
+                       stride_a=lda // batch, stride_b=ldb // batch, stride_c=cnt, split_k=split, split_stride=slab)
+                return out
+            o1, o2 = both(run)
+            assert torch.equal(o1, o2), (case, form, m, n, kk, batch, split)
+            tot = o2.sum(0).cpu().double()
+            for z in range(batch):
+                ref = dy[:, z * (lda // batch): z * (lda // batch) + m].cpu().double().t() @ x[:, z * (ldb // batch): z * (ldb // batch) + n].cpu().double()
+                assert (tot[z * cnt:(z + 1) * cnt].view(m, n) - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-6

@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     if (g.dbg && tid == 0) {
         long long* o = g.dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
-        o[0] = dbg_c0; o[1] = dbg_w0; o[2] = dbg_c1; o[3] = dbg_w1; o[4] = clock64(); o[5] = wall_clock64(); o[6] = dbg_c1;
+        o[0] = dbg_c0; o[1] = dbg_w0; o[2] = dbg_c1; o[3] = dbg_w1; o[4] = clock64(); o[5] = wall_clock64(); o[6] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         o[7] = wall_clock64();                    // the wave's stores acknowledged (tools/gemm_x3w_phases.py)
     }

@@ -52,7 +52,7 @@ def main():
             med = lambda v: float(v.median())
             print(f"{form} {m}x{n} K={k:5d} ({wgs} wgs, {nkt} k-tiles): span {float(w3.max() - w0.min()):6.1f} us | start spread {float(w0.max() - w0.min()):5.1f} | "
                   f"prologue + main loop {med(w1 - w0):6.1f} us = {med(cyc):9.0f} cyc at {ghz:.2f} GHz, MFMA pipe {ideal / med(cyc):.3f} busy | "
-                  f"epilogue issue {med(w2 - w1):5.1f} | store drain {med(w3 - w2):5.1f} | first image at +{float(((b[:, 6] - b[:, 2]) / (ghz * 1e3)).median()):4.1f} | "
+                  f"epilogue issue {med(w2 - w1):5.1f} | store drain {med(w3 - w2):5.1f} | "
                   f"per-WG total {med(w3 - w0):6.1f} (max {float((w3 - w0).max()):6.1f}) | gap to next launch {float(nxt[:, 1].min() / 100 - w3.max()):5.1f}", flush=True)
     K.gemm_set_option(4, 0)
 

@@ -335,3 +335,79 @@ def amp_obs_smpl(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, k
     parts = [root_pos[:, 2:3]] if root_height_obs else []
     parts += [rot6, lvel, lang, dof_to_obs_smpl(dof_pos), dof_vel, lkey]
     return torch.cat(parts, dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# zero_out_far (humanoid.py:311-329): envs whose root is further than close_distance from the reference see a reference that
+# is their own simulated state (plus a direction towards the goal), and are paid for approaching it instead of imitating.
+# ---------------------------------------------------------------------------------------------------------------------------
+def zero_out_far_refs(obs_v, root_pos, body_pos, body_rot, body_vel, body_ang_vel, ref_pos, ref_rot, ref_vel, ref_ang_vel,
+                      close_distance=0.25, far_distance=3.0):
+    """The zero_out_far blocks of HumanoidIm._compute_task_obs, phc/env/tasks/humanoid_im.py:763-777 (obs_v 4 / 5 / 6 / 8 / 9) and
+    :814-826 (obs_v 7: positions and velocities only).  All (N, Jt, .) over the TRACKED bodies, one reference sample.
+    Returns the masked copies of the four reference tensors and ``distance`` (= the new _point_goal)."""
+    ref_pos, ref_rot, ref_vel, ref_ang_vel = ref_pos.clone(), ref_rot.clone(), ref_vel.clone(), ref_ang_vel.clone()
+    distance = torch.norm(root_pos - ref_pos[..., 0, :], dim=-1)
+    zeros_subset = distance > close_distance
+    ref_pos[zeros_subset, 1:] = body_pos[zeros_subset, 1:]
+    if obs_v != 7:
+        ref_rot[zeros_subset, 1:] = body_rot[zeros_subset, 1:]
+    ref_vel[zeros_subset, :] = body_vel[zeros_subset, :]
+    if obs_v != 7:
+        ref_ang_vel[zeros_subset, :] = body_ang_vel[zeros_subset, :]
+    vector_zero_subset = distance > far_distance                      # beyond far_distance the root target is just a direction
+    ref_pos[vector_zero_subset, 0] = ((ref_pos[vector_zero_subset, 0] - body_pos[vector_zero_subset, 0]) / distance[vector_zero_subset, None]
+                                      * far_distance) + body_pos[vector_zero_subset, 0]
+    return ref_pos, ref_rot, ref_vel, ref_ang_vel, distance
+
+
+def point_goal_reward(prev_dist, curr_dist):
+    """compute_point_goal_reward, phc/env/tasks/humanoid_im.py:1577-1582."""
+    reward = torch.clamp(prev_dist - curr_dist, max=1 / 3) * 9
+    return reward, reward
+
+
+def im_reward_zero_out_far(rb, ref_pos, ref_rot, ref_vel, ref_ang_vel, point_goal, dof_force, dof_vel, progress,
+                           specs=None, power_coef=DEFAULT_POWER_COEF, power_reward=True):
+    """HumanoidIm._compute_reward with zero_out_far, humanoid_im.py:870-887 (+ the power term :908-917): the point-goal reward for
+    everyone, plus half the FULL-BODY imitation reward for the envs within 0.25 m (``transition_distance``) of the reference root."""
+    bp, br, bv, ba = split_rb(rb)
+    n = rb.shape[0]
+    distance = torch.norm(bp[..., 0, :] - ref_pos[..., 0, :], dim=-1)          # ref_root_pos = rg_pos[..., 0, :] (motion_lib_base.py:500)
+    zeros_subset = distance > 0.25
+    raw = torch.zeros((n, 4))
+    rew, raw[:, 0] = point_goal_reward(point_goal, distance)
+    inside = ~zeros_subset
+    im_rew, im_raw = im_reward(bp[inside], br[inside], bv[inside], ba[inside], ref_pos[inside], ref_rot[inside], ref_vel[inside],
+                               ref_ang_vel[inside], specs)
+    rew[inside] = rew[inside] + im_rew * 0.5
+    raw[inside, :4] = raw[inside, :4] + im_raw * 0.5
+    if power_reward:
+        p = power_term(dof_force, dof_vel, progress, power_coef)
+        rew = rew + p
+        raw = torch.cat([raw, p[:, None]], dim=-1)
+    return rew, raw
+
+
+def post_physics_zero_out_far(rb, ref_now, ref_next, point_goal, dof_force, dof_vel, progress, pass_time, reset_body_ids, track_body_ids,
+                              term_dist, cycle_counter=None, obs_v=6, close_distance=0.25, far_distance=3.0, specs=None,
+                              power_coef=DEFAULT_POWER_COEF, power_reward=True, upright=True):
+    """post_physics with ``zero_out_far: True`` (phc_kp_pnn_iccv.yaml:36 & co): reward on the old _point_goal, the unchanged reset
+    (humanoid_im.py:1158-1176 calls compute_humanoid_im_reset on the un-masked reference), then the task observation against the
+    masked reference, which also leaves the new _point_goal.  Returns post_physics' dict + ``point_goal``."""
+    bp, br, bv, ba = split_rb(rb)
+    rew, raw = im_reward_zero_out_far(rb, ref_now["pos"], ref_now["rot"], ref_now["vel"], ref_now["ang"], point_goal, dof_force, dof_vel,
+                                      progress, specs, power_coef, power_reward)
+    n = rb.shape[0]
+    reset, term = im_reset(torch.zeros(n, dtype=torch.int64), progress, bp[:, reset_body_ids].clone(), ref_now["pos"][:, reset_body_ids].clone(),
+                           pass_time, term_dist[..., reset_body_ids])
+    if cycle_counter is not None:
+        rec = torch.logical_and(~pass_time, cycle_counter > 0)
+        reset[rec] = 0
+        term[rec] = 0
+    tb = track_body_ids
+    rp, rr, rv, ra, goal = zero_out_far_refs(obs_v, bp[:, 0], bp[:, tb], br[:, tb], bv[:, tb], ba[:, tb], ref_next["pos"][:, tb],
+                                             ref_next["rot"][:, tb], ref_next["vel"][:, tb], ref_next["ang"][:, tb], close_distance, far_distance)
+    to = im_obs_variant(obs_v, bp[:, 0], br[:, 0], bp[:, tb], br[:, tb], bv[:, tb], ba[:, tb], rp, rr, rv, ra, 1, upright)
+    so = self_obs_smpl_max_general(bp, br, bv, ba, upright=upright)
+    return {"obs": torch.cat([so, to], dim=-1), "rew": rew, "raw": raw, "reset": reset, "terminate": term, "point_goal": goal}

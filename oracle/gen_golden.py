@@ -473,6 +473,83 @@ def gen_terrain(n=37):
     np.savez_compressed(os.path.join(GOLDEN_DIR, "terrain.npz"), **_np(out))
 
 
+def zero_out_far_inputs(n=83, seed=2025):
+    """One post-physics step of a ``zero_out_far: True`` env (phc_kp_pnn_iccv.yaml:36): whole humanoids standing 0 .. 8 m off their
+    reference (inside close_distance, between close and far, beyond far_distance), _point_goal of the step before."""
+    g = syn.make_generator(seed)
+    d = syn.env_step_inputs(g, n)
+    shift = torch.zeros(n, 2)
+    k = n // 4
+    shift[k:2 * k, 0] = torch.linspace(0.26, 2.9, k)                 # between close_distance and far_distance: own state as reference
+    ang = torch.rand(n - 2 * k, generator=g) * 6.2831853
+    rad = torch.linspace(3.05, 8.0, n - 2 * k)                       # beyond far_distance: the root target is a direction
+    shift[2 * k:, 0], shift[2 * k:, 1] = rad * torch.cos(ang), rad * torch.sin(ang)
+    shift[2] = torch.tensor([0.2, 0.1])                              # |.| ~ 0.224 + noise: around the 0.25 m transition of the reward
+    shift[3] = torch.tensor([0.15, 0.2])
+    d["rb"][:, :, 0:2] += shift[:, None, :]
+    dist_now = torch.norm(d["rb"][:, 0, 0:3] - d["ref_now"]["pos"][:, 0], dim=-1)
+    prev = dist_now + 0.05 * torch.randn(n, generator=g)
+    prev[::5] += 0.5                                                 # approached by more than 1/3 m: the clamp of compute_point_goal_reward
+    d["point_goal"] = prev
+    return d
+
+
+def gen_env_zero_out_far():
+    """HumanoidIm._compute_reward / _compute_reset / _compute_task_obs METHOD BODIES with zero_out_far (humanoid_im.py:763-777, 814-826,
+    870-887, 1158-1176) and compute_point_goal_reward (:1577-1582), run on a stub task whose motion cache hands out recorded frames."""
+    import types
+    f = refload.humanoid_im_methods()
+    fn = refload.env_functions()
+    d = zero_out_far_inputs()
+    rb, n = d["rb"], d["rb"].shape[0]
+    rn, rx = d["ref_now"], d["ref_next"]
+    out = {"rb": rb, "dof_force": d["dof_force"], "dof_vel": d["dof_vel"], "progress": d["progress"], "pass_time": d["pass_time"],
+           "point_goal_prev": d["point_goal"], "close_distance": torch.tensor(0.25), "far_distance": torch.tensor(3.0)}
+    for k in ("pos", "rot", "vel", "ang"):
+        out[f"ref_now_{k}"], out[f"ref_next_{k}"] = rn[k], rx[k]
+    out["point_goal_reward"], _ = fn["compute_point_goal_reward"](d["point_goal"], torch.norm(rb[:, 0, 0:3] - rn["pos"][:, 0], dim=-1))
+    dt = 1.0 / 30
+
+    def res(r):
+        return {"root_pos": r["pos"][:, 0].clone(), "root_rot": r["rot"][:, 0].clone(), "dof_pos": torch.zeros(n, 69), "root_vel": r["vel"][:, 0].clone(),
+                "root_ang_vel": r["ang"][:, 0].clone(), "dof_vel": torch.zeros(n, 69), "motion_bodies": torch.zeros(n, 17),
+                "motion_limb_weights": torch.zeros(n, 10), "motion_aa": torch.zeros(n, 72), "rg_pos": r["pos"].clone(), "rb_rot": r["rot"].clone(),
+                "body_vel": r["vel"].clone(), "body_ang_vel": r["ang"].clone()}
+
+    for obs_v, ids, tag in ((6, list(range(24)), "v6"), (7, syn.VR_TRACK_BODY_IDS, "v7_vr"), (7, list(range(24)), "v7"), (8, list(range(24)), "v8"),
+                            (9, list(range(24)), "v9"), (6, syn.VR_TRACK_BODY_IDS, "v6_vr")):
+        for close, far, dtag in ((0.25, 3.0, ""), (0.5, 1.5, "_c05_f15")):
+            task = types.SimpleNamespace(
+                _rigid_body_pos=rb[..., 0:3], _rigid_body_rot=rb[..., 3:7], _rigid_body_vel=rb[..., 7:10], _rigid_body_ang_vel=rb[..., 10:13],
+                num_envs=n, device="cpu", humanoid_shapes=torch.zeros(n, 17), _fut_tracks=False, _num_traj_samples=1, _traj_sample_timestep=1.0 / 30,
+                progress_buf=d["progress"].clone(), dt=dt, _motion_start_times=torch.zeros(n), _motion_start_times_offset=torch.zeros(n),
+                _sampled_motion_ids=torch.arange(n), _global_offset=torch.zeros(n, 3), _track_bodies_id=torch.tensor(ids), obs_v=obs_v,
+                _has_upright_start=True, zero_out_far=True, zero_out_far_train=True, close_distance=close, far_distance=far,
+                _point_goal=d["point_goal"].clone(), _occl_training=False, _fut_tracks_dropout=False, ref_body_pos=torch.zeros(n, 24, 3),
+                ref_body_vel=torch.zeros(n, 24, 3), ref_body_rot=torch.zeros(n, 24, 4), ref_body_pos_subset=torch.zeros(n, len(ids), 3),
+                ref_dof_pos=torch.zeros(n, 69), dof_force_tensor=d["dof_force"], _dof_vel=d["dof_vel"],
+                reward_specs={"k_pos": 100, "k_rot": 10, "k_vel": 0.1, "k_ang_vel": 0.1, "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1},
+                _full_body_reward=True, power_reward=True, power_coefficient=0.0005, rew_buf=torch.zeros(n), reward_raw=torch.zeros(n, 4),
+                max_episode_length=300, cycle_motion=False, cycle_motion_xp=False, _cycle_counter=torch.zeros(n, dtype=torch.int64),
+                reset_buf=torch.zeros(n, dtype=torch.int64), _terminate_buf=torch.zeros(n, dtype=torch.int64), _contact_forces=torch.zeros(n, 24, 3),
+                _contact_body_ids=torch.tensor([7, 3]), _reset_bodies_id=torch.tensor(syn.RESET_BODY_IDS), _enable_early_termination=True,
+                _termination_distances=torch.full((24,), 0.25), strict_eval=False,
+                _motion_lib=types.SimpleNamespace(_motion_lengths=torch.where(d["pass_time"], torch.zeros(n), torch.full((n,), 1e9))))
+            for k, m in f.items():
+                setattr(task, k, types.MethodType(m, task))
+            which = {"r": rn}
+            task._get_state_from_motionlib_cache = lambda ids_, times_, offset_=None: res(which["r"])
+            task._compute_reward(None)
+            task._compute_reset()
+            which["r"] = rx
+            obs = task._compute_task_obs()
+            out[f"task_obs_{tag}{dtag}"], out[f"point_goal_{tag}{dtag}"] = obs, task._point_goal.clone()
+            if tag == "v6" and not dtag:
+                out["reward"], out["reward_raw"] = task.rew_buf.clone(), task.reward_raw.clone()
+                out["reset"], out["terminate"] = task.reset_buf.clone(), task._terminate_buf.clone()
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "env_zero_out_far.npz"), **_np(out))
+
+
 def main():
     assert refload.available(), "reference tree not found; goldens can only be generated in the build container"
     os.makedirs(GOLDEN_DIR, exist_ok=True)
@@ -483,6 +560,7 @@ def main():
     gen_env_amp()
     gen_env_variants()
     gen_env_shape_obs()
+    gen_env_zero_out_far()
     gen_terrain()
     gen_agent_math()
     gen_rms()

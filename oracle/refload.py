@@ -93,7 +93,7 @@ HUMANOID_FUNCS = ["remove_base_rot", "compute_humanoid_observations_smpl_max", "
                   "compute_humanoid_observations_smpl_max_v3", "compute_humanoid_reset", "dof_to_obs_smpl"]
 HUMANOID_IM_FUNCS = ["compute_imitation_observations", "compute_imitation_observations_v2", "compute_imitation_observations_v3",
                      "compute_imitation_observations_v6", "compute_imitation_observations_v7", "compute_imitation_observations_v8",
-                     "compute_imitation_observations_v9", "compute_imitation_reward", "compute_humanoid_im_reset"]
+                     "compute_imitation_observations_v9", "compute_imitation_reward", "compute_humanoid_im_reset", "compute_point_goal_reward"]
 HUMANOID_AMP_FUNCS = ["build_amp_observations_smpl"]
 COMMON_AGENT_METHODS = ["discount_values", "_actor_loss", "_critic_loss", "bound_loss", "_calc_advs"]
 

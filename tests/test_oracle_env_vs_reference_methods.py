@@ -25,48 +25,74 @@ def _ref_motion_lib(tabs):
     return lib
 
 
-@pytest.mark.parametrize("cycle_motion,time_steps", [(False, 1), (False, 3), (True, 1)])
-def test_step_composition_matches_reference_methods(cycle_motion, time_steps):
+@pytest.mark.parametrize("cycle_motion,time_steps,zof", [(False, 1, None), (False, 3, None), (True, 1, None),
+                                                         # zero_out_far (phc_kp_pnn_iccv.yaml:24,36-37: obs_v 7; phc_shape_*_iccv.yaml: obs_v 6)
+                                                         (False, 1, (6, False)), (False, 1, (7, False)), (True, 1, (6, True)), (False, 1, (7, True))])
+def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zof):
+    obs_v, zof_train = zof if zof else (6, False)
     f = refload.humanoid_im_methods()
     n, dt, frames = 48, 2.0 / 60.0, 12
     g = syn.make_generator(31)
     tabs = syn.synthetic_motion_library(g, n, 10, 24)                      # short clips: motions run out within a few steps
     noise = torch.randn(frames, n, 24, 13, generator=g) * torch.tensor([0.03] * 3 + [0.04] * 4 + [0.15] * 3 + [0.3] * 3)
     noise[:, ::7, 13, 0:3] += 1.0                                          # some envs drift away -> early termination
+    if zof:                                                                # whole humanoids off the reference: 0.3 .. 7 m, some moving closer
+        shift = torch.linspace(0.3, 7.0, n // 3)[None, :, None, None] * (1.0 - 0.05 * torch.arange(frames)[:, None, None, None])
+        noise[:, ::3, :, 0:2] += shift
     bank = {"rb": noise, "dof_force": 50.0 * torch.randn(frames, n, 69, generator=g), "dof_pos": 0.02 * torch.randn(frames, n, 69, generator=g),
             "dof_vel": 0.1 * torch.randn(frames, n, 69, generator=g)}
     track = list(range(24))
     twin = OracleMotionEnv(OracleMotionLib(tabs), bank, torch.arange(n), torch.zeros(n, 3), syn.RESET_BODY_IDS, track, dt,
-                           time_steps=time_steps, cycle_motion=cycle_motion, max_episode_length=300)
+                           time_steps=time_steps, cycle_motion=cycle_motion, max_episode_length=300, obs_v=obs_v, zero_out_far=bool(zof),
+                           zero_out_far_train=zof_train, close_distance=0.3, far_distance=2.5, zero_out_far_steps=4)
     lib = _ref_motion_lib(tabs)
     starts = OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g)
-    twin.reset(torch.arange(n), starts)
+    twin.reset(torch.arange(n), starts, far_uniforms=torch.rand(n, 2, generator=g))
+    seen_far = seen_inside = seen_clipped = 0
     checked_cycle = 0
     for step in range(10):
-        pre = {k: getattr(twin, k).clone() for k in ("progress", "start", "start_off", "offset", "cycle_counter")}
+        pre = {k: getattr(twin, k).clone() for k in ("progress", "start", "start_off", "offset", "cycle_counter", "point_goal")}
         cyc = OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g)
-        obs_t, rew_t, reset_t, info_t = twin.step(cycle_start_times=cyc)
+        far_u = torch.rand(n, 2, generator=g)
+        obs_t, rew_t, reset_t, info_t = twin.step(cycle_start_times=cyc, far_uniforms=far_u)
         rb, fidx = twin.rb, twin.frame
         task = types.SimpleNamespace(
             _rigid_body_pos=rb[..., 0:3], _rigid_body_rot=rb[..., 3:7], _rigid_body_vel=rb[..., 7:10], _rigid_body_ang_vel=rb[..., 10:13],
             _humanoid_root_states=rb[:, 0], num_envs=n, device="cpu", humanoid_shapes=torch.zeros(n, 17), _fut_tracks=time_steps > 1,
             _num_traj_samples=time_steps, _traj_sample_timestep=1.0 / 30, progress_buf=pre["progress"] + 1, dt=dt,
             _motion_start_times=pre["start"].clone(), _motion_start_times_offset=pre["start_off"].clone(), _sampled_motion_ids=torch.arange(n),
-            _global_offset=pre["offset"].clone(), _motion_lib=lib, ref_motion_cache={}, _track_bodies_id=torch.tensor(track), obs_v=6,
-            _has_upright_start=True, zero_out_far=False, zero_out_far_train=False, _occl_training=False, _fut_tracks_dropout=False,
+            _global_offset=pre["offset"].clone(), _motion_lib=lib, ref_motion_cache={}, _track_bodies_id=torch.tensor(track), obs_v=obs_v,
+            _has_upright_start=True, zero_out_far=bool(zof), zero_out_far_train=zof_train, close_distance=0.3, far_distance=2.5,
+            _point_goal=pre["point_goal"].clone(), _occl_training=False, _fut_tracks_dropout=False,
             ref_body_pos=torch.zeros(n, 24, 3), ref_body_vel=torch.zeros(n, 24, 3), ref_body_rot=torch.zeros(n, 24, 4),
             ref_body_pos_subset=torch.zeros(n, 24, 3), ref_dof_pos=torch.zeros(n, 69), dof_force_tensor=bank["dof_force"][fidx], _dof_vel=twin.dof_vel,
             reward_specs={"k_pos": 100, "k_rot": 10, "k_vel": 0.1, "k_ang_vel": 0.1, "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1},
             _full_body_reward=True, power_reward=True, power_coefficient=0.0005, rew_buf=torch.zeros(n), reward_raw=torch.zeros(n, 4),
-            max_episode_length=300, cycle_motion=cycle_motion, cycle_motion_xp=False, _cycle_counter=torch.clamp_min(pre["cycle_counter"] - 1, 0) if cycle_motion else pre["cycle_counter"].clone(),
+            max_episode_length=300, cycle_motion=cycle_motion, cycle_motion_xp=False,
+            _cycle_counter=torch.clamp_min(pre["cycle_counter"] - 1, 0) if (cycle_motion or zof_train) else pre["cycle_counter"].clone(),
             _sample_time=lambda ids: cyc[ids], reset_buf=torch.zeros(n, dtype=torch.int64), _terminate_buf=torch.zeros(n, dtype=torch.int64),
             _contact_forces=torch.zeros(n, 24, 3), _contact_body_ids=torch.tensor([7, 3]), _reset_bodies_id=torch.tensor(syn.RESET_BODY_IDS),
             _enable_early_termination=True, _termination_distances=torch.full((24,), 0.25), strict_eval=False)
         for k, fn in f.items():
             setattr(task, k, types.MethodType(fn, task))
-        task._compute_reward(None)
-        task._compute_reset()
+        if zof_train:                      # the far restart of a cycled motion draws torch.rand twice (humanoid_im.py:1139-1140): replay far_u there
+            draws = iter([far_u[:, 0], far_u[:, 1]])
+            ended = (pre["progress"] + 1) * dt + pre["start"] + pre["start_off"] >= tabs["motion_lengths"][torch.arange(n)]
+            real_rand = torch.rand
+            f["_compute_reset"].__globals__["torch"] = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+            f["_compute_reset"].__globals__["torch"].rand = lambda *a, **kw: next(draws)[ended]
+        try:
+            task._compute_reward(None)
+            task._compute_reset()
+        finally:
+            if zof_train:
+                f["_compute_reset"].__globals__["torch"] = torch
         task_obs = task._compute_task_obs()
+        if zof:
+            assert torch.equal(task._point_goal, twin.point_goal), f"point goal step {step}"
+            seen_far += int((twin.point_goal > 0.3).sum())
+            seen_inside += int((twin.point_goal <= 0.3).sum())
+            seen_clipped += int((twin.point_goal > 2.5).sum())
         assert torch.equal(task.rew_buf, rew_t), f"reward step {step}"
         assert torch.equal(task.reward_raw, info_t["reward_raw"])
         assert torch.equal(task.reset_buf, reset_t) and torch.equal(task._terminate_buf, info_t["terminate"]), f"flags step {step}"
@@ -75,8 +101,12 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps):
         assert torch.equal(task._global_offset, twin.offset) and torch.equal(task._cycle_counter, twin.cycle_counter)
         checked_cycle += int((twin.cycle_counter == 60).sum())
         ids = torch.nonzero(reset_t).flatten()
-        twin.reset(ids, OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g))
-    if cycle_motion:
+        twin.reset(ids, OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g), far_uniforms=torch.rand(n, 2, generator=g))
+    if zof:
+        assert seen_far > 0 and seen_inside > 0 and seen_clipped > 0, "the far / inside / direction-only branches were not all taken"
+    if zof_train:
+        assert (twin.offset != 0).any()
+    elif cycle_motion:
         assert checked_cycle > 0, "no motion was cycled in place"
     else:
         assert (twin.offset == 0).all()

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 23
+#define PULSE_ABI_VERSION 24
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -206,6 +206,18 @@ typedef struct pulse_im_step_args {
        progress_rw is p - 1, and the observation stage runs on that clock, as in the reference where _compute_observations follows
        the decrement, humanoid.py:1325-1328).  Needs progress_rw; only read when ``what`` includes PULSE_IM_RESET. */
     const int32_t* recovery_counter;
+    /* ---- optional: ``zero_out_far`` (humanoid.py:311-329; True in phc_kp_pnn_iccv.yaml:36, phc_shape_pnn_iccv.yaml:39, phc_kp_mcp_iccv.yaml:34,
+       phc_shape_mcp_iccv.yaml:36, env_im_getup_mcp.yaml:27).  time_steps must be 1 (the reference's blocks broadcast (N, 3) against (N T, 3)).
+       Task observation (HumanoidIm._compute_task_obs, humanoid_im.py:763-777 for obs_version 6 / 8 / 9, :814-826 for 7):
+         d = |root_pos - ref_next_pos[track_ids[0]]|;  point_goal[e] = d;
+         d > close_distance: the reference of tracked bodies 1.. (pos, rot) and of every tracked body (vel, ang vel) := the simulated state;
+         d > far_distance:   ref pos of tracked body 0 := (ref - cur) / d * far_distance + cur   (a direction);
+       Reward (HumanoidIm._compute_reward, :870-887; compute_point_goal_reward :1577-1582), read BEFORE the observation stage overwrites it:
+         g = min(point_goal[e] - |root_pos - ref_now_pos[0]|, 1/3) * 9;  outside 0.25 m: reward = g, raw = (g, 0, 0, 0);
+         inside: reward = g + 0.5 * full-body imitation reward, raw = (g, 0, 0, 0) + 0.5 * imitation raw;  then the power term as usual.
+       The reset stage is unchanged (:1158-1176 calls compute_humanoid_im_reset on the un-masked reference). */
+    int32_t zero_out_far; float close_distance; float far_distance;
+    float* point_goal;        /* (num_envs) HumanoidIm._point_goal, read by the reward stage and written by the task-observation stage */
 } pulse_im_step_args;
 
 /* sizeof(pulse_im_step_args) as compiled, so a foreign-language binding can verify its mirror */

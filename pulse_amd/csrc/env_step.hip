@@ -184,6 +184,11 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
     float* obs_e = s_obs + slot * colsp;
     float* rd_e = s_rd + slot * ndp;
 
+    // zero_out_far: the reward stage pays for the approach since the LAST observation (_point_goal); the task-observation stage of this very
+    // launch overwrites it after the barrier, so every lane takes its copy now
+    float prev_goal = 0.f;
+    if (valid && a.zero_out_far && do_rew) prev_goal = a.point_goal[e];
+
     // ---------------- stage inputs (global -> LDS, coalesced) ----------------
     if (valid) {
         const float* g_rb = a.rb + e * a.rb_env_stride + (H - 1) * J13;      // the newest record of the history
@@ -351,17 +356,39 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
             float* tob = obs_e + L.self_w;
             auto put3 = [&](int off, const V3& x) { if (off >= 0) { float* o = tob + off; o[0] = x.x; o[1] = x.y; o[2] = x.z; } };
             auto put6 = [&](int off, const float* x) { if (off >= 0) { float* o = tob + off; for (int k = 0; k < 6; ++k) o[k] = x[k]; } };
+            // zero_out_far (humanoid_im.py:763-777, 814-826; T == 1): distance of the simulated root to the reference of tracked body 0
+            bool zof_far = false, zof_dir = false;
+            float zof_d = 0.f;
+            if (a.zero_out_far) {
+                const int t0 = a.track_ids[0];
+                const float dx = root_p.x - rx_e[3 * t0], dy = root_p.y - rx_e[3 * t0 + 1], dz = root_p.z - rx_e[3 * t0 + 2];
+                zof_d = sqrtf(dx * dx + dy * dy + dz * dz);
+                zof_far = zof_d > a.close_distance;
+                zof_dir = zof_d > a.far_distance;
+                if (lane == 0) a.point_goal[e] = zof_d;
+            }
             for (int t = 0; t < T; ++t) {
                 const float* x = rx_e + t * J13p;
-                const V3 pr{x[3 * tb], x[3 * tb + 1], x[3 * tb + 2]};
-                const V3 vr{x[J * 7 + 3 * tb], x[J * 7 + 3 * tb + 1], x[J * 7 + 3 * tb + 2]};
+                V3 pr{x[3 * tb], x[3 * tb + 1], x[3 * tb + 2]};
+                V3 vr{x[J * 7 + 3 * tb], x[J * 7 + 3 * tb + 1], x[J * 7 + 3 * tb + 2]};
+                if (zof_far) {                       // a far env's reference is its own state ...
+                    vr = v;
+                    if (lane >= 1) pr = p;
+                }
+                if (zof_dir && lane == 0)            // ... and beyond far_distance the root target is only a direction
+                    pr = V3{(pr.x - p.x) / zof_d * a.far_distance + p.x, (pr.y - p.y) / zof_d * a.far_distance + p.y,
+                            (pr.z - p.z) / zof_d * a.far_distance + p.z};
                 put3(task_off(ov, 0, Jt, T, t, lane), qrot(hinv, V3{pr.x - p.x, pr.y - p.y, pr.z - p.z}));
                 put3(task_off(ov, 2, Jt, T, t, lane), qrot(hinv, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z}));
                 put3(task_off(ov, 4, Jt, T, t, lane), qrot(hinv, V3{pr.x - root_p.x, pr.y - root_p.y, pr.z - root_p.z}));
                 put3(task_off(ov, 6, Jt, T, t, lane), qrot(hinv, vr));
                 if (ov != 7) {
-                    const Q4 qr{x[J * 3 + 4 * tb], x[J * 3 + 4 * tb + 1], x[J * 3 + 4 * tb + 2], x[J * 3 + 4 * tb + 3]};
-                    const V3 wr{x[J * 10 + 3 * tb], x[J * 10 + 3 * tb + 1], x[J * 10 + 3 * tb + 2]};
+                    Q4 qr{x[J * 3 + 4 * tb], x[J * 3 + 4 * tb + 1], x[J * 3 + 4 * tb + 2], x[J * 3 + 4 * tb + 3]};
+                    V3 wr{x[J * 10 + 3 * tb], x[J * 10 + 3 * tb + 1], x[J * 10 + 3 * tb + 2]};
+                    if (zof_far) {
+                        wr = w;
+                        if (lane >= 1) qr = q;
+                    }
                     float tn[6];
                     int off = task_off(ov, 1, Jt, T, t, lane);
                     if (off >= 0) { q_to_tan_norm(qmul(qmul(hinv, qmul(qr, qconj(q))), hfwd), tn); put6(off, tn); }   // change of basis
@@ -387,10 +414,12 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
 
         if (do_rew && r_now) {
             // bodies entering the reward: all J (full-body) or the tracked subset (humanoid_im.py:886-899)
-            const int nb = a.full_body_reward ? J : a.num_track;
+            // (the zero_out_far branch always takes the full body, humanoid_im.py:876-878)
+            const bool full = a.full_body_reward || a.zero_out_far;
+            const int nb = full ? J : a.num_track;
             float e_pos = 0.f, e_rot = 0.f, e_vel = 0.f, e_ang = 0.f;
             if (lane < nb) {
-                const int b = a.full_body_reward ? lane : a.track_ids[lane];
+                const int b = full ? lane : a.track_ids[lane];
                 const float* r = rb_e + 13 * b;
                 const float* x = rn_e;
                 float dx = x[3 * b] - r[0], dy = x[3 * b + 1] - r[1], dz = x[3 * b + 2] - r[2];
@@ -420,7 +449,22 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                 float rew = a.specs.w_pos * r_pos + a.specs.w_rot * r_rot + a.specs.w_vel * r_vel + a.specs.w_ang_vel * r_ang;
                 const int rw = a.specs.power_reward ? 5 : 4;
                 float* raw = a.rew_raw + e * rw;
-                raw[0] = r_pos; raw[1] = r_rot; raw[2] = r_vel; raw[3] = r_ang;
+                if (a.zero_out_far) {
+                    // _compute_reward's zero_out_far branch (humanoid_im.py:870-887): compute_point_goal_reward (:1577-1582) for everyone,
+                    // half the imitation reward on top within transition_distance = 0.25 m of the reference root
+                    const float dx = root_p.x - rn_e[0], dy = root_p.y - rn_e[1], dz = root_p.z - rn_e[2];
+                    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                    const float g = fminf(prev_goal - dist, (float)(1.0 / 3.0)) * 9.0f;
+                    if (dist > 0.25f) {
+                        rew = g;
+                        raw[0] = g; raw[1] = 0.f; raw[2] = 0.f; raw[3] = 0.f;
+                    } else {
+                        rew = g + rew * 0.5f;
+                        raw[0] = g + r_pos * 0.5f; raw[1] = r_rot * 0.5f; raw[2] = r_vel * 0.5f; raw[3] = r_ang * 0.5f;
+                    }
+                } else {
+                    raw[0] = r_pos; raw[1] = r_rot; raw[2] = r_vel; raw[3] = r_ang;
+                }
                 if (a.specs.power_reward) {
                     float p = -a.specs.power_coef * pw;
                     if (prog <= 3) p = 0.0f;     // first frames are not charged (humanoid_im.py:914)
@@ -553,6 +597,14 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
         PULSE_REQUIRE(a.reset && a.terminate && a.term_dist, "pulse_im_step: null reset inputs/outputs");
         PULSE_REQUIRE(a.pass_time || a.clock_motion_len || a.cycle_motion, "pulse_im_step: reset needs pass_time or the in-kernel clock");
         PULSE_REQUIRE(a.reset_ids && a.num_reset >= 1 && a.num_reset <= kLanesPerEnv, "pulse_im_step: bad reset ids");
+    }
+    if (a.zero_out_far) {
+        PULSE_REQUIRE(a.time_steps == 1, "pulse_im_step: zero_out_far takes one reference sample (the reference broadcasts (N, 3) against (N T, 3))");
+        PULSE_REQUIRE(a.point_goal != nullptr, "pulse_im_step: zero_out_far needs point_goal");
+        PULSE_REQUIRE(a.far_distance > 0.f && a.close_distance >= 0.f, "pulse_im_step: zero_out_far needs close_distance >= 0 and far_distance > 0");
+        const int ov = a.obs_version;
+        PULSE_REQUIRE(!(a.what & PULSE_IM_TASK_OBS) || ov == 6 || ov == 7 || ov == 8 || ov == 9,
+                      "pulse_im_step: zero_out_far is defined for obs_version 6 | 7 | 8 | 9 (humanoid_im.py:761,812), not %d", ov);
     }
     if (a.use_motion) {
         const pulse_motion_tables& M = a.motion;

@@ -32,6 +32,7 @@ import torch
 
 from .. import ops
 from .. import synthetic as syn
+from . import env_keys
 from .._lib import PULSE_IM_RESET, PULSE_IM_REWARD, PULSE_IM_SELF_OBS, PULSE_IM_TASK_OBS
 
 
@@ -48,12 +49,19 @@ class Box:
 class HumanoidIm:
     def __init__(self, cfg, sim, motion_lib, device="cuda:0"):
         env = cfg.get("env", cfg)
+        if "env" in env and isinstance(env["env"], dict):                       # legacy layout (phc_*_iccv.yaml): options nested under env:
+            env = env["env"]
+        if isinstance(cfg.get("robot", None), dict):                            # robot/*.yaml switches (humanoid.py:266-280 reads cfg.robot)
+            env = dict({k: v for k, v in cfg["robot"].items() if k in ("has_upright_start", "has_dof_subset", "has_shape_obs", "has_weight_obs")}, **env)
+        env_keys.audit(env, type(self).__name__)                               # every key is honoured, inert by contract, or raises by name
         self.cfg = cfg
         self.device = torch.device(device)
         self.sim, self._motion_lib = sim, motion_lib
         self.num_envs = sim.num_envs
+        if "num_envs" in env and int(env["num_envs"]) != self.num_envs:
+            raise ValueError(f"env.num_envs = {env['num_envs']} but the injected simulator has {self.num_envs} envs")
         self.num_bodies = syn.NUM_BODIES
-        self.dt = 2.0 / 60.0                                                   # controlFrequencyInv 2 @ 60 Hz
+        self.dt = int(env.get("controlFrequencyInv", 2)) / 60.0                 # base_task.py:92-93: control_freq_inv * sim dt (1 / 60 s, sim/default_sim.yaml)
         self.obs_v = int(env.get("obs_v", 6))
         self.self_obs_v = int(env.get("self_obs_v", 1))
         if self.self_obs_v not in (1, 2, 3) or self.obs_v not in (1, 2, 3, 6, 7, 8, 9):
@@ -82,6 +90,32 @@ class HumanoidIm:
         self._enable_early_termination = bool(env.get("enableEarlyTermination", True))
         self.max_episode_length = int(env.get("episode_length", 300))
         self.cycle_motion = bool(env.get("cycle_motion", False))
+        # zero_out_far (humanoid.py:311-329; True in the PHC teacher configs phc_kp_pnn_iccv.yaml:36 & co): far envs see their own state
+        # as the reference plus a direction to walk in, and are paid for approaching it
+        self.zero_out_far = bool(env.get("zero_out_far", False))
+        self.zero_out_far_train = bool(env.get("zero_out_far_train", True))
+        self.close_distance = float(env.get("close_distance", 0.25))
+        self.far_distance = float(env.get("far_distance", 3))
+        self._zero_out_far_steps = int(env.get("zero_out_far_steps", 90))
+        if self.zero_out_far and self._fut_tracks:
+            raise NotImplementedError("zero_out_far with fut_tracks: the reference's blocks subtract an (N T, 3) reference from an (N, 3) root "
+                                      "(humanoid_im.py:765,816) and fail for T > 1")
+        if self.zero_out_far and self.obs_v not in (6, 7, 8, 9):
+            raise NotImplementedError("zero_out_far is defined for obs_v 4 | 5 | 6 | 7 | 8 | 9 (humanoid_im.py:761,812)")
+        if self.zero_out_far and self.zero_out_far_train and not self._use_motion_lib:
+            raise NotImplementedError("zero_out_far_train moves the reference by a per-env offset: needs the MotionLib reference source")
+        self.strict_eval = bool(env.get("strict_eval", False))                  # humanoid.py:320
+        self.im_eval = False                                                    # flags.im_eval (run_hydra.py:291): set by the evaluation loop
+        self.auto_pmcp = bool(env.get("auto_pmcp", False))                      # humanoid.py:318-319 -> IMAmpAgent.update_training_data
+        self.auto_pmcp_soft = bool(env.get("auto_pmcp_soft", False))
+        self.shape_resampling_interval = int(env.get("shape_resampling_interval", 100))     # humanoid.py:283 -> AMPAgent.pre_epoch
+        self.getup_schedule = bool(env.get("getup_schedule", False))            # humanoid.py:284 (HumanoidImGetup implements the schedule)
+        if self.getup_schedule and not hasattr(self, "update_getup_schedule"):
+            raise NotImplementedError("getup_schedule: AMPAgent.pre_epoch calls task.update_getup_schedule (amp_agent.py:569-570), which only the "
+                                      "get-up tasks define (humanoid_im_getup.py:67-74): use HumanoidImGetup")
+        if env.get("stateInit", "Random") not in ("Random", "Start"):
+            raise NotImplementedError(f"stateInit {env.get('stateInit')!r}: Random and Start are built (Default / Hybrid need the simulator's "
+                                      "default pose, humanoid_amp.py:447-505)")
         track = env.get("trackBodies", syn.SMPL_BODY_NAMES)
         reset = env.get("reset_bodies", syn.RESET_BODY_NAMES)
         self._track_bodies_id = torch.tensor([syn.SMPL_BODY_NAMES.index(b) for b in track], dtype=torch.int32, device=self.device)
@@ -118,6 +152,7 @@ class HumanoidIm:
         self.progress_buf = torch.zeros(n, dtype=torch.int64, device=dev)
         self._terminate_buf = torch.zeros(n, dtype=torch.int64, device=dev)
         self._cycle_counter = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._point_goal = torch.zeros(n, device=dev)                          # humanoid_im.py:84
         self._motion_start_times = torch.zeros(n, device=dev)
         self._motion_start_times_offset = torch.zeros(n, device=dev)
         self._pass_time = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -145,7 +180,10 @@ class HumanoidIm:
         # attributes the agent reaches for (amp_agent.py:59-63; common_agent.py:54); defaults of humanoid.py:105,296-345
         self.temp_running_mean = bool(env.get("temp_running_mean", True))
         self.kin_lr = float(env.get("kin_lr", 5e-4))
-        self.fitting = False
+        # fitting (humanoid.py:310; True in env_im_vae.yaml:20 and the PHC teacher configs): AMPAgent loads the normaliser statistics of
+        # models[0] and freezes them (amp_agent.py:70-76)
+        self.fitting = bool(env.get("fitting", False))
+        self.models_path = list(env.get("models", []))
         self.save_kin_info = bool(env.get("save_kin_info", False))
         self.only_kin_loss = bool(env.get("only_kin_loss", False))
         self.distill = bool(env.get("distill", False))
@@ -341,8 +379,8 @@ class HumanoidIm:
 
     def pre_physics_step(self, actions):
         self.actions = actions
-        if self.cycle_motion and self._use_motion_lib:      # the counter only ever leaves zero in cycle / zero_out_far modes
-            self._update_cycle_count()
+        if (self.cycle_motion or (self.zero_out_far and self.zero_out_far_train)) and self._use_motion_lib:
+            self._update_cycle_count()                      # (the counter only ever leaves zero in these modes)
         self.sim.set_dof_position_target_tensor(self._action_to_pd_targets(actions))
 
     def _physics_step(self):
@@ -381,6 +419,8 @@ class HumanoidIm:
         rc = self._recovery_counter_for_step()
         if rc is not None:
             extra["recovery_counter"] = rc
+        if self.zero_out_far:
+            extra["zero_out_far"] = {"point_goal": self._point_goal, "close_distance": self.close_distance, "far_distance": self.far_distance}
         # the step and the masked-reset launch repeat with the same buffers every control step: their argument structs are cached per phase
         cache = self._im_launch_cache.setdefault((what, inc, env_ids is None, env_mask is None), {})
         return ops.im_step(
@@ -389,7 +429,7 @@ class HumanoidIm:
             time_steps=self._num_traj_samples, dof_force=self.sim.dof_force, dof_vel=self.sim.dof_vel,
             progress=self.progress_buf, pass_time=self._pass_time, cycle_counter=self._cycle_counter,
             track_ids=self._track_bodies_id, reset_ids=self._reset_bodies_id, term_dist=self._termination_distances,
-            reset_use_mean=False, full_body_reward=self._full_body_reward, obs_version=self.obs_v,
+            reset_use_mean=self.im_eval and not self.strict_eval, full_body_reward=self._full_body_reward, obs_version=self.obs_v,
             local_root_obs=self._local_root_obs, root_height_obs=self._root_height_obs, specs=self.reward_specs,
             power_coef=self.power_coefficient, power_reward=self.power_reward, env_ids=env_ids, env_mask=env_mask,
             obs=self._obs_store, obs_cols=self.obs_pitch, rew=self.rew_buf, rew_raw=self.reward_raw,
@@ -413,7 +453,28 @@ class HumanoidIm:
         self._cycle_counter.masked_fill_(ended, 60)
         root = lib.get_root_pos_smpl(ids, self._motion_start_times)["root_pos"]
         xy = self.sim.rigid_body_state[:, 0, 0:2] - root[:, 0:2]
+        if self.zero_out_far and self.zero_out_far_train:       # restart up to 5 m away from the reference (:1135-1142)
+            xy = xy + self._far_start_xy()
         self._global_offset[:, 0:2] = torch.where(ended[:, None], xy, self._global_offset[:, 0:2])
+
+    def _far_start_xy(self):
+        """humanoid_im.py:937-943 / :1137-1142: a point uniform over the disc of radius max_distance = 5 m, per env (sync-free: drawn for
+        every env, the caller keeps the rows it needs).  The draws are kept for the CPU twin (column 0 -> distance, 1 -> angle)."""
+        u = torch.rand(self.num_envs, 2, device=self.device, generator=self._clock_gen)
+        self._last_far_uniforms = u
+        rand_distance = torch.sqrt(u[:, 0]) * 5
+        rand_angle = u[:, 1] * torch.pi * 2
+        return torch.stack([torch.cos(rand_angle) * rand_distance, torch.sin(rand_angle) * rand_distance], dim=-1)
+
+    def resample_motions(self):
+        """HumanoidIm.resample_motions (humanoid_im.py:350-377), called by AMPAgent.pre_epoch every shape_resampling_interval epochs: the
+        reference re-draws which AMASS clips are resident (MotionLib.load_motions under the PMCP sampling weights -- AMASS loading is out of
+        scope, so a library that can reload exposes ``load_motions``; the synthetic one keeps every clip resident) and restarts every env."""
+        if hasattr(self._motion_lib, "load_motions"):
+            self._motion_lib.load_motions()
+            if self._use_motion_lib:
+                self._motion_len_env = self._motion_lib.get_motion_length(self._sampled_motion_ids).contiguous()
+        self.reset()
 
     def _update_cycle_count(self):
         """humanoid_im.py:1042-1045, called from pre_physics_step (:1112)."""
@@ -510,6 +571,12 @@ class HumanoidIm:
                                           "zero_start_offsets": self._motion_start_times_offset, "zero_global_offset": self._global_offset})
             if hasattr(sim, "on_reset"):
                 sim.on_reset(mask)
+            if self.zero_out_far and self.zero_out_far_train:
+                # _reset_ref_state_init (humanoid_im.py:932-946): the simulated state was initialised from the motion WITHOUT an offset;
+                # now the reference moves up to 5 m away and early termination is suspended for zero_out_far_steps steps
+                xy = self._far_start_xy()
+                self._global_offset[:, 0:2] = torch.where(mask[:, None], xy, self._global_offset[:, 0:2])
+                self._cycle_counter.masked_fill_(mask, self._zero_out_far_steps)
             if self.self_obs_v == 2:
                 self._init_tensor_history(mask)
             self._compute_observations(env_mask=mask)

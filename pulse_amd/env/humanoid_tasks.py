@@ -21,6 +21,7 @@ import torch
 from .. import ops
 from .. import synthetic as syn
 from .._lib import PULSE_IM_SELF_OBS, TASK_OBS, TASK_RESET, TASK_REWARD
+from . import env_keys
 from .humanoid_z import HumanoidZ
 
 
@@ -29,10 +30,11 @@ class HumanoidTask:
 
     def __init__(self, cfg, sim, device="cuda:0"):
         env = cfg.get("env", cfg)
+        env_keys.audit(env, type(self).__name__)             # every key is honoured, inert by contract, or raises by name
         self.cfg, self.sim = cfg, sim
         self.device = torch.device(device)
         self.num_envs, self.num_bodies = sim.num_envs, syn.NUM_BODIES
-        self.dt = 2.0 / 60.0
+        self.dt = int(env.get("controlFrequencyInv", 2)) / 60.0             # base_task.py:92-93
         self._local_root_obs = bool(env.get("local_root_obs", True))
         self._root_height_obs = bool(env.get("root_height_obs", True))
         self._has_upright_start = bool(env.get("has_upright_start", True))
@@ -57,7 +59,8 @@ class HumanoidTask:
         self.progress_buf = torch.zeros(n, dtype=torch.int64, device=dev)
         self._terminate_buf = torch.zeros(n, dtype=torch.int64, device=dev)
         self._prev_root_pos = torch.zeros(n, 3, device=dev)
-        contact = env.get("contactBodies", ["R_Ankle", "L_Ankle", "R_Toe", "L_Toe"])           # env_pulse_amp.yaml contactBodies
+        # humanoid.py:237 reads contact_bodies (env_pulse_amp.yaml:63); contactBodies is the legacy spelling (phc_*_iccv.yaml)
+        contact = env.get("contact_bodies", env.get("contactBodies", ["R_Ankle", "L_Ankle", "R_Toe", "L_Toe"]))
         self._contact_body_ids = torch.tensor([syn.SMPL_BODY_NAMES.index(b) for b in contact], dtype=torch.int32, device=dev)
         self._termination_heights = torch.full((self.num_bodies,), float(env.get("terminationHeight", 0.15)), device=dev)
         self._task_gen = torch.Generator(device=dev)

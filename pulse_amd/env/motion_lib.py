@@ -70,6 +70,12 @@ class MotionLib:
         self._sampling_prob = torch.ones(self._num_motions, device=dev) / self._num_motions      # :205, uniform until re-weighted
         self._sampling_batch_prob = self._sampling_prob
         self._lengths_host = None
+        # PMCP bookkeeping over the data set's clips (motion_lib_base.py:196-206): here every clip of the tables is resident, so the
+        # "unique motions" of the data set and the loaded batch coincide
+        self._num_unique_motions = self._num_motions
+        keys = tables.get("motion_data_keys")
+        self._motion_data_keys = list(keys) if keys is not None else [str(i) for i in range(self._num_motions)]
+        self._termination_history = torch.zeros(self._num_unique_motions, device=dev)
 
     @classmethod
     def from_tables(cls, tables, device="cuda:0"):
@@ -103,6 +109,41 @@ class MotionLib:
         if motion_ids is None:
             return (self._motion_num_frames * 30 / self._motion_fps).int()
         return (self._motion_num_frames[motion_ids] * 30 / self._motion_fps).int()
+
+    # ---- PMCP sampling weights (motion_lib_base.py:348-393; IMAmpAgent.update_training_data, im_amp.py:126-132).  In the reference
+    # _sampling_prob steers which clips load_motions makes resident (:212-222) and the batch distribution follows from it; with every
+    # clip resident, load_motions here only refreshes the batch distribution from the weights.
+    def update_hard_sampling_weight(self, failed_keys):
+        """auto_pmcp: train only on the sequences that failed evaluation (:348-360)."""
+        if len(failed_keys) > 0:
+            indexes = [self._motion_data_keys.index(k) for k in failed_keys]
+            self._sampling_prob[:] = 0
+            self._sampling_prob[indexes] = 1 / len(indexes)
+        else:
+            self._sampling_prob = torch.ones(self._num_unique_motions, device=self._device) / self._num_unique_motions
+
+    def update_soft_sampling_weight(self, failed_keys):
+        """auto_pmcp_soft: sampling weight proportional to how often a sequence failed evaluation (:362-376)."""
+        if len(failed_keys) > 0:
+            indexes = [self._motion_data_keys.index(k) for k in failed_keys]
+            self._termination_history[indexes] += 1
+            self.update_sampling_prob(self._termination_history)
+        else:
+            self._sampling_prob = torch.ones(self._num_unique_motions, device=self._device) / self._num_unique_motions
+
+    def update_sampling_prob(self, termination_history):
+        """:378-384."""
+        termination_history = torch.as_tensor(termination_history, dtype=torch.float32, device=self._device)
+        if len(termination_history) == len(self._termination_history) and termination_history.sum() > 0:
+            self._sampling_prob[:] = termination_history / termination_history.sum()
+            self._termination_history = termination_history
+            return True
+        return False
+
+    def load_motions(self):
+        """The part of MotionLibBase.load_motions (:172-285) that survives when every clip is resident: the batch distribution is the
+        data-set distribution restricted to the loaded clips and renormalised (:221-222)."""
+        self._sampling_batch_prob = self._sampling_prob / self._sampling_prob.sum()
 
     def sample_motions(self, n, generator=None):
         return torch.multinomial(self._sampling_batch_prob, num_samples=n, replacement=True, generator=generator).to(self._device)

@@ -96,6 +96,15 @@ class AMPAgent(CommonAgent):
             self.kin_exp_avg_sq = torch.zeros(n, device=self.ppo_device)
             self.kin_step = 0
             self.kin_dict_info = None
+        if getattr(task, "fitting", False):
+            # amp_agent.py:70-76: distillation needs the TEACHER's observation statistics: load the normalisers of env.models[0], freeze
+            # them, and take every network tensor whose name and shape match (load_my_state_dict, :27-33)
+            if not getattr(task, "models_path", None):
+                raise ValueError("env.fitting is set but env.models names no checkpoint to take the normaliser statistics from")
+            checkpoint = torch.load(task.models_path[0], map_location=self.ppo_device)
+            self.set_stats_weights(checkpoint)
+            self.freeze_state_weights()
+            self._load_matching_state(checkpoint["model"])
         self.running_mean_std_temp = self.running_mean_std.clone_frozen()
         self._disc_ring, self._disc_info_all, self._disc_pos = None, None, 0
         self.z_noise_provider = None                                      # tests inject the re-parameterisation noise
@@ -305,6 +314,32 @@ class AMPAgent(CommonAgent):
             if weights["amp_input_mean_std"]["running_mean"].shape == self._amp_input_mean_std.running_mean.shape:
                 self._amp_input_mean_std.load_state_dict(weights["amp_input_mean_std"])
 
+    def freeze_state_weights(self):
+        """amp_agent.py:123-131."""
+        if self.normalize_input:
+            self.running_mean_std.freeze()
+        if self.normalize_value:
+            self.value_mean_std.freeze()
+        if self.mixed_precision:
+            raise NotImplementedError("the reference raises for fitting with mixed_precision (amp_agent.py:130-131)")
+
+    def unfreeze_state_weights(self):
+        """amp_agent.py:133-141."""
+        if self.normalize_input:
+            self.running_mean_std.unfreeze()
+        if self.normalize_value:
+            self.value_mean_std.unfreeze()
+
+    def _load_matching_state(self, saved):
+        """load_my_state_dict (amp_agent.py:27-33): copy the saved tensors whose name exists here with the same shape; skip the rest."""
+        own = self.model.state_dict()
+        own.update({k: v for k, v in saved.items() if k in own and tuple(own[k].shape) == tuple(v.shape)})
+        self.model.load_state_dict(own)
+        if self.enable_disc:
+            own = self.disc.state_dict()
+            own.update({k: v for k, v in saved.items() if k in own and tuple(own[k].shape) == tuple(v.shape)})
+            self.disc.load_state_dict(own)
+
     def get_full_state_weights(self):
         """The reference's checkpoint dict: 'model' holds EVERY a2c_network.* tensor (policy, critic, discriminator) under
         the reference's names, the normalisers sit next to it.  The Adam moments are stored as flat buffers (the reference
@@ -339,6 +374,18 @@ class AMPAgent(CommonAgent):
 
     # ------------------------------------------------------------------ epoch hooks (amp_agent.py:557-583)
     def pre_epoch(self, epoch_num):
+        """amp_agent.py:557-579: motions re-drawn every shape_resampling_interval epochs, the get-up schedule (which also switches the
+        task / discriminator reward weights), then the frozen copy of the observation normaliser."""
+        task = self.vec_env.env.task
+        interval = int(getattr(task, "shape_resampling_interval", 0) or 0)
+        if interval > 0 and epoch_num > 1 and epoch_num % interval == 1 and hasattr(task, "resample_motions"):
+            task.resample_motions()
+        if getattr(task, "getup_schedule", False):
+            task.update_getup_schedule(epoch_num, getup_udpate_epoch=task.getup_udpate_epoch)
+            if epoch_num > task.getup_udpate_epoch:
+                self._task_reward_w, self._disc_reward_w = 0.5, 0.5
+            else:
+                self._task_reward_w, self._disc_reward_w = 0.0, 1.0
         self.running_mean_std_temp = self.running_mean_std.clone_frozen()
 
     def post_epoch(self, epoch_num):

@@ -60,20 +60,19 @@ class IMAmpAgent(AMPAgent):
             newest = sorted(fails, key=lambda x: int(x.split("_")[-1].split(".")[0]))[-1]
             with open(newest, "rb") as f:
                 history = pickle.load(f)["termination_history"]
-            lib = self.vec_env.env.task._motion_lib
-            if hasattr(lib, "update_sampling_prob"):
-                lib.update_sampling_prob(history)
+            self.vec_env.env.task._motion_lib.update_sampling_prob(history)
 
     def update_training_data(self, failed_keys):
         task = self.vec_env.env.task
         lib = task._motion_lib
-        if getattr(task, "auto_pmcp", False) and hasattr(lib, "update_hard_sampling_weight"):
+        # (no hasattr guards: a motion source without the PMCP hooks fails loudly instead of silently training on the old weights)
+        if task.auto_pmcp:
             lib.update_hard_sampling_weight(failed_keys)
-        elif getattr(task, "auto_pmcp_soft", False) and hasattr(lib, "update_soft_sampling_weight"):
+        elif task.auto_pmcp_soft:
             lib.update_soft_sampling_weight(failed_keys)
         os.makedirs(self.network_path, exist_ok=True)
         with open(osp.join(self.network_path, f"failed_{self.epoch_num:010d}.pkl"), "wb") as f:
-            pickle.dump({"failed_keys": failed_keys, "termination_history": getattr(lib, "_termination_history", None)}, f)
+            pickle.dump({"failed_keys": failed_keys, "termination_history": lib._termination_history}, f)
 
     # ------------------------------------------------------------------ im_amp.py:136-363 (metrics: see module docstring)
     def eval(self, max_steps=None):

@@ -218,8 +218,11 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
             root_height_obs=True, specs=None, power_coef=0.0005, power_reward=True,
             env_ids=None, env_mask=None, obs=None, obs_cols=None, rew=None, rew_raw=None, reset=None,
             terminate=None, clock=None, motion=None, upright=True, enable_early_termination=True, self_obs_version=1,
-            force_sensor=None, dof_pos=None, ref_next_dof_pos=None, smpl_params=None, limb_weights=None, recovery_counter=None, cache=None):
-    """``cache``: a dict owned by a caller that launches the same step on the same buffers over and over (the env's post-physics step): the
+            force_sensor=None, dof_pos=None, ref_next_dof_pos=None, smpl_params=None, limb_weights=None, recovery_counter=None, cache=None,
+            zero_out_far=None):
+    """``zero_out_far``: dict(point_goal (N,) float32 read by the reward stage / written by the task-observation stage, close_distance,
+    far_distance) -- the far-masking branch of _compute_task_obs / _compute_reward (humanoid_im.py:763-777, 814-826, 870-887).
+    ``cache``: a dict owned by a caller that launches the same step on the same buffers over and over (the env's post-physics step): the
     filled argument struct is kept in it and re-launched as long as the arguments' signature (_launch_sig) does not change -- the struct takes
     ~40 tensor checks to build, a third of the rollout's host time.
     ``clock``: dict(progress_rw, inc, dt, start_times, start_offsets, motion_len, cycle_motion, max_episode_length,
@@ -233,7 +236,7 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         sig = _launch_sig((rb, what, ref_now, ref_next, time_steps, dof_force, dof_vel, progress, pass_time, cycle_counter, track_ids, reset_ids, term_dist,
                            reset_use_mean, full_body_reward, obs_version, local_root_obs, root_height_obs, specs, power_coef, power_reward, env_ids, env_mask,
                            obs, obs_cols, rew, rew_raw, reset, terminate, clock, motion, upright, enable_early_termination, self_obs_version, force_sensor,
-                           dof_pos, ref_next_dof_pos, smpl_params, limb_weights, recovery_counter, _IM_DEBUG_BITS))
+                           dof_pos, ref_next_dof_pos, smpl_params, limb_weights, recovery_counter, zero_out_far, _IM_DEBUG_BITS))
         if cache.get("sig") == sig:
             _lib.check(lib.pulse_im_step(ctypes.byref(cache["args"]), _stream()), "pulse_im_step")
             return cache["out"]
@@ -288,6 +291,12 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
             fsw += t.shape[1]
     if recovery_counter is not None:
         a.recovery_counter = P(recovery_counter, "recovery_counter", torch.int32)
+    if zero_out_far is not None:
+        pg = zero_out_far["point_goal"]
+        if pg.shape != (n,) or not pg.is_contiguous():
+            raise ValueError("zero_out_far.point_goal: contiguous (num_envs,) float32 expected")
+        a.zero_out_far, a.point_goal = 1, P(pg, "zero_out_far.point_goal")
+        a.close_distance, a.far_distance = float(zero_out_far.get("close_distance", 0.25)), float(zero_out_far.get("far_distance", 3.0))
     a.dof_pos, a.ref_next_dof_pos = P(dof_pos, "dof_pos"), P(ref_next_dof_pos, "ref_next_dof_pos")
     if dof_pos is not None and dof_force is None:
         a.num_dof = dof_pos.shape[-1]

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 24
+#define PULSE_ABI_VERSION 25
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -541,6 +541,14 @@ typedef struct pulse_gemm_desc {
        accumulated in fp32.  fp32-grade results (same tolerances as PULSE_GEMM_COMPUTE_F32, same exactness / linearity
        properties) at up to 2.67x the fp32 MFMA rate of gfx950.  Inputs must be finite. */
     int32_t compute_type; int32_t round_output_bf16;
+    /* optional (v25): the ReLU derivative as a BIT mask instead of a second pass over the activation matrix.  A forward launch
+       (PULSE_EPI_BIAS_ACT + PULSE_ACT_RELU) with relu_mask != NULL also records which outputs are positive; a PULSE_EPI_RELU_GRAD launch with
+       aux == NULL and relu_mask != NULL takes C = acc * (bit set) -- the same values as with aux = the forward's output (h > 0 <=> z > 0), at
+       1/32 of the aux traffic (nn.ReLU's backward, network_builder.py:105-124 / amp_network_builder.py:230-249 through autograd).
+       Layout (independent of the tiling that writes or reads it): 32-bit word [((r >> 6) * 8 + (r & 7)) * ld_mask + (c >> 2)] of batch z's
+       mask (relu_mask + z * stride_mask words), bit 4 * ((r >> 3) & 7) + (c & 3) <-> output (r, c).  The buffer holds
+       roundup64(M) / 8 * ld_mask words per batch-strided matrix, ld_mask >= roundup4(N) / 4; needs 16-byte aligned C / pitches. */
+    uint32_t* relu_mask; int32_t ld_mask; int64_t stride_mask;
 } pulse_gemm_desc;
 
 int pulse_sizeof_gemm_desc(void);

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -212,6 +212,7 @@ class GemmDesc(Structure):
         ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
         ("rowsum", c_void_p), ("stride_rowsum", c_int64),
         ("compute_type", c_int32), ("round_output_bf16", c_int32),
+        ("relu_mask", c_void_p), ("ld_mask", c_int32), ("stride_mask", c_int64),
     ]
 
 

@@ -139,6 +139,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
     float* C = g.C + bz * g.sC + sp * g.sSplit;
     float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
     const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+    unsigned* mask = g.mask ? g.mask + bz * g.sMask : nullptr;     // ReLU bit mask: written by the relu forward, read by relu-grad when aux is null
+    const bool use_mask = g.epi == 1 && aux == nullptr;
 
     // The accumulators are transposed through LDS (the staging buffers are free after the main loop) so every global access of the vector
     // epilogue is a 16-byte access covering 512 contiguous bytes of one row per half-wave.  The scalar path (unaligned pitches) reads the
@@ -148,7 +150,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
     const int c4 = (tid & 31) * 4;
     const int rl0 = tid >> 5;
     f32x4 ax[8 * WM];
-    if (fast && g.epi != 0) {                  // relu-grad / multiply-by-aux: the 16 aux loads fly while the accumulators go through LDS
+    unsigned mw[WM];                           // this thread's mask words: rows rl0 + 8 q of 64-row block b = q / 8, columns c4 .. c4 + 3
+    if (fast && use_mask) {
+#pragma unroll
+        for (int b = 0; b < WM; ++b) mw[b] = mask[mask_word(m0 + 64 * b + rl0, (n0 + c4) >> 2, g.ldmask)];
+    } else if (fast && g.epi != 0) {           // relu-grad / multiply-by-aux: the 16 aux loads fly while the accumulators go through LDS
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
                                                                             0xffffffffu, RSRC_FLAGS);
         const int voX = (rl0 * g.ldaux + c4) * 4;
@@ -174,10 +180,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
             const int ldsC = (rl0 * CP + c4) * 4;
             if (g.epi == 0) {
                 const bool relu = g.act == 1;
+                const bool wmask = relu && mask != nullptr;
+                unsigned w = 0;
 #pragma unroll
                 for (int q = 0; q < 8 * WM; ++q) {
                     f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
+                    if (wmask) {
+                        w |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * (q & 7));
+                        if ((q & 7) == 7) { mask[mask_word(m0 + 64 * (q >> 3) + rl0, (n0 + c4) >> 2, g.ldmask)] = w; w = 0; }
+                    }
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                }
+            } else if (use_mask) {
+#pragma unroll
+                for (int q = 0; q < 8 * WM; ++q) {
+                    const unsigned nb = mw[q >> 3] >> (4 * (q & 7));
+                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
+                    v.x = (nb & 1u) ? v.x : 0.f; v.y = (nb & 2u) ? v.y : 0.f; v.z = (nb & 4u) ? v.z : 0.f; v.w = (nb & 8u) ? v.w : 0.f;
                     buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
                 }
             } else if (g.epi == 1) {
@@ -202,13 +222,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
         const int col = n0 + c4;
         if (col < g.N) {
             const bool full = col + 3 < g.N;
+            const bool wmask = g.epi == 0 && g.act == 1 && mask != nullptr;
+            unsigned w = 0;
 #pragma unroll 4
             for (int q = 0; q < 8 * WM; ++q) {
                 const int rl = rl0 + 8 * q;
                 const int row = m0 + rl;
-                if (row >= g.M) continue;
+                // ragged tiles: the word of a 64-row block is stored after its last row slot (rows past M contribute zero bits; the buffer
+                // covers roundup64(M) rows), and read once at the block's first slot
+                if (use_mask && (q & 7) == 0 && m0 + 64 * (q >> 3) < g.M) w = mask[mask_word(m0 + 64 * (q >> 3) + rl0, col >> 2, g.ldmask)];
+                if (row >= g.M) {
+                    if (wmask && (q & 7) == 7 && m0 + 64 * (q >> 3) < g.M) { mask[mask_word(m0 + 64 * (q >> 3) + rl0, col >> 2, g.ldmask)] = w; w = 0; }
+                    continue;
+                }
                 float4 v = *reinterpret_cast<const float4*>(sC + rl * CP + c4);
                 float o[4] = {v.x, v.y, v.z, v.w};
+                if (wmask) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w |= (col + k < g.N && o[k] > 0.f ? 1u : 0u) << (4 * (q & 7) + k);
+                    if ((q & 7) == 7) { mask[mask_word(m0 + 64 * (q >> 3) + rl0, col >> 2, g.ldmask)] = w; w = 0; }
+                }
+                if (use_mask) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = ((w >> (4 * (q & 7) + k)) & 1u) ? o[k] : 0.f;
+                    float* pc = C + (long long)row * g.ldc + col;
+                    if (full) *reinterpret_cast<float4*>(pc) = make_float4(o[0], o[1], o[2], o[3]);
+                    else for (int k = 0; k < 4 && col + k < g.N; ++k) pc[k] = o[k];
+                    continue;
+                }
                 if (g.epi == 0) {
                     if (g.act == 1) {
 #pragma unroll
@@ -1212,7 +1253,11 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     PULSE_REQUIRE(d->epilogue >= 0 && d->epilogue <= 3 && d->activation >= 0 && d->activation <= 3, "pulse_gemm_f32: bad epilogue / activation");
     PULSE_REQUIRE(d->activation != PULSE_ACT_SILU_D || (d->C2 != nullptr && d->ldc2 >= d->N), "pulse_gemm_f32: ACT_SILU_D stores the derivative in C2");
     PULSE_REQUIRE(d->epilogue == 0 || d->activation == 0, "pulse_gemm_f32: a gradient epilogue takes no activation");
-    PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr, "pulse_gemm_f32: gradient epilogue needs aux");
+    PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr || (d->epilogue == PULSE_EPI_RELU_GRAD && d->relu_mask != nullptr),
+                  "pulse_gemm_f32: gradient epilogue needs aux (or, for relu-grad, relu_mask)");
+    const bool mask_on = d->relu_mask != nullptr && ((d->epilogue == PULSE_EPI_RELU_GRAD && d->aux == nullptr) ||
+                                                     (d->epilogue == PULSE_EPI_BIAS_ACT && d->activation == PULSE_ACT_RELU));
+    PULSE_REQUIRE(!mask_on || (d->ld_mask >= (d->N + 3) / 4 && d->split_k == 1), "pulse_gemm_f32: relu_mask needs ld_mask >= roundup4(N) / 4 and no split-K");
     PULSE_REQUIRE(d->rowsum == nullptr || (!akc && !bkc), "pulse_gemm_f32: rowsum needs the (OUT, OUT) layouts (dW pass)");
     PULSE_REQUIRE(d->split_k == 1 || (d->epilogue == 0 && d->activation == 0 && d->bias == nullptr),
                   "pulse_gemm_f32: split-K slabs carry no epilogue");
@@ -1230,6 +1275,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     g.sSplit = d->split_stride;
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
+    g.mask = mask_on ? d->relu_mask : nullptr; g.ldmask = d->ld_mask; g.sMask = d->stride_mask;
     g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     // x3 only: a 64-row tile for skinny outputs (one column tile: the mu / value heads) whose 128-row tiling leaves the chip at one
     // workgroup per CU or less.  Measured: heads at M = 16384 36.2 -> 32.8 us, at M = 4096 28.5 -> 21.6 us; full-width outputs at the same
@@ -1250,6 +1296,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     auto al16 = [](const void* p, long long ld, long long st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0 && (st % 4) == 0; };
     g.vec_epi = al16(d->C, d->ldc, d->stride_c) && (d->split_stride % 4) == 0 && (!d->aux || al16(d->aux, d->ldaux, d->stride_aux)) &&
                 (!d->C2 || al16(d->C2, d->ldc2, d->stride_c2)) && (!d->bias || al16(d->bias, 4, d->stride_bias));
+    PULSE_REQUIRE(!mask_on || g.vec_epi, "pulse_gemm_f32: relu_mask needs 16-byte aligned C / pitches (a lane owns four columns of a mask word)");
     const size_t lds = (size_t)(x3 ? X_LDS : LDS_BYTES) + (size_t)g_opt[1];   // 65,536 / 66,048 B -> two workgroups per CU
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d->batch * d->split_k));
     // The 64.5 KiB dynamic-LDS opt-in is a per-function attribute: set it ONCE per instantiation (calling

@@ -25,7 +25,11 @@ struct GemmArgs {
     float* rowsum; long long sRowsum;          // <MC,MC> only: per-slab sums over k of A(k, m)  (bias gradient)
     long long* dbg;                            // optional per-workgroup clock stamps (tools/gemm_bench --clocks)
     int round_bf16;                            // outputs rounded to bf16-representable values (bf16 autocast semantics)
+    unsigned* mask; int ldmask; long long sMask;   // ReLU bit mask (pulse_gemm_desc.relu_mask): written by EPI 0 + relu, read by EPI 1 when aux is null
 };
+
+// word of the ReLU bit mask that holds output row r (within its 64-row block: rows r, r + 8, .., r + 56 share a word), column group cg = col / 4
+__device__ __forceinline__ long long mask_word(int r, int cg, int ldmask) { return (long long)((r >> 6) * 8 + (r & 7)) * ldmask + cg; }
 
 __device__ __forceinline__ int slot_of(int out) { return out ^ ((out >> 3) & 7); }
 

@@ -165,11 +165,13 @@ struct StagerW {
 // ---- epilogue: one 256 x 128 pass through the LDS image (pitch W_CP floats).  Image column c holds tile column (c >> 6) * 128 + 64 pass + (c & 63) --------
 __device__ __forceinline__ int w_tile_col(int c, int pass) { return ((c >> 6) << 7) + 64 * pass + (c & 63); }
 
-__device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int tid, int m0, int n0, float* C, float* C2, const float* aux) {
+__device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int tid, int m0, int n0, float* C, float* C2, const float* aux, unsigned* mask) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int c4 = (tid & 31) * 4;               // image column of this thread's four values
     const int tc = w_tile_col(c4, pass);         // tile column
     const int rl0 = tid >> 5;                    // 8 rows per sweep, 32 sweeps
+    const bool use_mask = g.epi == 1 && aux == nullptr;      // relu-grad from the forward's bit mask (gemm_shared.h: mask_word)
+    const int cg = (n0 + tc) >> 2;
     if (g.vec_epi) {
         const bool fast = m0 + WT <= g.M && n0 + WT <= g.N && (g.epi == 1 || g.epi == 3 || (g.epi == 0 && g.act < 2));
         if (fast) {
@@ -178,11 +180,30 @@ __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int ti
             const int ldsC = (rl0 * W_CP + c4) * 4;
             if (g.epi == 0) {
                 const bool relu = g.act == 1;
+                const bool wmask = relu && mask != nullptr;
+                unsigned w = 0;
 #pragma unroll 8
                 for (int q = 0; q < 32; ++q) {
                     f32x4 v = lds_read(ldsC + q * 8 * W_CP * 4);
+                    if (wmask) {
+                        w |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * (q & 7));
+                        if ((q & 7) == 7) { mask[mask_word(m0 + 64 * (q >> 3) + rl0, cg, g.ldmask)] = w; w = 0; }
+                    }
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                }
+            } else if (use_mask) {
+#pragma unroll 1
+                for (int b = 0; b < 4; ++b) {                                      // one mask word per 64-row block of this thread's column group
+                    const unsigned mw = mask[mask_word(m0 + 64 * b + rl0, cg, g.ldmask)];
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const int q = 8 * b + qq;
+                        const unsigned nb = mw >> (4 * qq);
+                        f32x4 v = lds_read(ldsC + q * 8 * W_CP * 4);
+                        v.x = (nb & 1u) ? v.x : 0.f; v.y = (nb & 2u) ? v.y : 0.f; v.z = (nb & 4u) ? v.z : 0.f; v.w = (nb & 8u) ? v.w : 0.f;
+                        buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
+                    }
                 }
             } else {
                 const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
@@ -208,13 +229,33 @@ __device__ __forceinline__ void w_store_pass(const GemmArgs& g, int pass, int ti
         const int col = n0 + tc;
         if (col < g.N) {
             const bool full = col + 3 < g.N;
+            const bool wmask = g.epi == 0 && g.act == 1 && mask != nullptr;
+            unsigned w = 0;
 #pragma unroll 4
             for (int q = 0; q < 32; ++q) {
                 const int rl = rl0 + 8 * q;
                 const int row = m0 + rl;
-                if (row >= g.M) continue;
+                // ragged tiles: a 64-row block's word is read at its first row slot / stored after its last one (rows past M: zero bits)
+                if (use_mask && (q & 7) == 0 && m0 + 64 * (q >> 3) < g.M) w = mask[mask_word(m0 + 64 * (q >> 3) + rl0, cg, g.ldmask)];
+                if (row >= g.M) {
+                    if (wmask && (q & 7) == 7 && m0 + 64 * (q >> 3) < g.M) { mask[mask_word(m0 + 64 * (q >> 3) + rl0, cg, g.ldmask)] = w; w = 0; }
+                    continue;
+                }
                 const float4 v = *reinterpret_cast<const float4*>(smem + rl * W_CP + c4);
                 float o[4] = {v.x, v.y, v.z, v.w};
+                if (wmask) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w |= (col + k < g.N && o[k] > 0.f ? 1u : 0u) << (4 * (q & 7) + k);
+                    if ((q & 7) == 7) { mask[mask_word(m0 + 64 * (q >> 3) + rl0, cg, g.ldmask)] = w; w = 0; }
+                }
+                if (use_mask) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = ((w >> (4 * (q & 7) + k)) & 1u) ? o[k] : 0.f;
+                    float* pc = C + (long long)row * g.ldc + col;
+                    if (full) *reinterpret_cast<float4*>(pc) = make_float4(o[0], o[1], o[2], o[3]);
+                    else for (int k = 0; k < 4 && col + k < g.N; ++k) pc[k] = o[k];
+                    continue;
+                }
                 if (g.epi == 0) {
                     if (g.act == 1) {
 #pragma unroll
@@ -479,6 +520,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         float* C = g.C + bz * g.sC + sp * g.sSplit;
         float* C2 = g.C2 ? g.C2 + bz * g.sC2 : nullptr;
         const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+        unsigned* mask = g.mask ? g.mask + bz * g.sMask : nullptr;
         const int img = lb + ((wm * 128 + l31) * W_CP + wn * 64 + 4 * half) * 4;
         __syncthreads();                                          // the image overlays the staging buffers
 #pragma unroll
@@ -494,7 +536,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                         lds_st<f32x4>(img + (i * 32 * W_CP + jj * 32 + 8 * gq) * 4, (f32x4){t[4 * gq], t[4 * gq + 1], t[4 * gq + 2], t[4 * gq + 3]});
                     }
             __syncthreads();
-            w_store_pass(g, pass, tid, m0, n0, C, C2, aux);
+            w_store_pass(g, pass, tid, m0, n0, C, C2, aux, mask);
         }
     }
     if (g.dbg && tid == 0) {

@@ -78,8 +78,10 @@ def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG,
                    activation=ACT_NONE, epilogue=EPI_BIAS_ACT, aux=None, ldaux=0, C2=None, ldc2=0, batch=1, stride_a=0,
                    stride_b=0, stride_c=0, stride_c2=0, stride_bias=0, stride_aux=0, split_k=1, split_stride=0,
                    a_off=0, b_off=0, c_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None, rowsum=None, rowsum_off=0,
-                   stride_rowsum=0, compute_bf16=False, f32_mode=None):
-    """Build (descriptor, algorithmic FLOPs, variant tag) once; launch many times with launch_gemm."""
+                   stride_rowsum=0, compute_bf16=False, f32_mode=None, relu_mask=None, ld_mask=0, stride_mask=0, mask_off=0):
+    """Build (descriptor, algorithmic FLOPs, variant tag) once; launch many times with launch_gemm.
+    ``relu_mask``: int32 tensor (alloc_relu_mask) -- a relu forward records the sign bits there, a relu-grad launch with aux=None reads them
+    (pulse_hip.h: pulse_gemm_desc.relu_mask); ld_mask / stride_mask / mask_off in 32-bit words."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -95,6 +97,10 @@ def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG,
     d.split_k, d.split_stride, d.activation, d.epilogue = split_k, split_stride, activation, epilogue
     d.rowsum = (rowsum.data_ptr() + 4 * rowsum_off) if rowsum is not None else None
     d.stride_rowsum = stride_rowsum
+    if relu_mask is not None:
+        if relu_mask.dtype != torch.int32:
+            raise TypeError("relu_mask must be an int32 tensor (alloc_relu_mask)")
+        d.relu_mask, d.ld_mask, d.stride_mask = relu_mask.data_ptr() + 4 * mask_off, int(ld_mask), int(stride_mask)
     # bf16 MFMA with fp32 storage (bf16 autocast over fp32 master weights); split-K slabs are partial sums and stay unrounded
     x3 = (not compute_bf16) and (f32_mode or F32_MODE) == "x3"
     d.compute_type = _lib.GEMM_COMPUTE_BF16 if compute_bf16 else (_lib.GEMM_COMPUTE_F32X3 if x3 else _lib.GEMM_COMPUTE_F32)
@@ -106,6 +112,12 @@ def make_gemm_desc(A, B, C, *, M, N, K, lda, ldb, ldc, a_layout=GEMM_RED_CONTIG,
         tag = "x3_" + tag
     flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
     return d, flops, tag
+
+
+def alloc_relu_mask(rows, cols, device):
+    """The ReLU bit mask of a (rows, cols) activation matrix (pulse_gemm_desc.relu_mask): (roundup64(rows) / 8, roundup4(cols) / 4) int32,
+    ld_mask = its row pitch in words.  1 bit per activation: 1/32 of the fp32 matrix a relu-grad epilogue would otherwise re-read."""
+    return torch.zeros((rows + 63) // 64 * 8, (cols + 3) // 4, dtype=torch.int32, device=device)
 
 
 def dw_split(tiles, max_split, fill=512):

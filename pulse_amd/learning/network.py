@@ -30,6 +30,10 @@ from .. import kernels as K
 from .._lib import ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG
 
 
+# PULSE_RELU_BITMASK=0: the input-gradient launches re-read the fp32 activations (A/B switch; same bits either way)
+RELU_BITMASK = os.environ.get("PULSE_RELU_BITMASK", "1") != "0"
+
+
 def _r4(x):
     return (x + 3) // 4 * 4
 
@@ -254,7 +258,13 @@ class A2CNetwork:
                     self._wt16 = [None] + [i16(2 * u[l - 1], u[l]) for l in range(1, len(u))]     # W_l^T of both nets: (2, u_{l-1}, u_l)
                 ws["plan_fwd_train"] = self._plan_forward_b16(ws, m)
             else:
-                ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, bf16=True) if self.mixed_precision else ws["plan_fwd"]
+                # ReLU nets: the training forward also records each hidden activation's sign bits (1 bit per element), and the input-gradient
+                # launches mask with those instead of re-reading the fp32 activation matrix (134 MB per layer-1-wide launch at cfg2)
+                if self.act == ACT_RELU and not self.mixed_precision and RELU_BITMASK:
+                    ws["hmask"] = [K.alloc_relu_mask(m, 2 * uu, dev) for uu in u]
+                    ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, masks=True)
+                else:
+                    ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, bf16=True) if self.mixed_precision else ws["plan_fwd"]
                 ws["dh"] = [e(m, 2 * uu) for uu in u]
             if self._slabs is None:
                 # twice split_k slabs: the upper layers' weight gradients are small outputs over a long reduction and fill the chip on the 256 x 256
@@ -357,11 +367,14 @@ class A2CNetwork:
             p.call_partial_reduce(cs[l], cs[l].shape[0], 2 * uu, slabs, self.b_off[l])
         return p
 
-    def _plan_forward(self, ws, m, n0, cnt, bf16=False, planar=False):
-        """nets n0 .. n0+cnt-1 (0 = actor, 1 = critic)."""
+    def _plan_forward(self, ws, m, n0, cnt, bf16=False, planar=False, masks=False):
+        """nets n0 .. n0+cnt-1 (0 = actor, 1 = critic).  ``masks``: the hidden layers also write their ReLU bit masks (ws['hmask'])."""
         u, f = self.units, self.flat
         pre = ws.get("z")
         p = K.Plan(bf16=bf16)
+        hm = ws["hmask"] if masks else None
+        mk = lambda l, net0, per_net: ({} if hm is None else
+                                       dict(relu_mask=hm[l], ld_mask=hm[l].stride(0), mask_off=net0 * (u[l] // 4), stride_mask=u[l] // 4 if per_net else 0))
         for l, uu in enumerate(u):
             k = self.in_w[l]
             if l == 0 and planar:
@@ -376,13 +389,13 @@ class A2CNetwork:
             elif l == 0:   # both nets read the same input: one GEMM of N = cnt*u1
                 p.gemm(ws["x"], f, ws["h"][0], M=m, N=cnt * uu, K=k, lda=k, ldb=k, ldc=2 * uu, bias=f, activation=self.act,
                        algo_k=self.in_dim, b_off=self.w_off[0] + n0 * uu * k, bias_off=self.b_off[0] + n0 * uu, c_off=n0 * uu,
-                       C2=pre[0] if pre else None, ldc2=2 * uu, c2_off=n0 * uu)
+                       C2=pre[0] if pre else None, ldc2=2 * uu, c2_off=n0 * uu, **mk(0, n0, False))
             else:
                 up = u[l - 1]
                 p.gemm(ws["h"][l - 1], f, ws["h"][l], M=m, N=uu, K=up, lda=2 * up, ldb=up, ldc=2 * uu, bias=f, activation=self.act,
                        batch=cnt, stride_a=up, stride_b=uu * up, stride_c=uu, stride_bias=uu,
                        a_off=n0 * up, b_off=self.w_off[l] + n0 * uu * up, bias_off=self.b_off[l] + n0 * uu, c_off=n0 * uu,
-                       C2=pre[l] if pre else None, ldc2=2 * uu, stride_c2=uu, c2_off=n0 * uu)
+                       C2=pre[l] if pre else None, ldc2=2 * uu, stride_c2=uu, c2_off=n0 * uu, **mk(l, n0, True))
         uL, ap, hr = u[-1], self.a_pitch, self.head_rows
         # heads (batched: mu from the actor half of h_L, value from the critic half)
         p.gemm(ws["h"][-1], f, ws["heads"], M=m, N=hr, K=uL, lda=2 * uL, ldb=uL, ldc=2 * ap, bias=f, batch=cnt, stride_a=uL,
@@ -402,7 +415,8 @@ class A2CNetwork:
                 K.to_b16(ws["x"], ws["x16"])
             ws["plan_fwd_train"].run()
             return
-        (ws["plan_fwd_train"] if (self.training and "plan_fwd_train" in ws) else ws["plan_fwd"]).run()
+        # (a workspace with ReLU bit masks always runs the mask-writing plan: its backward must never see the masks of an older forward)
+        (ws["plan_fwd_train"] if ((self.training or "hmask" in ws) and "plan_fwd_train" in ws) else ws["plan_fwd"]).run()
 
     def _take_planes(self, ws):
         """True once per normaliser pass that also wrote ws['xp'] (the caller raised ws['xp_fresh']); anyone who fills ws['x'] by other
@@ -424,6 +438,12 @@ class A2CNetwork:
         egrad = EPI_RELU_GRAD if self.act == ACT_RELU else EPI_SILU_GRAD
         aux = ws["h"] if self.act == ACT_RELU else ws["z"]
         p = K.Plan(bf16=self.mixed_precision)
+        hm = ws.get("hmask")                 # ReLU bit masks the training forward wrote: the input-gradient epilogues read 1 bit, not 4 bytes, per element
+
+        def deriv(l):
+            if hm is not None:
+                return dict(relu_mask=hm[l], ld_mask=hm[l].stride(0), stride_mask=u[l] // 4)
+            return dict(aux=aux[l], ldaux=2 * u[l], stride_aux=u[l])
 
         dhd = ws["dheads"]
         # Order: the whole dX chain first, then the layer-1 weight gradient -- the largest GEMM and the largest gradient bucket
@@ -432,13 +452,12 @@ class A2CNetwork:
         # (the forward order of the weight-gradient GEMMs does not matter: nothing consumes them before the optimiser).
         # heads -> dH_L for both nets in one launch (activation derivative fused)
         p.gemm(dhd, f, ws["dh"][-1], M=m, N=uL, K=hr, lda=2 * ap, ldb=uL, ldc=2 * uL, b_layout=GEMM_OUT_CONTIG, batch=2,
-               stride_a=ap, stride_b=hr * uL, stride_c=uL, stride_aux=uL, b_off=self.wh_off, epilogue=egrad, aux=aux[-1],
-               ldaux=2 * uL, algo_k=(self.actions_num + 1) / 2.0)
+               stride_a=ap, stride_b=hr * uL, stride_c=uL, b_off=self.wh_off, epilogue=egrad, algo_k=(self.actions_num + 1) / 2.0,
+               **deriv(L - 1))
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
             p.gemm(ws["dh"][l], f, ws["dh"][l - 1], M=m, N=up, K=uu, lda=2 * uu, ldb=up, ldc=2 * up, b_layout=GEMM_OUT_CONTIG,
-                   batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad,
-                   aux=aux[l - 1], ldaux=2 * up, stride_aux=up)
+                   batch=2, stride_a=uu, stride_b=uu * up, stride_c=up, b_off=self.w_off[l], epilogue=egrad, **deriv(l - 1))
         p.split_dx = len(p.ops)             # everything before this point is the input-gradient chain; the weight gradients after it are independent of each other
         # weight gradients; the bias gradients (column sums of dz) ride along as the GEMM's per-slab row sums
         uu, k = u[0], self.in_w[0]

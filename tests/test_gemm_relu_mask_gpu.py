@@ -1,0 +1,115 @@
+"""The ReLU bit mask of pulse_gemm_f32 (pulse_gemm_desc.relu_mask, ABI v25): a relu forward records one bit per output, a relu-grad launch
+with aux = None masks with those bits -- nn.ReLU's backward (phc/learning/network_builder.py:105-124, amp_network_builder.py:230-249) at 1/32
+of the traffic of re-reading the activation matrix.
+
+  * the mask IS (h > 0), bit for bit, in the documented layout, whatever tiling wrote it (64-row, 128 x 128, 256 x 256, fp32-MFMA kernel);
+  * a relu-grad launch reading the mask gives BIT-IDENTICAL results to the one reading aux = h, across tilings (writer and reader need not
+    use the same one), on ragged shapes and batched (actor | critic column halves) launches;
+  * the actor / critic network's training pass with masks == the pass without them (PULSE_RELU_BITMASK=0 form), every gradient bit."""
+import math
+
+import pytest
+import torch
+
+from pulse_amd import kernels as K
+from pulse_amd._lib import ACT_RELU, EPI_RELU_GRAD, GEMM_OUT_CONTIG
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(g, *shape):
+    return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+def unpack(mask, rows, cols):
+    """(rows, cols) bool from the documented layout: word [((r >> 6) * 8 + (r & 7)) * ld + (c >> 2)], bit 4 * ((r >> 3) & 7) + (c & 3)."""
+    mk = mask.cpu().to(torch.int64) & 0xFFFFFFFF
+    r = torch.arange(rows)[:, None]
+    c = torch.arange(cols)[None, :]
+    w = mk[(r >> 6) * 8 + (r & 7), c >> 2]
+    return ((w >> (4 * ((r >> 3) & 7) + (c & 3))) & 1).bool()
+
+
+@pytest.mark.parametrize("mode", ["x3", "mfma32"])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (300, 200, 100), (1024, 512, 96), (129, 132, 17), (64, 128, 32), (2048, 1024, 40), (700, 260, 33)])
+def test_forward_mask_and_masked_gradient(dev, monkeypatch, mode, m, n, k):
+    monkeypatch.setattr(K, "F32_MODE", mode)
+    g = torch.Generator().manual_seed(m + 3 * n + k)
+    kp = (k + 3) // 4 * 4
+    x = torch.zeros(m, kp); x[:, :k] = rnd(g, m, k)
+    w = torch.zeros(n, kp); w[:, :k] = rnd(g, n, k) / math.sqrt(k)
+    b = rnd(g, n)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    ldc = (n + 3) // 4 * 4
+    k2 = 72
+    dy = torch.zeros(m, k2); dy[:, :69] = rnd(g, m, 69)
+    w2 = rnd(g, 69, ldc)                                    # [red][out]: the head weights as the dX GEMM reads them
+    dyd, w2d = dy.to(dev), w2.to(dev)
+    results = []
+    for opt_f in ((1, 2) if mode == "x3" else (0,)):         # narrow / wide writer
+        K.gemm_set_option(4, opt_f)
+        h = torch.full((m, ldc), 7.0, device=dev)
+        mask = K.alloc_relu_mask(m, n, dev)
+        mask.fill_(-1)                                      # every word the launch owns is rewritten
+        K.gemm(xd, wd, h, M=m, N=n, K=k, lda=kp, ldb=kp, ldc=ldc, bias=bd, activation=ACT_RELU, relu_mask=mask, ld_mask=mask.stride(0))
+        assert torch.equal(unpack(mask, m, n), (h[:, :n] > 0).cpu()), f"mask != (h > 0), writer tiling {opt_f}"
+        for opt_r in ((1, 2) if mode == "x3" else (0,)):     # narrow / wide reader
+            K.gemm_set_option(4, opt_r)
+            a = torch.full((m, ldc), 5.0, device=dev)
+            c = torch.full((m, ldc), 5.0, device=dev)
+            K.gemm(dyd, w2d, a, M=m, N=n, K=69, lda=k2, ldb=ldc, ldc=ldc, b_layout=GEMM_OUT_CONTIG, epilogue=EPI_RELU_GRAD, aux=h, ldaux=ldc)
+            K.gemm(dyd, w2d, c, M=m, N=n, K=69, lda=k2, ldb=ldc, ldc=ldc, b_layout=GEMM_OUT_CONTIG, epilogue=EPI_RELU_GRAD, relu_mask=mask,
+                   ld_mask=mask.stride(0))
+            assert torch.equal(a, c), f"masked gradient differs: writer {opt_f}, reader {opt_r}"
+            results.append(c)
+    K.gemm_set_option(4, 0)
+    for r in results[1:]:
+        assert torch.equal(results[0], r)
+    ref = (dy[:, :69].double() @ w2[:, :n].double()) * (results[0][:, :n].cpu() != 0)      # sanity against fp64 where the mask is set
+    live = results[0][:, :n].cpu() != 0
+    assert live.float().mean() > 0.2
+    err = (results[0][:, :n].cpu().double() - ref)[live].abs().max().item()
+    assert err <= 4e-6 * (ref.abs().max().item() + 1e-30)
+
+
+def test_batched_column_halves(dev, monkeypatch):
+    """Actor | critic halves of one (m, 2 u) matrix in ONE batched launch (stride_c = u floats, stride_mask = u / 4 words)."""
+    monkeypatch.setattr(K, "F32_MODE", "x3")
+    g = torch.Generator().manual_seed(11)
+    m, u, k = 640, 384, 128
+    x = rnd(g, m, 2 * k).to(dev)
+    w = (rnd(g, 2 * u, k) / math.sqrt(k)).to(dev)
+    b = rnd(g, 2 * u).to(dev)
+    h = torch.zeros(m, 2 * u, device=dev)
+    mask = K.alloc_relu_mask(m, 2 * u, dev)
+    for opt in (1, 2):
+        K.gemm_set_option(4, opt)
+        mask.fill_(-1)
+        K.gemm(x, w, h, M=m, N=u, K=k, lda=2 * k, ldb=k, ldc=2 * u, bias=b, activation=ACT_RELU, batch=2, stride_a=k, stride_b=u * k, stride_c=u,
+               stride_bias=u, relu_mask=mask, ld_mask=mask.stride(0), stride_mask=u // 4)
+        assert torch.equal(unpack(mask, m, 2 * u), (h > 0).cpu())
+    K.gemm_set_option(4, 0)
+
+
+def test_network_training_pass_is_bit_identical_with_and_without_masks(dev, monkeypatch):
+    from pulse_amd import configs
+    from pulse_amd.learning import network as N
+    monkeypatch.setattr(K, "F32_MODE", "x3")
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(N, "RELU_BITMASK", on)
+        torch.manual_seed(5)
+        net = N.A2CNetwork(configs.NETWORK_IM, actions_num=69, input_shape=(934,), device=dev)
+        m = 1024
+        ws = net.workspace(m, True)
+        assert ("hmask" in ws) == on
+        gsrc = torch.Generator().manual_seed(9)
+        ws["x"][:, :934] = rnd(gsrc, m, 934).to(dev)
+        net.train()
+        net.forward(ws, m)
+        ws["dheads"].zero_()
+        ws["dmu"].copy_(rnd(gsrc, m, 69).to(dev))
+        ws["dval"].copy_(rnd(gsrc, m, 1).to(dev))
+        grads.append(net.backward(ws, m).clone())
+    assert torch.equal(grads[0], grads[1])
+    assert grads[0].abs().sum() > 0

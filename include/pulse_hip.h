@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 25
+#define PULSE_ABI_VERSION 26
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -570,6 +570,10 @@ int pulse_gemm_set_debug_buffer(long long* device_buffer);
 /* Tile rows (64 / 128 / 256) of the calling thread's last pulse_gemm_f32 launch: which kernel served it (256 = gemm_x3w_kernel).  Diagnostics
  * (bench.py attributes its per-launch event times to the kernel that ran); no effect on results. */
 int pulse_gemm_last_tile(void);
+/* The tiling rule in effect for the calling thread's fp32 (x3) launches: 0 = the launcher's cost model, 1 = 128 x 128 only (option 4 = 1,
+ * PULSE_X3_WIDE=0 in the environment, or a device that refused the wide tile's 135 KB of LDS), 2 = 256 x 256 whenever M, N > 128.  Planners that
+ * size split-K slab counts for a tiling (pulse_amd/kernels.py: dw_split_x3) ask this instead of re-reading the environment. */
+int pulse_gemm_x3_mode(void);
 /* ------------------------------------------------------------------------- *
  * 4b. The same fp32-grade GEMM (PULSE_GEMM_COMPUTE_F32X3 arithmetic) over operands kept PRE-SPLIT in HBM: a matrix is stored as
  *     three bf16 "planes" (x = p0 + p1 + p2 exactly, p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1), round to nearest

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -262,6 +262,7 @@ SIGNATURES = {
     "pulse_gemm_set_option": (c_int, [c_int, c_int]),
     "pulse_gemm_set_debug_buffer": (c_int, [P]),
     "pulse_gemm_last_tile": (c_int, []),
+    "pulse_gemm_x3_mode": (c_int, []),
     "pulse_sizeof_amp_obs_args": (c_int, []),
     "pulse_amp_obs_width": (c_int, [c_int, c_int, c_int]),
     "pulse_amp_obs": (c_int, [POINTER(AmpObsArgs), P]),

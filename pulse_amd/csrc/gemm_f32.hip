@@ -1192,10 +1192,16 @@ namespace {
 // per CU and round at 1.1-1.2 x the narrow kernel's rate on long reductions (about 3.3 units per wide round, more on short ones; calibrated on
 // profiles/r05_gemm_x3_wide_ab.txt and on every launch of a cfg2 / cfg3 epoch, profiles/r05_gemm_shapes_cfg{2,3}.txt).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
 // 2 whenever the output has more than 128 rows and columns (tests).
-bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
+bool g_wide_unavailable = false;      // the device refused the wide tile's LDS request once: never asked again
+// 0 = the launcher's cost model, 1 = never the 256 x 256 tile, 2 = whenever the output has more than 128 rows and columns
+int x3_mode() {
     static const int env = [] { const char* e = getenv("PULSE_X3_WIDE"); return e ? atoi(e) : -1; }();
     int mode = g_opt[4];
     if (mode == 0 && env >= 0) mode = env == 0 ? 1 : env == 1 ? 0 : env;          // PULSE_X3_WIDE=0 off, 1 automatic, 2 always
+    return g_wide_unavailable ? 1 : mode;
+}
+bool x3_wide_tile(const GemmArgs& g, int lda, int ldb, bool akc, bool bkc) {
+    const int mode = x3_mode();
     if (mode == 1 || g.M <= 128 || g.N <= 128) return false;
     // per-workgroup buffer offsets are 32-bit: 256 rows of a reduction-contiguous operand, kchunk rows of a [red][out] operand
     if ((long long)lda * (akc ? 257 : g.kchunk + 1) >= (1LL << 28) || (long long)ldb * (bkc ? 257 : g.kchunk + 1) >= (1LL << 28) ||
@@ -1226,6 +1232,7 @@ int pulse_sizeof_gemm_desc(void) { return (int)sizeof(pulse_gemm_desc); }
 int pulse_gemm_set_debug_buffer(long long* device_buffer) { g_dbg = device_buffer; return PULSE_OK; }
 
 int pulse_gemm_last_tile(void) { return g_last_tile; }
+int pulse_gemm_x3_mode(void) { return x3_mode(); }
 
 int pulse_gemm_set_option(int key, int value) {
     PULSE_REQUIRE(key >= 0 && key < 8, "pulse_gemm_set_option: bad key");
@@ -1329,10 +1336,12 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_, WM_>), grid, dim3(256), lds, as_stream(s), g)
     g_last_tile = half_tile ? 64 : 128;
     if (x3 && !half_tile && x3_wide_tile(g, d->lda, d->ldb, akc, bkc)) {
-        g_last_tile = 256;
         // 256 x 256 tile (gemm_x3w.hip): half the split / staging work per MFMA; taken when its one-workgroup-per-CU rounds cost less than the
-        // 128 x 128 tiling's (two workgroups per CU) -- see x3_wide_tile
-        return launch_gemm_x3w(g, akc, bkc, as_stream(s));
+        // 128 x 128 tiling's (two workgroups per CU) -- see x3_wide_tile.  A device that does not grant its 135 KB of LDS keeps the narrow tile
+        // (same bits either way).
+        const int rc = launch_gemm_x3w(g, akc, bkc, as_stream(s));
+        if (rc != kWideTileUnavailable) { g_last_tile = 256; return rc; }
+        g_wide_unavailable = true;
     }
     if (x3 && half_tile) {
         if (akc && bkc) { LAUNCHX(9, true, true, 1); }

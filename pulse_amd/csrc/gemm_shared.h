@@ -31,6 +31,9 @@ struct GemmArgs {
 // word of the ReLU bit mask that holds output row r (within its 64-row block: rows r, r + 8, .., r + 56 share a word), column group cg = col / 4
 __device__ __forceinline__ long long mask_word(int r, int cg, int ldmask) { return (long long)((r >> 6) * 8 + (r & 7)) * ldmask + cg; }
 
+// launch_gemm_x3w's answer when the device refuses the 256 x 256 tile's dynamic-LDS request: not an error, the launcher falls back (internal code)
+constexpr int kWideTileUnavailable = -1000;
+
 __device__ __forceinline__ int slot_of(int out) { return out ^ ((out >> 3) & 7); }
 
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {

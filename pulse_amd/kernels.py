@@ -63,7 +63,6 @@ class GemmProfiler:
 
 
 PROFILER = GemmProfiler()
-PLAN_GRAPHS = os.environ.get("PULSE_PLAN_GRAPHS", "0") == "1"       # Plan.run replays captured HIP graphs (see Plan.run): measured, no gain, off
 
 # How an fp32 GEMM is computed (inputs / outputs / storage are fp32 either way):
 #   "x3"      three-way bf16 operand split, six bf16 MFMAs per k step, fp32 accumulation (PULSE_GEMM_COMPUTE_F32X3): fp32-grade
@@ -149,7 +148,9 @@ def dw_split_x3(M, N, batch, max_split, K=16384):
     the lowest modelled time = min(narrow, wide cost) / split (the reduction length per workgroup is K / split) plus a charge per slab for its
     write and its share of the reduce (calibrated on the 2048 x 960 output: 16 us per 4 slabs against 281 us of GEMM), fewer slabs on ties.  cfg2 layer 1 (2048 x 960): 4 slabs on the narrow tiling -> 8 on the wide one
     (327 -> 296 us, profiles/r05_gemm_x3_wide_ab.txt); the [512, 1024] pair keeps 8 narrow slabs."""
-    if F32_MODE != "x3" or os.environ.get("PULSE_X3_WIDE", "1") == "0":
+    # the tiling the LAUNCHER will use (environment switch read once by the library + this thread's gemm option 4): planner and launcher
+    # cannot disagree (round-5 advisor finding)
+    if F32_MODE != "x3" or _lib.load().pulse_gemm_x3_mode() == 1:
         return dw_split(((M + 127) // 128) * ((N + 127) // 128) * batch, max_split)
     best, best_t = max_split, None
     s = max_split
@@ -280,41 +281,8 @@ class Plan:
     def run(self, start=0, stop=None, skip_partial_reduces=False):
         """``skip_partial_reduces``: leave out the small ordered reduces registered with call_partial_reduce -- the caller's fused gradient reduce
         (ReduceGrads regions with their own source) sums those partials itself.
-
-        [r5] PULSE_PLAN_GRAPHS=1 (OFF by default): a plan segment is a fixed list of launches over fixed buffers (descriptors and pointers are built
-        once per workspace), so from its THIRD run on it can be replayed as one captured HIP graph -- same kernels, arguments and order: same bits
-        (the parity suites pass with it on).  A stand-alone chain of 24 dependent GEMMs runs 10.8 us per launch faster as a graph replay
-        (tools/graph_gap_probe.py: 119.0 -> 108.2 us), but inside the epoch it gives nothing (profiles/r05_ab_runs.txt: cfg2 68.0 / 68.6 ms eager,
-        68.4 / 69.2 with graphs; cfg3 902.2 vs 902.4): the update is a single dependent chain whose launches the host already enqueues far ahead of
-        the device, and the gap between two of them is the device's own.  The first two runs stay eager (lazy one-time setup such as
-        hipFuncSetAttribute must not fall inside a capture), as does the bench's instrumented step (an event pair per launch)."""
-        if PLAN_GRAPHS and not PROFILER.enabled and self.ops and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
-            if not hasattr(self, "_graphs"):
-                self._graphs = {}
-            key = (start, stop, bool(skip_partial_reduces))
-            ent = self._graphs.get(key, 0)
-            if isinstance(ent, torch.cuda.CUDAGraph):
-                ent.replay()
-                return
-            if ent is not None:                                  # None: this segment could not be captured and stays eager
-                if ent < 2:
-                    self._graphs[key] = ent + 1                  # runs 1 and 2: eager (falls through)
-                else:
-                    g = torch.cuda.CUDAGraph()
-                    try:
-                        with torch.cuda.graph(g):
-                            self._run_eager(start, stop, skip_partial_reduces)
-                    except Exception as e:                       # nothing of the segment has run yet: fall through to the eager path
-                        self._graphs[key] = None
-                        import warnings
-                        warnings.warn(f"Plan.run: HIP-graph capture failed ({e}); this segment keeps the eager path")
-                    else:
-                        self._graphs[key] = g
-                        g.replay()                               # the capture recorded the launches, it did not run them
-                        return
-        self._run_eager(start, stop, skip_partial_reduces)
-
-    def _run_eager(self, start=0, stop=None, skip_partial_reduces=False):
+        (Round 5 measured replaying plan segments as captured HIP graphs: flat inside the epoch -- cfg2 68.0 / 68.6 ms eager vs 68.4 / 69.2,
+        profiles/r05_ab_runs.txt; the update is one dependent chain the host enqueues far ahead of the device.  The path was removed in round 6.)"""
         st = _stream()
         for op in self.ops[start:stop]:
             if op[0] == 0:

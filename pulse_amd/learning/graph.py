@@ -285,7 +285,9 @@ class MlpGraph:
             # sub-networks a pass does NOT visit, so the slabs a visited layer leaves alone must never have been written by anyone: every
             # plan built over this book has to agree on the count (it depends on m) -- otherwise reduce_slabs would silently add another
             # graph's stale partial sums (round-3 advisor finding)
-            sl = K.dw_split_x3(lin.n, lin.k_phys, 1, S, K=m)
+            # (the count is taken at the TRAINING minibatch's reduction length whatever m this graph is built for: graphs over one book must
+            #  agree on it, and network_z / network_sept also build backward plans for the rollout's m -- round-5 advisor finding)
+            sl = K.dw_split_x3(lin.n, lin.k_phys, 1, S, K=16384)
             book.note_slab_layout(lin.w.name, 1 if via_scratch else sl, m)
             if via_scratch:
                 ws_ = self._w_scratch

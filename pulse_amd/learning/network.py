@@ -504,20 +504,6 @@ class A2CNetwork:
         ws["reduce_all_fused"] = fused
         return K.ReduceGrads(self._slabs, self.n_flat, regions, self.grad) if len(regions) <= 8 else None
 
-    def _bwd_side_stream(self, ws, plan):
-        """The stream the weight gradients past layer 1 run on beside the layer-1 one, or None.  OFF unless PULSE_BWD_STREAM=1: round 4 measured
-        +1.3 % on cfg2 with the 128 x 128 tiling (two workgroups per CU left gaps to fill); with the 256 x 256 tiling every launch is one workgroup
-        per CU holding the whole register file, two such launches side by side only take CUs from each other, and the same A/B reads 70.1 ms
-        without vs 70.8 ms with the side chain (profiles/r05_ab_runs.txt).  Kept as a switch (fp32-storage plans on a GPU only: the bf16 plans of
-        the AMP agent already run the discriminator chain beside this one)."""
-        if (ws.get("b16") or not getattr(plan, "split_dx", 0) or plan.split <= plan.split_dx or self.device.type != "cuda"
-                or os.environ.get("PULSE_BWD_STREAM", "0") != "1"):
-            return None
-        if getattr(self, "_bwd_stream", None) is None:
-            self._bwd_stream = torch.cuda.Stream(device=self.device)
-            self._ev_bfork, self._ev_bjoin = torch.cuda.Event(), torch.cuda.Event()
-        return self._bwd_stream
-
     def backward(self, ws, m, grad_scale=1.0, on_bucket=None, sq_partials=None):
         """Given d loss/d(mu, value) in ws['dheads'], fill self.grad (flat, same layout as self.flat).
         Deterministic: split-K slabs + ordered reduces.
@@ -539,23 +525,9 @@ class A2CNetwork:
             if "reduce_all" not in ws:
                 ws["reduce_all"] = self._build_reduce_all(ws, plan)
             rg = ws["reduce_all"]
-            side = self._bwd_side_stream(ws, plan)
-            if rg is not None and side is not None:
-                # the upper layers' and the heads' weight gradients on a side stream beside the layer-1 one: every launch here is one round of one
-                # workgroup per CU, so the chains do not share CUs -- what overlaps is each launch's tail, launch gap and prologue with the other
-                # chain's next workgroups (A/B: profiles/r05_ab_runs.txt).  Disjoint outputs (gradient elements below / above w_off[1], the heads'
-                # scratch); both chains only read the activations and the dX chain's results.
-                main = torch.cuda.current_stream()
-                plan.run(0, plan.split_dx)
-                self._ev_bfork.record(main)
-                side.wait_event(self._ev_bfork)
-                with torch.cuda.stream(side):
-                    plan.run(plan.split, None, skip_partial_reduces=ws["reduce_all_fused"])
-                    self._ev_bjoin.record(side)
-                plan.run(plan.split_dx, plan.split)
-                main.wait_event(self._ev_bjoin)
-                rg.run(scale=grad_scale, sq_partials=sq_partials)
-            elif rg is not None:
+            # (round 4 / 5 measured the upper layers' weight gradients on a side stream beside the layer-1 one: +1.3 % on the 128 x 128 tiling, -1 %
+            #  on the 256 x 256 one, whose launches each hold every CU's whole register file -- profiles/r05_ab_runs.txt; removed in round 6)
+            if rg is not None:
                 plan.run(skip_partial_reduces=ws["reduce_all_fused"])
                 rg.run(scale=grad_scale, sq_partials=sq_partials)
             else:                                                # deep MLP: more ranges than one fused launch takes

@@ -41,10 +41,16 @@ def test_slab_count_is_a_power_of_two_fraction_and_falls_back(monkeypatch):
         for ms in (1, 2, 8, 16, 32):
             s = K.dw_split_x3(m, n, b, ms, K=16384)
             assert 1 <= s <= ms and ms % s == 0 and (ms // s) & ((ms // s) - 1) == 0
-    # the fp32-MFMA arithmetic and PULSE_X3_WIDE=0 keep the round-4 rule (smallest count that still gives 512 narrow workgroups)
-    monkeypatch.setenv("PULSE_X3_WIDE", "0")
-    assert K.dw_split_x3(2048, 960, 1, 8) == K.dw_split(16 * 8, 8) == 4
-    monkeypatch.delenv("PULSE_X3_WIDE")
+    # the fp32-MFMA arithmetic and a launcher held to the 128 x 128 tile keep the round-4 rule (smallest count that still gives 512 narrow
+    # workgroups).  The planner asks the LIBRARY which tiling is in effect (pulse_gemm_x3_mode: gemm option 4 of this thread, or PULSE_X3_WIDE
+    # as the library read it once), so planner and launcher cannot disagree.
+    K.gemm_set_option(4, 1)
+    try:
+        assert K._lib.load().pulse_gemm_x3_mode() == 1
+        assert K.dw_split_x3(2048, 960, 1, 8) == K.dw_split(16 * 8, 8) == 4
+    finally:
+        K.gemm_set_option(4, 0)
+    assert K._lib.load().pulse_gemm_x3_mode() == 0
     monkeypatch.setattr(K, "F32_MODE", "mfma32")
     assert K.dw_split_x3(2048, 960, 1, 8) == 4
 

@@ -70,7 +70,7 @@ td = eb.tensor_dict
 t = timeit(lambda: ops.discount_values(td["dones"], td["values"], td["rewards"], td["next_values"], 0.99, 0.95, return_returns=True))
 report("gae_kernel", n * T * 21, t, f"{T}x{n} elements")
 net = agent.model
-t = timeit(lambda: K.reduce_slabs(net._slabs, net.split_k, net.n_flat, net.n_flat, net.grad, scale=1.0))
+t = timeit(lambda: [K.reduce_slabs(net._slabs, ns, net.n_flat, cnt, net.grad, scale=1.0, slabs_off=off, out_off=off) for off, cnt, ns in net._slab_regions(ws)])
 report("reduce_slabs_kernel (8 slabs)", net.n_flat * 4 * (net.split_k + 1), t, f"{net.n_flat} params")
 sq, gn = torch.zeros(256, device=dev), torch.zeros(1, device=dev)
 

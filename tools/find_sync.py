@@ -27,7 +27,7 @@ for rep in range(12):
             T(f"bwd{i}:gemm {op[3]} {op[1].M}x{op[1].N}x{op[1].K}", lambda: K.launch_gemm(op[1], op[2], op[3]))
         else:
             T(f"bwd{i}:{op[3]}", lambda: K._lib.check(op[1](*op[2], K._stream()), op[3]))
-    T("final reduce", lambda: K.reduce_slabs(net._slabs, net.split_k, net.n_flat, net.n_flat, net.grad, scale=1.0))
+    T("final reduce", lambda: [K.reduce_slabs(net._slabs, ns, net.n_flat, cnt, net.grad, scale=1.0, slabs_off=off, out_off=off) for off, cnt, ns in net._slab_regions(ws)])
     T("sqnorm", lambda: K.sqnorm_partial(net.grad, net.n_flat, agent._sq_partials))
     T("adam", lambda: K.adam_step(net.flat, net.grad, agent.exp_avg, agent.exp_avg_sq, net.n_flat, lr=1e-5, step=5 + rep, max_norm=50.0, sqnorm_partials=agent._sq_partials, grad_norm_out=agent._grad_norm))
     T("info torch ops", lambda: (agent._loss_partials.sum(0) / mb, agent._grad_norm.clone()))

@@ -20,6 +20,11 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
                else (B16 if k.rstrip().endswith("1>(pulse::XpArgs)") or ", 1>" in k else "gemm_x3p_kernel") if "gemm_x3p_kernel" in k
                else ("other_pulse" if "pulse" in k else "torch"))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # [r6] the two tilings of the x3 GEMM also get rows of their own (they are different kernels with different traffic per launch)
+        if "gemm_x3w_kernel" in k:
+            agg["gemm_x3w_kernel"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        elif "gemm_x3_kernel" in k:
+            agg["gemm_x3_kernel (128 x 128 / 64 x 128 tile only)"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for key, cs in agg.items():
     f, w = cs.get("FETCH_SIZE", []), cs.get("WRITE_SIZE", [])

@@ -1192,6 +1192,7 @@ namespace {
 // per CU and round at 1.1-1.2 x the narrow kernel's rate on long reductions (about 3.3 units per wide round, more on short ones; calibrated on
 // profiles/r05_gemm_x3_wide_ab.txt and on every launch of a cfg2 / cfg3 epoch, profiles/r05_gemm_shapes_cfg{2,3}.txt).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
 // 2 whenever the output has more than 128 rows and columns (tests).
+constexpr int WIDE_TILE = 256;
 bool g_wide_unavailable = false;      // the device refused the wide tile's LDS request once: never asked again
 // 0 = the launcher's cost model, 1 = never the 256 x 256 tile, 2 = whenever the output has more than 128 rows and columns
 int x3_mode() {
@@ -1339,6 +1340,32 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
         // 256 x 256 tile (gemm_x3w.hip): half the split / staging work per MFMA; taken when its one-workgroup-per-CU rounds cost less than the
         // 128 x 128 tiling's (two workgroups per CU) -- see x3_wide_tile.  A device that does not grant its 135 KB of LDS keeps the narrow tile
         // (same bits either way).
+        // A narrow column tail that costs the wide tiling a whole extra round of workgroups (N = 3096 = 12 x 256 + 24: 13 column tiles, 832
+        // workgroups = 4 rounds at M = 16384, where 12 x 64 = 768 is exactly 3) goes to the 128 x 128 tiling as a launch of its own: the two
+        // tilings are bit-identical, so the split is invisible in the results.  (Epilogue-carrying launches only: a split-K / row-sum launch
+        // writes slabs whose tiling the planner already sized.)
+        const int ntail = d->N % WIDE_TILE;
+        if (ntail > 0 && ntail <= 64 && d->N > WIDE_TILE && d->split_k == 1 && d->rowsum == nullptr && g_opt[5] == 0) {
+            const long long tm = (d->M + WIDE_TILE - 1) / WIDE_TILE, z = d->batch;
+            const long long r_all = (tm * ((d->N + WIDE_TILE - 1) / WIDE_TILE) * z + 255) / 256, r_main = (tm * (d->N / WIDE_TILE) * z + 255) / 256;
+            if (r_main < r_all) {
+                const int n0 = d->N - ntail;
+                pulse_gemm_desc m = *d, t = *d;
+                m.N = n0;
+                t.N = ntail;
+                t.B = bkc ? d->B + (long long)n0 * d->ldb : d->B + n0;
+                t.C = d->C + n0;
+                if (d->C2) t.C2 = d->C2 + n0;
+                if (d->bias) t.bias = d->bias + n0;
+                if (d->aux) t.aux = d->aux + n0;
+                if (d->relu_mask) t.relu_mask = d->relu_mask + n0 / 4;
+                const int rc_main = pulse_gemm_f32(&m, s);
+                if (rc_main != PULSE_OK) return rc_main;
+                const int rc_tail = pulse_gemm_f32(&t, s);
+                g_last_tile = 256;                                   // (diagnostics: the launch's time is the wide kernel's)
+                return rc_tail;
+            }
+        }
         const int rc = launch_gemm_x3w(g, akc, bkc, as_stream(s));
         if (rc != kWideTileUnavailable) { g_last_tile = 256; return rc; }
         g_wide_unavailable = true;

@@ -312,3 +312,40 @@ def test_random_shapes_both_tilings_agree(dev):
             for z in range(batch):
                 ref = dy[:, z * (lda // batch): z * (lda // batch) + m].cpu().double().t() @ x[:, z * (ldb // batch): z * (ldb // batch) + n].cpu().double()
                 assert (tot[z * cnt:(z + 1) * cnt].view(m, n) - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("form", ["fwd_relu_mask", "dx_mul_aux", "fwd_silu_d"])
+def test_column_tail_split_is_invisible(dev, form):
+    """A narrow column tail that would cost the 256 x 256 tiling a whole extra round of workgroups (cfg3's N = 3096 = 12 x 256 + 24) is launched
+    on the 128 x 128 tiling beside the wide main part (gemm_f32.hip; gemm option 5 = 1 switches the split off): same bits, every output
+    (C, C2, the ReLU bit mask) and nothing written past N."""
+    g = torch.Generator().manual_seed(77)
+    m, n, k = 4096, 16 * 256 + 24, 64                       # 16 x 17 = 272 wide tiles = 2 rounds; 16 x 16 = 256 = 1 round + the tail
+    x = rnd(g, m, k).to(dev)
+    b = rnd(g, n).to(dev)
+    ldc = n + 8
+    outs = []
+    for opt5 in (1, 0):
+        K.gemm_set_option(5, opt5)
+        K.gemm_set_option(4, 0)
+        c = torch.full((m, ldc), 3.0, device=dev)
+        c2 = torch.full((m, ldc), 3.0, device=dev)
+        if form == "fwd_relu_mask":
+            w = (rnd(torch.Generator().manual_seed(1), n, k) / 8).to(dev)
+            mask = K.alloc_relu_mask(m, n, dev)
+            K.gemm(x, w, c, M=m, N=n, K=k, lda=k, ldb=k, ldc=ldc, bias=b, activation=ACT_RELU, relu_mask=mask, ld_mask=mask.stride(0))
+            outs.append((c, mask))
+        elif form == "fwd_silu_d":
+            w = (rnd(torch.Generator().manual_seed(1), n, k) / 8).to(dev)
+            K.gemm(x, w, c, M=m, N=n, K=k, lda=k, ldb=k, ldc=ldc, bias=b, activation=ACT_SILU_D, C2=c2, ldc2=ldc)
+            outs.append((c, c2))
+        else:
+            wt = torch.zeros(k, ldc); wt[:, :n] = rnd(torch.Generator().manual_seed(2), k, n) / 8      # [red][out] weight, as an input gradient reads it
+            aux = torch.zeros(m, ldc); aux[:, :n] = rnd(torch.Generator().manual_seed(3), m, n)
+            K.gemm(x, wt.to(dev), c, M=m, N=n, K=k, lda=k, ldb=ldc, ldc=ldc, b_layout=GEMM_OUT_CONTIG, epilogue=EPI_MUL_AUX, aux=aux.to(dev), ldaux=ldc)
+            outs.append((c,))
+        assert torch.equal(c[:, n:].cpu(), torch.full((m, ldc - n), 3.0))
+    K.gemm_set_option(5, 0)
+    for a, bb in zip(outs[0], outs[1]):
+        assert torch.equal(a, bb)
+    assert outs[0][0][:, :n].abs().sum() > 0

@@ -560,7 +560,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
  * same results either way up to accumulation order), option 4 = tile of the fp32 (x3) launches of pulse_gemm_f32 (0 = the launcher's cost model,
  * also steered by PULSE_X3_WIDE = 0 / 1 / 2 in the environment; 1 = 128 x 128 only; 2 = 256 x 256 whenever M, N > 128; BIT-IDENTICAL matrix outputs
  * either way, the weight-gradient form's row sums agree to rounding), option 5 = 1: never split a narrow column tail off a 256 x 256 launch (A/B;
- * same bits).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
+ * same bits), option 6 = 1: never the skinny-N kernel (N <= 96 over a long M; same bits).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
  * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID.  The 256 x 256 bf16-storage
  * kernel of pulse_gemm_x3p honours the same buffer with wall-clock stamps only: [0] start, [1] first stage landed, [2] main loop done,
  * [3] epilogue stores issued, [4] stores acknowledged, [5] XCC_ID, [6] / [7] transpose image written / stores issued of the last epilogue
@@ -568,7 +568,7 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
  * stores issued, [7] stores acknowledged (wall; tools/gemm_x3w_phases.py). */
 int pulse_gemm_set_option(int key, int value);
 int pulse_gemm_set_debug_buffer(long long* device_buffer);
-/* Tile rows (64 / 128 / 256) of the calling thread's last pulse_gemm_f32 launch: which kernel served it (256 = gemm_x3w_kernel).  Diagnostics
+/* Tile rows (64 / 128 / 256; 96 = the skinny-N kernel gemm_x3s_kernel) of the calling thread's last pulse_gemm_f32 launch: which kernel served it (256 = gemm_x3w_kernel).  Diagnostics
  * (bench.py attributes its per-launch event times to the kernel that ran); no effect on results. */
 int pulse_gemm_last_tile(void);
 /* The tiling rule in effect for the calling thread's fp32 (x3) launches: 0 = the launcher's cost model, 1 = 128 x 128 only (option 4 = 1,

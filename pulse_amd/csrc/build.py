@@ -47,6 +47,8 @@ SOURCES = [
     # the 256 x 256 x3 tile runs ONE wave per SIMD with its 256 accumulator registers in AGPRs: no VGPR-form flag here
     # (its k-tile body is one fully unrolled 96-MFMA schedule: lift the pragma-unroll size limit, or the loop stays rolled and the accumulators go to scratch)
     ("gemm_x3w.hip", ["-mllvm", "-pragma-unroll-threshold=4000000", "-Wno-unused-const-variable"]),
+    # the skinny-N x3 kernel: one wave per SIMD with plenty of registers (a phase of raw A + B staging units in flight)
+    ("gemm_x3s.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("learner_ops.hip", NO_CONTRACT),
     ("b16_ops.hip", NO_CONTRACT),
     ("vae_head.hip", NO_CONTRACT),

@@ -1193,6 +1193,8 @@ namespace {
 // profiles/r05_gemm_x3_wide_ab.txt and on every launch of a cfg2 / cfg3 epoch, profiles/r05_gemm_shapes_cfg{2,3}.txt).  Option 4 (pulse_gemm_set_option) / PULSE_X3_WIDE: 0 automatic, 1 never,
 // 2 whenever the output has more than 128 rows and columns (tests).
 constexpr int WIDE_TILE = 256;
+bool skinny_env_off() { static const bool off = [] { const char* e = getenv("PULSE_X3_SKINNY"); return e && e[0] == '0'; }(); return off; }   // A/B switch, read once
+bool g_skinny_unavailable = false;    // the device refused the skinny-N kernel's 144 KB of LDS once
 bool g_wide_unavailable = false;      // the device refused the wide tile's LDS request once: never asked again
 // 0 = the launcher's cost model, 1 = never the 256 x 256 tile, 2 = whenever the output has more than 128 rows and columns
 int x3_mode() {
@@ -1336,6 +1338,18 @@ int pulse_gemm_f32(const pulse_gemm_desc* d, pulse_stream_t s) {
     }                                                                                                             \
     hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_, WM_>), grid, dim3(256), lds, as_stream(s), g)
     g_last_tile = half_tile ? 64 : 128;
+    // skinny outputs over a long M (the mu / value heads, the latent-width layers): gemm_x3s.hip -- a workgroup owns 128 rows x all N <= 96
+    // columns, A goes global -> registers -> fragments, B is split once per workgroup and 128-deep k phase.  Bit-identical to the other tilings.
+    // Taken when the launch is ONE round of 128-row workgroups that fills most of the chip (192 .. 256 of them; measured, tools/bench_gemm_x3_skinny.py:
+    // 16384 x 69 x 512 x 2 nets 34.2 -> 29.1 us, but two rounds (32768 rows) 47.7 -> 57.9 and half a round no gain); gemm option 6 = 1: never.
+    if (x3 && akc && d->N <= 96 && d->epilogue == PULSE_EPI_BIAS_ACT && d->activation <= PULSE_ACT_RELU && d->C2 == nullptr && d->split_k == 1 &&
+        d->rowsum == nullptr && !mask_on && g_dbg == nullptr && g_opt[6] == 0 && !g_skinny_unavailable && !skinny_env_off() &&
+        (long long)((d->M + 127) / 128) * d->batch >= 192 && (long long)((d->M + 127) / 128) * d->batch <= 256 && (long long)d->lda * 129 < (1LL << 28) &&
+        (bkc ? (long long)d->ldb * 97 : (long long)d->ldb * (d->K + 1)) < (1LL << 28)) {
+        const int rc = launch_gemm_x3s(g, bkc, as_stream(s));
+        if (rc != kWideTileUnavailable) { g_last_tile = 96; return rc; }
+        g_skinny_unavailable = true;
+    }
     if (x3 && !half_tile && x3_wide_tile(g, d->lda, d->ldb, akc, bkc)) {
         // 256 x 256 tile (gemm_x3w.hip): half the split / staging work per MFMA; taken when its one-workgroup-per-CU rounds cost less than the
         // 128 x 128 tiling's (two workgroups per CU) -- see x3_wide_tile.  A device that does not grant its 135 KB of LDS keeps the narrow tile

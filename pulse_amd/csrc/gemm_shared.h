@@ -65,5 +65,8 @@ __device__ __forceinline__ unsigned pack_rn(float lo_elem, float hi_elem) {
 // gemm_x3w.hip: the x3 arithmetic on a 256 x 256 x 16 tile (one wave per SIMD, accumulators in AGPRs).  ``g.tiles_m`` / ``g.tiles_n`` are
 // recomputed for the 256-wide tiling by the callee.  Returns a PULSE_* code.
 int launch_gemm_x3w(const GemmArgs& g, bool akc, bool bkc, hipStream_t stream);
+// gemm_x3s.hip: the x3 arithmetic for skinny outputs (N <= 96, A reduction-contiguous, plain / ReLU epilogue): 128 rows x all columns per
+// workgroup.  Returns a PULSE_* code, or kWideTileUnavailable when the device refuses its dynamic LDS.
+int launch_gemm_x3s(const GemmArgs& g, bool bkc, hipStream_t stream);
 
 }  // namespace pulse

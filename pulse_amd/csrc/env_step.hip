@@ -299,7 +299,10 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
         Q4 root_q{rb_e[3], rb_e[4], rb_e[5], rb_e[6]};
         if (!a.upright_start) root_q = qmul(root_q, Q4{-0.5f, -0.5f, -0.5f, 0.5f});   // remove_base_rot, humanoid.py:1616-1620
         const Q4 hinv = heading_quat(root_q, true);   // calc_heading_quat_inv
-        const Q4 hfwd = heading_quat(root_q, false);  // calc_heading_quat
+        // calc_heading_quat is its exact conjugate: quat_from_angle_axis(+-h, z^) differ in the sign of sin(h / 2) only (sin is odd in fp32 too,
+        // the normalisation is the same) -- one heading evaluation (atan2 + sin + cos + two normalisations) per lane instead of two [r6]
+        const Q4 hfwd = qconj(hinv);
+        const float h_s = 2.0f * (hinv.w * hinv.w) - 1.0f;                  // shared by every rotation into the heading frame (qrot_heading)
 
         if (do_self && r_now) {
             for (int hs = 0; hs < H; ++hs) {
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                     const V3 w{r[10], r[11], r[12]};
                     if (lane >= 1) {
                         // every step is expressed relative to the NEWEST root (humanoid.py:1737-1753)
-                        const V3 lp = qrot(hinv, V3{p.x - root_p.x, p.y - root_p.y, p.z - root_p.z});
+                        const V3 lp = qrot_heading(hinv, h_s, V3{p.x - root_p.x, p.y - root_p.y, p.z - root_p.z});
                         float* o = ob + L.off_pos + 3 * (lane - 1);
                         o[0] = lp.x; o[1] = lp.y; o[2] = lp.z;
                     } else if (a.root_height_obs) {
@@ -326,10 +329,10 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                     float* o = ob + L.off_rot + 6 * lane;
 #pragma unroll
                     for (int k = 0; k < 6; ++k) o[k] = tn[k];
-                    const V3 lv = qrot(hinv, v);
+                    const V3 lv = qrot_heading(hinv, h_s, v);
                     o = ob + L.off_vel + 3 * lane;
                     o[0] = lv.x; o[1] = lv.y; o[2] = lv.z;
-                    const V3 lw = qrot(hinv, w);
+                    const V3 lw = qrot_heading(hinv, h_s, w);
                     o = ob + L.off_ang + 3 * lane;
                     o[0] = lw.x; o[1] = lw.y; o[2] = lw.z;
                 }
@@ -378,10 +381,10 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                 if (zof_dir && lane == 0)            // ... and beyond far_distance the root target is only a direction
                     pr = V3{(pr.x - p.x) / zof_d * a.far_distance + p.x, (pr.y - p.y) / zof_d * a.far_distance + p.y,
                             (pr.z - p.z) / zof_d * a.far_distance + p.z};
-                put3(task_off(ov, 0, Jt, T, t, lane), qrot(hinv, V3{pr.x - p.x, pr.y - p.y, pr.z - p.z}));
-                put3(task_off(ov, 2, Jt, T, t, lane), qrot(hinv, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z}));
-                put3(task_off(ov, 4, Jt, T, t, lane), qrot(hinv, V3{pr.x - root_p.x, pr.y - root_p.y, pr.z - root_p.z}));
-                put3(task_off(ov, 6, Jt, T, t, lane), qrot(hinv, vr));
+                put3(task_off(ov, 0, Jt, T, t, lane), qrot_heading(hinv, h_s, V3{pr.x - p.x, pr.y - p.y, pr.z - p.z}));
+                put3(task_off(ov, 2, Jt, T, t, lane), qrot_heading(hinv, h_s, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z}));
+                put3(task_off(ov, 4, Jt, T, t, lane), qrot_heading(hinv, h_s, V3{pr.x - root_p.x, pr.y - root_p.y, pr.z - root_p.z}));
+                put3(task_off(ov, 6, Jt, T, t, lane), qrot_heading(hinv, h_s, vr));
                 if (ov != 7) {
                     Q4 qr{x[J * 3 + 4 * tb], x[J * 3 + 4 * tb + 1], x[J * 3 + 4 * tb + 2], x[J * 3 + 4 * tb + 3]};
                     V3 wr{x[J * 10 + 3 * tb], x[J * 10 + 3 * tb + 1], x[J * 10 + 3 * tb + 2]};
@@ -392,14 +395,14 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                     float tn[6];
                     int off = task_off(ov, 1, Jt, T, t, lane);
                     if (off >= 0) { q_to_tan_norm(qmul(qmul(hinv, qmul(qr, qconj(q))), hfwd), tn); put6(off, tn); }   // change of basis
-                    put3(task_off(ov, 3, Jt, T, t, lane), qrot(hinv, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z}));
+                    put3(task_off(ov, 3, Jt, T, t, lane), qrot_heading(hinv, h_s, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z}));
                     off = task_off(ov, 5, Jt, T, t, lane);
                     if (off >= 0) { q_to_tan_norm(qmul(hinv, qr), tn); put6(off, tn); }
-                    put3(task_off(ov, 7, Jt, T, t, lane), qrot(hinv, wr));
+                    put3(task_off(ov, 7, Jt, T, t, lane), qrot_heading(hinv, h_s, wr));
                     if (ov == 9 && lane == 0) {          // root velocity differences (tracked body 0), humanoid_im.py:1510-1517
                         const int base = t * (18 * Jt + 6) + 9 * Jt;
-                        put3(base, qrot(hinv, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z}));
-                        put3(base + 3, qrot(hinv, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z}));
+                        put3(base, qrot_heading(hinv, h_s, V3{vr.x - v.x, vr.y - v.y, vr.z - v.z}));
+                        put3(base + 3, qrot_heading(hinv, h_s, V3{wr.x - w.x, wr.y - w.y, wr.z - w.z}));
                     }
                 }
             }

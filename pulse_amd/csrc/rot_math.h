@@ -76,8 +76,33 @@ __device__ __forceinline__ float q_to_angle_axis(const Q4 q, V3* axis) {
     return ok ? ang : 0.0f;
 }
 
-// quat_to_tan_norm, phc/utils/torch_utils.py:100-113: [R x^, R z^]
+// my_quat_rotate by a HEADING quaternion h = (0, 0, z, w) (calc_heading_quat(_inv): a rotation about +z, x = y = +-0 exactly).  The terms of qrot
+// that carry h.x / h.y are exact zeros there (0 * v = +-0, a + +-0 = a), so leaving them out gives the SAME fp32 values (at most the sign of a
+// zero differs) in 15 instead of 35 operations; ``s`` = 2 h.w^2 - 1 is shared by every rotation of a lane.  [r6]
+__device__ __forceinline__ V3 qrot_heading(const Q4 h, const float s, const V3 v) {
+    V3 r;
+    r.x = v.x * s + (-(h.z * v.y)) * h.w * 2.0f;      // cx = h.y v.z - h.z v.y = -(h.z v.y)
+    r.y = v.y * s + (h.z * v.x) * h.w * 2.0f;         // cy = h.z v.x - h.x v.z =   h.z v.x
+    r.z = v.z * s + h.z * (h.z * v.z) * 2.0f;         // cz = 0;  d = h.z v.z
+    return r;
+}
+
+// quat_to_tan_norm, phc/utils/torch_utils.py:100-113: [R x^, R z^] = my_quat_rotate(q, (1, 0, 0)), my_quat_rotate(q, (0, 0, 1)).
+// Written out for the two unit vectors [r6]: the products with their zero components are exact zeros and 1 * x = x, so the values are those of
+// the two general rotations (at most the sign of a zero differs) in 26 instead of 70 operations.
 __device__ __forceinline__ void q_to_tan_norm(const Q4 q, float out[6]) {
+    const float s = 2.0f * (q.w * q.w) - 1.0f;
+    // v = x^: cross = (0, q.z, -q.y), dot = q.x
+    out[0] = s + q.x * q.x * 2.0f;
+    out[1] = q.z * q.w * 2.0f + q.y * q.x * 2.0f;
+    out[2] = (-q.y) * q.w * 2.0f + q.z * q.x * 2.0f;
+    // v = z^: cross = (q.y, -q.x, 0), dot = q.z
+    out[3] = q.y * q.w * 2.0f + q.x * q.z * 2.0f;
+    out[4] = (-q.x) * q.w * 2.0f + q.y * q.z * 2.0f;
+    out[5] = s + q.z * q.z * 2.0f;
+}
+// the two general rotations q_to_tan_norm stands for (tests compare the two forms)
+__device__ __forceinline__ void q_to_tan_norm_general(const Q4 q, float out[6]) {
     const V3 t = qrot(q, V3{1.0f, 0.0f, 0.0f});
     const V3 n = qrot(q, V3{0.0f, 0.0f, 1.0f});
     out[0] = t.x; out[1] = t.y; out[2] = t.z;
@@ -86,8 +111,11 @@ __device__ __forceinline__ void q_to_tan_norm(const Q4 q, float out[6]) {
 
 // calc_heading, phc/utils/torch_utils.py:200-212
 __device__ __forceinline__ float heading_angle(const Q4 q) {
-    const V3 d = qrot(q, V3{1.0f, 0.0f, 0.0f});
-    return atan2f(d.y, d.x);
+    // my_quat_rotate(q, x^).xy, written out as in q_to_tan_norm (same values as the general rotation) [r6]
+    const float s = 2.0f * (q.w * q.w) - 1.0f;
+    const float dx = s + q.x * q.x * 2.0f;
+    const float dy = q.z * q.w * 2.0f + q.y * q.x * 2.0f;
+    return atan2f(dy, dx);
 }
 // calc_heading_quat(_inv), phc/utils/torch_utils.py:215-240
 __device__ __forceinline__ Q4 heading_quat(const Q4 q, bool inverse) {

@@ -15,4 +15,4 @@ for G in "$G1" "$G2" "$G3"; do
   rocprofv3 --kernel-trace --pmc $G -d $D/p$i --output-format csv -- python $ROOT/tools/pmc_env_driver.py > /dev/null 2> $D/p$i.err
 done
 PMC_KERNEL_FILTER="im_step traj_step" python $ROOT/tools/pmc_gemm_report.py $D > $OUTF
-tail -3 $D/p1.err >> $OUTF
+# (round 6: the rocprofv3 log tail is no longer appended to the counter file)

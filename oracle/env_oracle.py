@@ -411,3 +411,30 @@ def post_physics_zero_out_far(rb, ref_now, ref_next, point_goal, dof_force, dof_
     to = im_obs_variant(obs_v, bp[:, 0], br[:, 0], bp[:, tb], br[:, tb], bv[:, tb], ba[:, tb], rp, rr, rv, ra, 1, upright)
     so = self_obs_smpl_max_general(bp, br, bv, ba, upright=upright)
     return {"obs": torch.cat([so, to], dim=-1), "rew": rew, "raw": raw, "reset": reset, "terminate": term, "point_goal": goal}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Small training-time options of the step composition (no shipped config enables them; humanoid.py:314-326).
+# ---------------------------------------------------------------------------------------------------------------------------
+def fut_tracks_dropout(task_obs, uniforms, time_steps, dropout_rate=0.1):
+    """_compute_task_obs, humanoid_im.py:804-810: the block of future sample t of env e is zeroed where uniforms[e, t] < 0.1
+    (``uniforms`` = the torch.rand(n, T) draw)."""
+    n = task_obs.shape[0]
+    obs = task_obs.clone().view(n, time_steps, -1)
+    mask = uniforms < dropout_rate
+    obs[mask, :] = 0
+    return obs.view(n, -1)
+
+
+def add_obs_noise(obs, z):
+    """_compute_observations, humanoid_im.py:691-692: obs + randn_like(obs) * 0.1 (``z`` = the draw)."""
+    return obs + z * 0.1
+
+
+def res_action_pd_targets(ref_dof_pos, pd_action_scale, action, dof_pos):
+    """HumanoidIm._action_to_pd_targets with res_action, humanoid_im.py:1096-1101."""
+    import numpy as np
+    pd_tar = ref_dof_pos + pd_action_scale * action
+    pd_lower = dof_pos - np.pi / 2
+    pd_upper = dof_pos + np.pi / 2
+    return torch.maximum(torch.minimum(pd_tar, pd_upper), pd_lower)

@@ -190,7 +190,7 @@ def learning_methods():
     return out
 
 
-HUMANOID_IM_METHODS = ["_compute_task_obs", "_compute_reward", "_compute_reset", "_get_state_from_motionlib_cache"]
+HUMANOID_IM_METHODS = ["_compute_task_obs", "_compute_reward", "_compute_reset", "_get_state_from_motionlib_cache", "_action_to_pd_targets"]
 
 
 def humanoid_im_methods():

@@ -25,7 +25,7 @@ HONOURED = {
     "obs_v", "self_obs_v", "past_track_steps", "force_sensor_joints", "fut_tracks", "numTrajSamples", "trajSampleTimestepInv",
     "local_root_obs", "root_height_obs", "full_body_reward", "power_reward", "power_coefficient", "reward_specs",
     "enableEarlyTermination", "episode_length", "cycle_motion", "trackBodies", "reset_bodies", "terminationDistance", "stateInit",
-    "controlFrequencyInv", "strict_eval",
+    "controlFrequencyInv", "strict_eval", "cycle_motion_xp", "fut_tracks_dropout", "add_obs_noise", "res_action",
     # zero_out_far (humanoid.py:311-329)
     "zero_out_far", "zero_out_far_train", "zero_out_far_steps", "close_distance", "far_distance",
     # robot switches the env dict may carry (robot/*.yaml merged by the caller)
@@ -44,7 +44,7 @@ HONOURED = {
     "trajSampleTimestep", "speedMin", "speedMax", "accelMax", "sharpTurnProb", "sensor_extent", "sensor_res", "fuzzy_target",
     "terrain", "terrain_obs", "terrain_obs_type", "terrain_obs_root", "use_center_height",
     # keys of THIS package (no reference counterpart): seeds of the synthetic stand-ins, stand-in selection
-    "motion_clock_seed", "shape_seed", "task_seed", "getup_seed", "physics", "contactBodies", "tarDistMin", "nearDist", "nearProb",
+    "motion_clock_seed", "obs_noise_seed", "shape_seed", "task_seed", "getup_seed", "physics", "contactBodies", "tarDistMin", "nearDist", "nearProb",
 }
 
 _SIM = "Isaac Gym scene / actor / asset creation (closed-source physics: out of scope, SURVEY.md section 2 #20, #36)"
@@ -78,12 +78,8 @@ INERT = {
 # key -> (values at which the reference's behaviour is what is built here, where the reference implements the rest)
 UNBUILT = {
     "occl_training": ((False,), "humanoid_im.py:606-612, 778-784, 827-831, 1046-1058, 1182-1183 (random body occlusion)"),
-    "fut_tracks_dropout": ((False,), "humanoid_im.py:804-810 (random zeroing of future samples)"),
-    "cycle_motion_xp": ((False,), "humanoid_im.py:1133-1134 (restart cycled motions a random metre away)"),
-    "add_obs_noise": ((False,), "humanoid_im.py:691-692 (Gaussian observation noise)"),
     "add_amp_input_noise": ((False,), "humanoid_amp.py:281-283"),
     "addInputNoise": ((False,), "vec_task / task input noise"),
-    "res_action": ((False,), "humanoid_im.py:1096-1101 (residual PD targets around the reference pose)"),
     "remove_disc_rot": ((False,), "humanoid.py:413-416 (discriminator dof subset without global rotation)"),
     "amp_obs_v": ((1,), "humanoid_amp.py:300-314, 670-680 (build_amp_observations_smpl_v2)"),
     "numAMPEncObsSteps": ("==numAMPObsSteps", "humanoid_amp.py:94, 834-880 (CALM encoder windows)"),

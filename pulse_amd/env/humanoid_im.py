@@ -104,6 +104,19 @@ class HumanoidIm:
             raise NotImplementedError("zero_out_far is defined for obs_v 4 | 5 | 6 | 7 | 8 | 9 (humanoid_im.py:761,812)")
         if self.zero_out_far and self.zero_out_far_train and not self._use_motion_lib:
             raise NotImplementedError("zero_out_far_train moves the reference by a per-env offset: needs the MotionLib reference source")
+        # four small options of the reference's step composition [r6]
+        self.cycle_motion_xp = bool(env.get("cycle_motion_xp", False))          # humanoid.py:314: a cycled motion restarts up to a metre off (humanoid_im.py:1133-1134)
+        self._fut_tracks_dropout = bool(env.get("fut_tracks_dropout", False))   # humanoid_im.py:804-810: a future sample's block is zeroed with p = 0.1
+        self.add_obs_noise = bool(env.get("add_obs_noise", False))              # humanoid_im.py:691-692: obs += 0.1 N(0, 1)
+        self._res_action = bool(env.get("res_action", False))                   # humanoid_im.py:1096-1101: PD targets = reference pose + scaled action
+        self.test = False                                                       # flags.test (run_hydra.py:284): dropout / noise are training-time only
+        if self._fut_tracks_dropout and self.obs_v not in (6, 8, 9):
+            raise NotImplementedError("fut_tracks_dropout acts on obs_v 4 | 5 | 6 | 8 | 9 only (humanoid_im.py:761-810)")
+        if self._res_action and not self._use_motion_lib:
+            raise NotImplementedError("res_action adds the action to the REFERENCE dof positions: needs the MotionLib reference source")
+        if (self._fut_tracks_dropout or self.add_obs_noise) and self.self_obs_v == 2:
+            raise NotImplementedError("fut_tracks_dropout / add_obs_noise with self_obs_v 2: not built")
+        self._noise_gen = None
         self.strict_eval = bool(env.get("strict_eval", False))                  # humanoid.py:320
         self.im_eval = False                                                    # flags.im_eval (run_hydra.py:291): set by the evaluation loop
         self.auto_pmcp = bool(env.get("auto_pmcp", False))                      # humanoid.py:318-319 -> IMAmpAgent.update_training_data
@@ -375,6 +388,14 @@ class HumanoidIm:
         self.post_physics_step()
 
     def _action_to_pd_targets(self, action):
+        if self._res_action:
+            # humanoid_im.py:1096-1101: residual action around the reference pose the last _compute_task_obs stored (ref_dof_pos = the t + 1
+            # reference's dof positions, :841-848 -- here the buffer the fused step writes for the physics stand-in), clamped to +- pi / 2
+            # around the simulated pose
+            pd_tar = self._track["dof_pos"] + self._pd_action_scale * action
+            pd_lower = self.sim.dof_pos - torch.pi / 2
+            pd_upper = self.sim.dof_pos + torch.pi / 2
+            return torch.maximum(torch.minimum(pd_tar, pd_upper), pd_lower)
         return torch.addcmul(self._pd_action_offset, self._pd_action_scale, action)   # offset + scale * action, humanoid.py:1392-1394
 
     def pre_physics_step(self, actions):
@@ -453,7 +474,10 @@ class HumanoidIm:
         self._cycle_counter.masked_fill_(ended, 60)
         root = lib.get_root_pos_smpl(ids, self._motion_start_times)["root_pos"]
         xy = self.sim.rigid_body_state[:, 0, 0:2] - root[:, 0:2]
-        if self.zero_out_far and self.zero_out_far_train:       # restart up to 5 m away from the reference (:1135-1142)
+        if self.cycle_motion_xp:                                # ... up to a metre away per axis (:1133-1134); drawn for every env (sync-free)
+            self._last_xp_uniforms = torch.rand(self.num_envs, 2, device=self.device, generator=self._clock_gen)
+            xy = xy + self._last_xp_uniforms
+        elif self.zero_out_far and self.zero_out_far_train:     # restart up to 5 m away from the reference (:1135-1142)
             xy = xy + self._far_start_xy()
         self._global_offset[:, 0:2] = torch.where(ended[:, None], xy, self._global_offset[:, 0:2])
 
@@ -489,6 +513,40 @@ class HumanoidIm:
 
     def _compute_observations(self, env_ids=None, env_mask=None, ref_next=None):
         self._im_step(PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, env_ids=env_ids, env_mask=env_mask, ref_next=ref_next)
+        self._obs_post(env_ids=env_ids, env_mask=env_mask)
+
+    def _obs_post(self, env_ids=None, env_mask=None):
+        """What the reference applies to a freshly computed observation at training time (``not flags.test``): fut_tracks_dropout
+        (_compute_task_obs, humanoid_im.py:804-810: each future sample's block of the task observation is zeroed with probability 0.1) and
+        add_obs_noise (_compute_observations, :691-692: obs + 0.1 N(0, 1) over self AND task observation).  Torch ops on the env's own row
+        buffer, only for the envs whose observation was just recomputed; the draws are kept for the CPU twin."""
+        if self.test or not (self._fut_tracks_dropout or self.add_obs_noise):
+            return
+        n, dev = self.num_envs, self.device
+        if self._noise_gen is None:
+            self._noise_gen = torch.Generator(device=dev)
+            self._noise_gen.manual_seed(int(self.cfg.get("env", self.cfg).get("obs_noise_seed", 515)))
+        sel = None
+        if env_ids is not None:
+            sel = torch.zeros(n, dtype=torch.bool, device=dev)
+            sel[env_ids] = True
+        elif env_mask is not None:
+            sel = env_mask
+        if self._fut_tracks_dropout:
+            t = self._num_traj_samples
+            u = torch.rand(n, t, device=dev, generator=self._noise_gen)
+            self._last_dropout_uniforms = u
+            drop = u < 0.1
+            if sel is not None:
+                drop = drop & sel[:, None]
+            task = self._obs_store[:, self._self_obs_size:self.num_obs].unflatten(1, (t, self._task_obs_size // t))      # a view: (N, T, per sample)
+            task.masked_fill_(drop[:, :, None], 0.0)
+        if self.add_obs_noise:
+            z = torch.randn(n, self.num_obs, device=dev, generator=self._noise_gen)
+            self._last_obs_noise = z
+            if sel is not None:
+                z = z * sel[:, None]
+            self.obs_buf.add_(z * 0.1)
 
     def _update_tensor_history(self):
         """humanoid.py:1308-1312, called before the tensors are refreshed (:1320-1321): the state the LAST observation was computed
@@ -518,6 +576,7 @@ class HumanoidIm:
             self.progress_buf += 1
             self._update_pass_time()
             self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
+        self._obs_post()
         self.extras["terminate"] = self._terminate_buf
         self.extras["reward_raw"] = self.reward_raw
         if self._enable_amp_obs:                      # HumanoidAMP.post_physics_step (humanoid_amp.py:194-210)

@@ -27,8 +27,12 @@ def _ref_motion_lib(tabs):
 
 @pytest.mark.parametrize("cycle_motion,time_steps,zof", [(False, 1, None), (False, 3, None), (True, 1, None),
                                                          # zero_out_far (phc_kp_pnn_iccv.yaml:24,36-37: obs_v 7; phc_shape_*_iccv.yaml: obs_v 6)
-                                                         (False, 1, (6, False)), (False, 1, (7, False)), (True, 1, (6, True)), (False, 1, (7, True))])
+                                                         (False, 1, (6, False)), (False, 1, (7, False)), (True, 1, (6, True)), (False, 1, (7, True)),
+                                                         (True, 1, "xp")])      # cycle_motion_xp (humanoid_im.py:1133-1134)
 def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zof):
+    xp = zof == "xp"
+    if xp:
+        zof = None
     obs_v, zof_train = zof if zof else (6, False)
     f = refload.humanoid_im_methods()
     n, dt, frames = 48, 2.0 / 60.0, 12
@@ -44,7 +48,7 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zo
     track = list(range(24))
     twin = OracleMotionEnv(OracleMotionLib(tabs), bank, torch.arange(n), torch.zeros(n, 3), syn.RESET_BODY_IDS, track, dt,
                            time_steps=time_steps, cycle_motion=cycle_motion, max_episode_length=300, obs_v=obs_v, zero_out_far=bool(zof),
-                           zero_out_far_train=zof_train, close_distance=0.3, far_distance=2.5, zero_out_far_steps=4)
+                           zero_out_far_train=zof_train, close_distance=0.3, far_distance=2.5, zero_out_far_steps=4, cycle_motion_xp=xp)
     lib = _ref_motion_lib(tabs)
     starts = OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g)
     twin.reset(torch.arange(n), starts, far_uniforms=torch.rand(n, 2, generator=g))
@@ -54,7 +58,7 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zo
         pre = {k: getattr(twin, k).clone() for k in ("progress", "start", "start_off", "offset", "cycle_counter", "point_goal")}
         cyc = OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g)
         far_u = torch.rand(n, 2, generator=g)
-        obs_t, rew_t, reset_t, info_t = twin.step(cycle_start_times=cyc, far_uniforms=far_u)
+        obs_t, rew_t, reset_t, info_t = twin.step(cycle_start_times=cyc, far_uniforms=far_u, xp_uniforms=far_u)
         rb, fidx = twin.rb, twin.frame
         task = types.SimpleNamespace(
             _rigid_body_pos=rb[..., 0:3], _rigid_body_rot=rb[..., 3:7], _rigid_body_vel=rb[..., 7:10], _rigid_body_ang_vel=rb[..., 10:13],
@@ -68,24 +72,23 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zo
             ref_body_pos_subset=torch.zeros(n, 24, 3), ref_dof_pos=torch.zeros(n, 69), dof_force_tensor=bank["dof_force"][fidx], _dof_vel=twin.dof_vel,
             reward_specs={"k_pos": 100, "k_rot": 10, "k_vel": 0.1, "k_ang_vel": 0.1, "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1},
             _full_body_reward=True, power_reward=True, power_coefficient=0.0005, rew_buf=torch.zeros(n), reward_raw=torch.zeros(n, 4),
-            max_episode_length=300, cycle_motion=cycle_motion, cycle_motion_xp=False,
+            max_episode_length=300, cycle_motion=cycle_motion, cycle_motion_xp=xp,
             _cycle_counter=torch.clamp_min(pre["cycle_counter"] - 1, 0) if (cycle_motion or zof_train) else pre["cycle_counter"].clone(),
             _sample_time=lambda ids: cyc[ids], reset_buf=torch.zeros(n, dtype=torch.int64), _terminate_buf=torch.zeros(n, dtype=torch.int64),
             _contact_forces=torch.zeros(n, 24, 3), _contact_body_ids=torch.tensor([7, 3]), _reset_bodies_id=torch.tensor(syn.RESET_BODY_IDS),
             _enable_early_termination=True, _termination_distances=torch.full((24,), 0.25), strict_eval=False)
         for k, fn in f.items():
             setattr(task, k, types.MethodType(fn, task))
-        if zof_train:                      # the far restart of a cycled motion draws torch.rand twice (humanoid_im.py:1139-1140): replay far_u there
-            draws = iter([far_u[:, 0], far_u[:, 1]])
+        if zof_train or xp:                # the far restart of a cycled motion draws torch.rand twice (humanoid_im.py:1139-1140), cycle_motion_xp once
+            draws = iter([far_u] if xp else [far_u[:, 0], far_u[:, 1]])            # ((k, 2), :1134): replay far_u there
             ended = (pre["progress"] + 1) * dt + pre["start"] + pre["start_off"] >= tabs["motion_lengths"][torch.arange(n)]
-            real_rand = torch.rand
             f["_compute_reset"].__globals__["torch"] = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
             f["_compute_reset"].__globals__["torch"].rand = lambda *a, **kw: next(draws)[ended]
         try:
             task._compute_reward(None)
             task._compute_reset()
         finally:
-            if zof_train:
+            if zof_train or xp:
                 f["_compute_reset"].__globals__["torch"] = torch
         task_obs = task._compute_task_obs()
         if zof:
@@ -104,11 +107,11 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zo
         twin.reset(ids, OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g), far_uniforms=torch.rand(n, 2, generator=g))
     if zof:
         assert seen_far > 0 and seen_inside > 0 and seen_clipped > 0, "the far / inside / direction-only branches were not all taken"
-    if zof_train:
+    if zof_train or xp:
         assert (twin.offset != 0).any()
-    elif cycle_motion:
+    if cycle_motion:
         assert checked_cycle > 0, "no motion was cycled in place"
-    else:
+    elif not zof_train:
         assert (twin.offset == 0).all()
 
 
@@ -186,3 +189,48 @@ def test_amp_window_matches_reference_methods():
     task._init_amp_obs(torch.tensor([0, 2]))
     twin.reset(torch.tensor([0, 2]), rb, dp, dv, starts, from_motion=False)
     assert torch.equal(amp_buf, twin.buf)
+
+
+def test_small_step_options_match_reference_bodies():
+    """fut_tracks_dropout inside _compute_task_obs (humanoid_im.py:804-810) and res_action's _action_to_pd_targets (:1096-1101): the
+    oracle's restatements against the reference's method bodies, the torch.rand draw replayed."""
+    from oracle import env_oracle as E
+    f = refload.humanoid_im_methods()
+    n, T = 29, 3
+    g = syn.make_generator(12)
+    tabs = syn.synthetic_motion_library(g, n, 10, 24)
+    lib = _ref_motion_lib(tabs)
+    rb = syn.rigid_body_state(g, n)
+    track = list(range(24))
+    u = torch.rand(n, T, generator=g)
+    u[0, 1] = 0.01                                                         # at least one dropped and one kept sample
+    u[1] = 0.9
+    task = types.SimpleNamespace(
+        _rigid_body_pos=rb[..., 0:3], _rigid_body_rot=rb[..., 3:7], _rigid_body_vel=rb[..., 7:10], _rigid_body_ang_vel=rb[..., 10:13], num_envs=n,
+        device="cpu", humanoid_shapes=torch.zeros(n, 17), _fut_tracks=True, _num_traj_samples=T, _traj_sample_timestep=1.0 / 30,
+        progress_buf=torch.randint(0, 5, (n,), generator=g), dt=1.0 / 30, _motion_start_times=torch.rand(n, generator=g) * 0.2,
+        _motion_start_times_offset=torch.zeros(n), _sampled_motion_ids=torch.arange(n), _global_offset=torch.zeros(n, 3), _motion_lib=lib,
+        ref_motion_cache={}, _track_bodies_id=torch.tensor(track), obs_v=6, _has_upright_start=True, zero_out_far=False, _occl_training=False,
+        _fut_tracks_dropout=False, ref_body_pos=torch.zeros(n, 24, 3), ref_body_vel=torch.zeros(n, 24, 3), ref_body_rot=torch.zeros(n, 24, 4),
+        ref_body_pos_subset=torch.zeros(n, 24, 3), ref_dof_pos=torch.zeros(n, 69))
+    for k, fn in f.items():
+        setattr(task, k, types.MethodType(fn, task))
+    clean = task._compute_task_obs()
+    task._fut_tracks_dropout = True
+    fake = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+    fake.rand = lambda *a, **kw: u
+    f["_compute_task_obs"].__globals__["torch"] = fake
+    try:
+        dropped = task._compute_task_obs()
+    finally:
+        f["_compute_task_obs"].__globals__["torch"] = torch
+    assert torch.equal(dropped, E.fut_tracks_dropout(clean, u, T))
+    assert (dropped.view(n, T, -1)[0, 1] == 0).all() and torch.equal(dropped[1], clean[1])
+    # res_action
+    act = torch.randn(n, 69, generator=g) * 2.0
+    t2 = types.SimpleNamespace(_res_action=True, ref_dof_pos=torch.randn(n, 69, generator=g), _pd_action_scale=torch.rand(69, generator=g) + 0.5,
+                               _pd_action_offset=torch.zeros(69), _dof_pos=torch.randn(n, 69, generator=g))
+    want = f["_action_to_pd_targets"](t2, act)
+    got = E.res_action_pd_targets(t2.ref_dof_pos, t2._pd_action_scale, act, t2._dof_pos)
+    assert torch.equal(want, got)
+    assert (got == t2._dof_pos + torch.pi / 2).any() or (got == t2._dof_pos - torch.pi / 2).any()      # the clamp is exercised

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 26
+#define PULSE_ABI_VERSION 27
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -218,6 +218,12 @@ typedef struct pulse_im_step_args {
        The reset stage is unchanged (:1158-1176 calls compute_humanoid_im_reset on the un-masked reference). */
     int32_t zero_out_far; float close_distance; float far_distance;
     float* point_goal;        /* (num_envs) HumanoidIm._point_goal, read by the reward stage and written by the task-observation stage */
+    /* ---- optional (v27): ``occl_training`` (humanoid.py:323-324; HumanoidIm.random_occlu_idx, humanoid_im.py:85, 1046-1058).  occl_bits[e] bit j set:
+       tracked body j of env e is occluded -- the task observation sees the simulated state as that body's reference (pos, rot, vel, ang vel for
+       obs_version 6 / 8 / 9, :778-784; pos / rot for 7, :827-831; applied after the zero_out_far masking), and, when occl_reset != 0
+       (HumanoidIm._compute_reset's else-branch, :1178-1183, which indexes the mask by BODY id: tracked bodies must be all bodies in order),
+       an occluded reset body never counts as fallen. */
+    const uint32_t* occl_bits; int32_t occl_reset;
 } pulse_im_step_args;
 
 /* sizeof(pulse_im_step_args) as compiled, so a foreign-language binding can verify its mirror */

@@ -438,3 +438,15 @@ def res_action_pd_targets(ref_dof_pos, pd_action_scale, action, dof_pos):
     pd_lower = dof_pos - np.pi / 2
     pd_upper = dof_pos + np.pi / 2
     return torch.maximum(torch.minimum(pd_tar, pd_upper), pd_lower)
+
+
+def occlude_refs(obs_v, body_pos, body_rot, body_vel, body_ang_vel, ref_pos, ref_rot, ref_vel, ref_ang_vel, occl_idx):
+    """The occl_training blocks of _compute_task_obs, humanoid_im.py:778-784 (obs_v 4 / 5 / 6 / 8 / 9: all four quantities) and :827-831 (obs_v 7:
+    positions and rotations): an occluded (env, tracked body)'s reference is the simulated state.  occl_idx (N, Jt) bool."""
+    ref_pos, ref_rot, ref_vel, ref_ang_vel = ref_pos.clone(), ref_rot.clone(), ref_vel.clone(), ref_ang_vel.clone()
+    ref_pos[occl_idx] = body_pos[occl_idx]
+    ref_rot[occl_idx] = body_rot[occl_idx]
+    if obs_v != 7:
+        ref_vel[occl_idx] = body_vel[occl_idx]
+        ref_ang_vel[occl_idx] = body_ang_vel[occl_idx]
+    return ref_pos, ref_rot, ref_vel, ref_ang_vel

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -64,6 +64,7 @@ class ImStepArgs(Structure):
         ("limb_weights", c_void_p), ("limb_weights_width", c_int32), ("limb_weights_stride", c_int64),
         ("recovery_counter", c_void_p),
         ("zero_out_far", c_int32), ("close_distance", c_float), ("far_distance", c_float), ("point_goal", c_void_p),
+        ("occl_bits", c_void_p), ("occl_reset", c_int32),
     ]
 
 

@@ -378,7 +378,12 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                     vr = v;
                     if (lane >= 1) pr = p;
                 }
-                if (zof_dir && lane == 0)            // ... and beyond far_distance the root target is only a direction
+                const bool occl = a.occl_bits && ((a.occl_bits[e] >> lane) & 1u);       // occl_training (humanoid_im.py:778-784, 827-831), after the far masking
+                if (occl) {
+                    pr = p;
+                    if (a.obs_version != 7) vr = v;
+                }
+                if (zof_dir && lane == 0 && !occl)   // ... and beyond far_distance the root target is only a direction
                     pr = V3{(pr.x - p.x) / zof_d * a.far_distance + p.x, (pr.y - p.y) / zof_d * a.far_distance + p.y,
                             (pr.z - p.z) / zof_d * a.far_distance + p.z};
                 put3(task_off(ov, 0, Jt, T, t, lane), qrot_heading(hinv, h_s, V3{pr.x - p.x, pr.y - p.y, pr.z - p.z}));
@@ -392,6 +397,7 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                         wr = w;
                         if (lane >= 1) qr = q;
                     }
+                    if (occl) { qr = q; wr = w; }
                     float tn[6];
                     int off = task_off(ov, 1, Jt, T, t, lane);
                     if (off >= 0) { q_to_tan_norm(qmul(qmul(hinv, qmul(qr, qconj(q))), hfwd), tn); put6(off, tn); }   // change of basis
@@ -486,6 +492,8 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
                 const float* r = rb_e + 13 * b;
                 const float dx = r[0] - rn_e[3 * b], dy = r[1] - rn_e[3 * b + 1], dz = r[2] - rn_e[3 * b + 2];
                 dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                // occl_training: an occluded reset body's reference is its own position (_compute_reset, humanoid_im.py:1178-1183; the mask is indexed by body id)
+                if (a.occl_bits && a.occl_reset && ((a.occl_bits[e] >> b) & 1u)) dist = 0.f;
                 fell = dist > a.term_dist[b];
             }
             int fallen;
@@ -608,6 +616,13 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
         const int ov = a.obs_version;
         PULSE_REQUIRE(!(a.what & PULSE_IM_TASK_OBS) || ov == 6 || ov == 7 || ov == 8 || ov == 9,
                       "pulse_im_step: zero_out_far is defined for obs_version 6 | 7 | 8 | 9 (humanoid_im.py:761,812), not %d", ov);
+    }
+    if (a.occl_bits) {
+        const int ov = a.obs_version;
+        PULSE_REQUIRE(!(a.what & PULSE_IM_TASK_OBS) || ov == 6 || ov == 7 || ov == 8 || ov == 9,
+                      "pulse_im_step: occl_bits is defined for obs_version 6 | 7 | 8 | 9 (humanoid_im.py:778,827), not %d", ov);
+        PULSE_REQUIRE(a.time_steps == 1, "pulse_im_step: occl_bits takes one reference sample (an (N, Jt) mask indexes an (N T, Jt, .) reference in the reference)");
+        PULSE_REQUIRE(!a.occl_reset || a.num_track == a.num_bodies, "pulse_im_step: occl_reset indexes the mask by body id: every body must be tracked, in order");
     }
     if (a.use_motion) {
         const pulse_motion_tables& M = a.motion;

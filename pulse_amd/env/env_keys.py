@@ -26,6 +26,7 @@ HONOURED = {
     "local_root_obs", "root_height_obs", "full_body_reward", "power_reward", "power_coefficient", "reward_specs",
     "enableEarlyTermination", "episode_length", "cycle_motion", "trackBodies", "reset_bodies", "terminationDistance", "stateInit",
     "controlFrequencyInv", "strict_eval", "cycle_motion_xp", "fut_tracks_dropout", "add_obs_noise", "res_action",
+    "occl_training", "occl_training_prob",
     # zero_out_far (humanoid.py:311-329)
     "zero_out_far", "zero_out_far_train", "zero_out_far_steps", "close_distance", "far_distance",
     # robot switches the env dict may carry (robot/*.yaml merged by the caller)
@@ -44,7 +45,7 @@ HONOURED = {
     "trajSampleTimestep", "speedMin", "speedMax", "accelMax", "sharpTurnProb", "sensor_extent", "sensor_res", "fuzzy_target",
     "terrain", "terrain_obs", "terrain_obs_type", "terrain_obs_root", "use_center_height",
     # keys of THIS package (no reference counterpart): seeds of the synthetic stand-ins, stand-in selection
-    "motion_clock_seed", "obs_noise_seed", "shape_seed", "task_seed", "getup_seed", "physics", "contactBodies", "tarDistMin", "nearDist", "nearProb",
+    "motion_clock_seed", "obs_noise_seed", "occl_seed", "shape_seed", "task_seed", "getup_seed", "physics", "contactBodies", "tarDistMin", "nearDist", "nearProb",
 }
 
 _SIM = "Isaac Gym scene / actor / asset creation (closed-source physics: out of scope, SURVEY.md section 2 #20, #36)"
@@ -66,7 +67,6 @@ INERT = {
     "num_prim": _TEACH, "training_prim": _TEACH, "actors_to_load": _TEACH, "has_lateral": _TEACH,
     "distill_model_config": "structure of the frozen PULSE networks: HumanoidZ.initialize_z_models takes the checkpoint and network params as arguments",
     "hybridInitProb": "only read when stateInit is Hybrid (humanoid_amp.py:490-505), which raises here",
-    "occl_training_prob": "only read when occl_training is on, which raises here",
     "power_usage_coefficient": "only read when power_usage_reward is on, which raises here",
     "dict_size": "VQ dictionary size: only read for z_type vq_vae variants, which raise here",
     "embedding_partion": "VQ partition count: only read for z_type vq_vae variants, which raise here",
@@ -77,7 +77,6 @@ INERT = {
 
 # key -> (values at which the reference's behaviour is what is built here, where the reference implements the rest)
 UNBUILT = {
-    "occl_training": ((False,), "humanoid_im.py:606-612, 778-784, 827-831, 1046-1058, 1182-1183 (random body occlusion)"),
     "add_amp_input_noise": ((False,), "humanoid_amp.py:281-283"),
     "addInputNoise": ((False,), "vec_task / task input noise"),
     "remove_disc_rot": ((False,), "humanoid.py:413-416 (discriminator dof subset without global rotation)"),

@@ -110,6 +110,9 @@ class HumanoidIm:
         self.add_obs_noise = bool(env.get("add_obs_noise", False))              # humanoid_im.py:691-692: obs += 0.1 N(0, 1)
         self._res_action = bool(env.get("res_action", False))                   # humanoid_im.py:1096-1101: PD targets = reference pose + scaled action
         self.test = False                                                       # flags.test (run_hydra.py:284): dropout / noise are training-time only
+        # occl_training (humanoid.py:323-324): tracked bodies whose reference the task observation does not get to see
+        self._occl_training = bool(env.get("occl_training", False))
+        self._occl_training_prob = float(env.get("occl_training_prob", 0.1))
         if self._fut_tracks_dropout and self.obs_v not in (6, 8, 9):
             raise NotImplementedError("fut_tracks_dropout acts on obs_v 4 | 5 | 6 | 8 | 9 only (humanoid_im.py:761-810)")
         if self._res_action and not self._use_motion_lib:
@@ -166,6 +169,17 @@ class HumanoidIm:
         self._terminate_buf = torch.zeros(n, dtype=torch.int64, device=dev)
         self._cycle_counter = torch.zeros(n, dtype=torch.int64, device=dev)
         self._point_goal = torch.zeros(n, device=dev)                          # humanoid_im.py:84
+        if self._occl_training:
+            jt = self._track_bodies_id.numel()
+            if jt != self.num_bodies or self._fut_tracks or self.obs_v not in (6, 7, 8, 9):
+                raise NotImplementedError("occl_training: the reference's mask update indexes columns 9 .. 23 and its reset indexes the mask by body id "
+                                          "(humanoid_im.py:1058, 1183): all 24 bodies tracked, one reference sample, obs_v 4 | 5 | 6 | 7 | 8 | 9")
+            self.random_occlu_idx = torch.zeros(n, jt, dtype=torch.bool, device=dev)            # humanoid_im.py:85-86
+            self.random_occlu_count = torch.zeros(n, jt, dtype=torch.int64, device=dev)
+            self._occl_bits = torch.zeros(n, dtype=torch.int32, device=dev)
+            self._occl_weights = (1 << torch.arange(jt, device=dev, dtype=torch.int64))
+            self._occl_gen = torch.Generator(device=dev)
+            self._occl_gen.manual_seed(int(env.get("occl_seed", 909)))
         self._motion_start_times = torch.zeros(n, device=dev)
         self._motion_start_times_offset = torch.zeros(n, device=dev)
         self._pass_time = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -402,6 +416,8 @@ class HumanoidIm:
         self.actions = actions
         if (self.cycle_motion or (self.zero_out_far and self.zero_out_far_train)) and self._use_motion_lib:
             self._update_cycle_count()                      # (the counter only ever leaves zero in these modes)
+        if self._occl_training:
+            self._update_occl_training()                    # humanoid_im.py:1114-1115
         self.sim.set_dof_position_target_tensor(self._action_to_pd_targets(actions))
 
     def _physics_step(self):
@@ -442,6 +458,9 @@ class HumanoidIm:
             extra["recovery_counter"] = rc
         if self.zero_out_far:
             extra["zero_out_far"] = {"point_goal": self._point_goal, "close_distance": self.close_distance, "far_distance": self.far_distance}
+        if self._occl_training:
+            # the reset only masks occluded bodies in _compute_reset's else-branch (humanoid_im.py:1158 vs :1178-1183)
+            extra["occl_bits"], extra["occl_reset"] = self._occl_bits, not (self.zero_out_far and self.zero_out_far_train)
         # the step and the masked-reset launch repeat with the same buffers every control step: their argument structs are cached per phase
         cache = self._im_launch_cache.setdefault((what, inc, env_ids is None, env_mask is None), {})
         return ops.im_step(
@@ -489,6 +508,26 @@ class HumanoidIm:
         rand_distance = torch.sqrt(u[:, 0]) * 5
         rand_angle = u[:, 1] * torch.pi * 2
         return torch.stack([torch.cos(rand_angle) * rand_distance, torch.sin(rand_angle) * rand_distance], dim=-1)
+
+    def _update_occl_training(self):
+        """HumanoidIm._update_occl_training, humanoid_im.py:1046-1058, statement for statement: bodies start an occlusion of 30 .. 59 steps with
+        probability occl_training_prob per step (never the root) -- and then the reference OVERWRITES the mask (its last two statements: every
+        tracked body occluded except columns 9 .. 23), so what the observation sees is bodies 0 .. 8 hidden; the draws only advance the counters."""
+        n, jt = self.random_occlu_idx.shape
+        idx = torch.bernoulli(torch.full((n, jt), self._occl_training_prob, device=self.device), generator=self._occl_gen).bool()
+        idx[:, 0] = False
+        fresh = torch.randint(30, 60, (n, jt), device=self.device, generator=self._occl_gen)       # (drawn for every slot: sync-free masked form)
+        self.random_occlu_count = torch.where(idx, fresh, self.random_occlu_count)
+        self.random_occlu_count -= 1
+        self.random_occlu_count = torch.clamp_min(self.random_occlu_count, 0)
+        self.random_occlu_idx = self.random_occlu_count > 0
+        self.random_occlu_idx[:] = True
+        self.random_occlu_idx[:, [9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23]] = False
+        self._pack_occl_bits()
+
+    def _pack_occl_bits(self):
+        """random_occlu_idx (N, Jt) bool -> one 32-bit word per env for the fused step (bit j = tracked body j)."""
+        self._occl_bits.copy_((self.random_occlu_idx.to(torch.int64) * self._occl_weights).sum(dim=1).to(torch.int32))
 
     def resample_motions(self):
         """HumanoidIm.resample_motions (humanoid_im.py:350-377), called by AMPAgent.pre_epoch every shape_resampling_interval epochs: the

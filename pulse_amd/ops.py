@@ -219,8 +219,10 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
             env_ids=None, env_mask=None, obs=None, obs_cols=None, rew=None, rew_raw=None, reset=None,
             terminate=None, clock=None, motion=None, upright=True, enable_early_termination=True, self_obs_version=1,
             force_sensor=None, dof_pos=None, ref_next_dof_pos=None, smpl_params=None, limb_weights=None, recovery_counter=None, cache=None,
-            zero_out_far=None):
-    """``zero_out_far``: dict(point_goal (N,) float32 read by the reward stage / written by the task-observation stage, close_distance,
+            zero_out_far=None, occl_bits=None, occl_reset=False):
+    """``occl_bits``: (N,) int32, bit j = tracked body j of the env is occluded (occl_training, humanoid_im.py:778-784, 827-831); ``occl_reset``:
+    occluded reset bodies never count as fallen (:1178-1183).
+    ``zero_out_far``: dict(point_goal (N,) float32 read by the reward stage / written by the task-observation stage, close_distance,
     far_distance) -- the far-masking branch of _compute_task_obs / _compute_reward (humanoid_im.py:763-777, 814-826, 870-887).
     ``cache``: a dict owned by a caller that launches the same step on the same buffers over and over (the env's post-physics step): the
     filled argument struct is kept in it and re-launched as long as the arguments' signature (_launch_sig) does not change -- the struct takes
@@ -236,7 +238,7 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         sig = _launch_sig((rb, what, ref_now, ref_next, time_steps, dof_force, dof_vel, progress, pass_time, cycle_counter, track_ids, reset_ids, term_dist,
                            reset_use_mean, full_body_reward, obs_version, local_root_obs, root_height_obs, specs, power_coef, power_reward, env_ids, env_mask,
                            obs, obs_cols, rew, rew_raw, reset, terminate, clock, motion, upright, enable_early_termination, self_obs_version, force_sensor,
-                           dof_pos, ref_next_dof_pos, smpl_params, limb_weights, recovery_counter, zero_out_far, _IM_DEBUG_BITS))
+                           dof_pos, ref_next_dof_pos, smpl_params, limb_weights, recovery_counter, zero_out_far, occl_bits, occl_reset, _IM_DEBUG_BITS))
         if cache.get("sig") == sig:
             _lib.check(lib.pulse_im_step(ctypes.byref(cache["args"]), _stream()), "pulse_im_step")
             return cache["out"]
@@ -291,6 +293,10 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
             fsw += t.shape[1]
     if recovery_counter is not None:
         a.recovery_counter = P(recovery_counter, "recovery_counter", torch.int32)
+    if occl_bits is not None:
+        if occl_bits.shape != (n,) or occl_bits.dtype != torch.int32:
+            raise ValueError("occl_bits: (num_envs,) int32 expected")
+        a.occl_bits, a.occl_reset = P(occl_bits, "occl_bits", torch.int32), int(bool(occl_reset))
     if zero_out_far is not None:
         pg = zero_out_far["point_goal"]
         if pg.shape != (n,) or not pg.is_contiguous():

@@ -28,9 +28,16 @@ def _ref_motion_lib(tabs):
 @pytest.mark.parametrize("cycle_motion,time_steps,zof", [(False, 1, None), (False, 3, None), (True, 1, None),
                                                          # zero_out_far (phc_kp_pnn_iccv.yaml:24,36-37: obs_v 7; phc_shape_*_iccv.yaml: obs_v 6)
                                                          (False, 1, (6, False)), (False, 1, (7, False)), (True, 1, (6, True)), (False, 1, (7, True)),
-                                                         (True, 1, "xp")])      # cycle_motion_xp (humanoid_im.py:1133-1134)
+                                                         (True, 1, "xp"),       # cycle_motion_xp (humanoid_im.py:1133-1134)
+                                                         # occl_training (:778-784, 827-831, 1178-1183) with a fresh random mask per step, alone and
+                                                         # on top of zero_out_far
+                                                         (False, 1, "occl6"), (False, 1, "occl7"), (False, 1, "occl6zof")])
 def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zof):
     xp = zof == "xp"
+    occl = isinstance(zof, str) and zof.startswith("occl")
+    if occl:
+        zof = {"occl6": None, "occl7": (7, False), "occl6zof": (6, False)}[zof]
+        occl_v7_plain = zof == (7, False)
     if xp:
         zof = None
     obs_v, zof_train = zof if zof else (6, False)
@@ -58,6 +65,8 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zo
         pre = {k: getattr(twin, k).clone() for k in ("progress", "start", "start_off", "offset", "cycle_counter", "point_goal")}
         cyc = OracleMotionLib(tabs).sample_time_interval(torch.arange(n), generator=g)
         far_u = torch.rand(n, 2, generator=g)
+        if occl:
+            twin.occl_idx = torch.rand(n, 24, generator=g) < 0.3
         obs_t, rew_t, reset_t, info_t = twin.step(cycle_start_times=cyc, far_uniforms=far_u, xp_uniforms=far_u)
         rb, fidx = twin.rb, twin.frame
         task = types.SimpleNamespace(
@@ -67,7 +76,7 @@ def test_step_composition_matches_reference_methods(cycle_motion, time_steps, zo
             _motion_start_times=pre["start"].clone(), _motion_start_times_offset=pre["start_off"].clone(), _sampled_motion_ids=torch.arange(n),
             _global_offset=pre["offset"].clone(), _motion_lib=lib, ref_motion_cache={}, _track_bodies_id=torch.tensor(track), obs_v=obs_v,
             _has_upright_start=True, zero_out_far=bool(zof), zero_out_far_train=zof_train, close_distance=0.3, far_distance=2.5,
-            _point_goal=pre["point_goal"].clone(), _occl_training=False, _fut_tracks_dropout=False,
+            _point_goal=pre["point_goal"].clone(), _occl_training=occl, random_occlu_idx=twin.occl_idx, _fut_tracks_dropout=False,
             ref_body_pos=torch.zeros(n, 24, 3), ref_body_vel=torch.zeros(n, 24, 3), ref_body_rot=torch.zeros(n, 24, 4),
             ref_body_pos_subset=torch.zeros(n, 24, 3), ref_dof_pos=torch.zeros(n, 69), dof_force_tensor=bank["dof_force"][fidx], _dof_vel=twin.dof_vel,
             reward_specs={"k_pos": 100, "k_rot": 10, "k_vel": 0.1, "k_ang_vel": 0.1, "w_pos": 0.5, "w_rot": 0.3, "w_vel": 0.1, "w_ang_vel": 0.1},

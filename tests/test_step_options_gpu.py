@@ -101,3 +101,59 @@ def test_res_action_pd_targets(dev):
         np.testing.assert_allclose(seen[-1].cpu().numpy(), want.numpy(), atol=1e-6, rtol=0)
     with pytest.raises(NotImplementedError):
         configs.make_env(8, 4, dev, env_overrides={"res_action": True})      # recorded reference frames carry no reference dof positions
+
+
+@pytest.mark.parametrize("overrides", [{}, {"obs_v": 7}, {"zero_out_far": True, "zero_out_far_train": False}])
+def test_occl_training_lockstep(dev, overrides):
+    """occl_training (humanoid_im.py:778-784, 827-831, 1178-1183): the fused step with a per-env occlusion word against the CPU twin (pinned to
+    the reference's method bodies), a fresh RANDOM mask every step -- the generality the reference's data structure has -- and then the
+    reference's own mask update, whose last two statements fix the mask to bodies 0 .. 8."""
+    n, seed = 61, 321
+    env, task = _env(dev, n, dict({"occl_training": True}, **overrides), seed)
+    tabs = syn.synthetic_motion_library(syn.make_generator(seed + 5, 0), min(n, 1024))
+    twin = OracleMotionEnv(OracleMotionLib(tabs), {k: v.cpu() for k, v in task.sim.bank.items()}, task._sampled_motion_ids.cpu(), task._global_offset.cpu(),
+                           task._reset_bodies_id.cpu().long(), task._track_bodies_id.cpu().long(), task.dt, obs_v=task.obs_v,
+                           zero_out_far=task.zero_out_far, zero_out_far_train=False)
+    g = torch.Generator().manual_seed(5)
+    real_update = task._update_occl_training
+
+    def random_mask():
+        m = torch.rand(n, 24, generator=g) < 0.3
+        task.random_occlu_idx = m.to(dev)
+        task._pack_occl_bits()
+        twin.occl_idx = m
+
+    task._update_occl_training = random_mask
+    random_mask()
+    obs = env.reset()
+    o_ref = twin.reset(torch.arange(n), task._motion_start_times.cpu())
+    np.testing.assert_allclose(obs.cpu().numpy(), o_ref.numpy(), atol=5e-5, rtol=1e-5)
+    dones = 0
+    for step in range(30):
+        obs, rew, done, info = env.step(torch.zeros(n, 69, device=dev))          # pre_physics_step installs the step's mask
+        o_ref, r_ref, d_ref, i_ref = twin.step()
+        np.testing.assert_allclose(rew.cpu().numpy(), r_ref.numpy(), atol=2e-5, rtol=1e-5)
+        assert torch.equal(done.cpu(), d_ref) and torch.equal(info["terminate"].cpu(), i_ref["terminate"]), f"flags step {step}"
+        np.testing.assert_allclose(obs.cpu().numpy(), o_ref.numpy(), atol=5e-5, rtol=1e-5, err_msg=f"obs step {step}")
+        ids = torch.nonzero(d_ref).flatten()
+        dones += ids.numel()
+        obs = env.reset(ids.to(dev))
+        if ids.numel():
+            o_ref = twin.reset(ids, task._motion_start_times.cpu())
+            np.testing.assert_allclose(obs.cpu().numpy(), o_ref.numpy(), atol=5e-5, rtol=1e-5)
+    assert dones > 0
+    # an occluded body's difference blocks are exact zeros
+    sw = task._self_obs_size
+    dpos = obs[:, sw:sw + 72].cpu().view(n, 24, 3)
+    assert (dpos[twin.occl_idx] == 0).all() and (dpos[~twin.occl_idx] != 0).any()
+    # the reference's own update: whatever it draws, the mask it leaves is bodies 0 .. 8
+    real_update()
+    want = torch.zeros(n, 24, dtype=torch.bool)
+    want[:, :9] = True
+    assert torch.equal(task.random_occlu_idx.cpu(), want) and (task._occl_bits.cpu() == 0x1FF).all()
+    assert (task.random_occlu_count >= 0).all() and (task.random_occlu_count[:, 0] == 0).all() and (task.random_occlu_count > 0).any()
+
+
+def test_occl_training_needs_the_full_body(dev):
+    with pytest.raises(NotImplementedError):
+        configs.make_env(8, 4, dev, reference="motion_lib", env_overrides={"occl_training": True, "trackBodies": ["Head", "L_Hand", "R_Hand"], "obs_v": 7})

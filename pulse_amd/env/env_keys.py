@@ -32,7 +32,7 @@ HONOURED = {
     # robot switches the env dict may carry (robot/*.yaml merged by the caller)
     "has_upright_start", "has_dof_subset", "has_shape_obs", "has_weight_obs",
     # AMP observations
-    "enable_amp_obs", "numAMPObsSteps", "ampRootHeightObs", "key_bodies",
+    "enable_amp_obs", "numAMPObsSteps", "ampRootHeightObs", "key_bodies", "add_amp_input_noise",
     # PULSE / distillation attributes the agent reads off the task (amp_agent.py:59-63, 773-832)
     "temp_running_mean", "kin_lr", "save_kin_info", "only_kin_loss", "distill", "z_type", "kld_coefficient", "kld_coefficient_min",
     "ar1_coefficient", "kld_anneal", "use_ar1_prior", "use_vae_prior", "use_vae_prior_regu", "embedding_size", "embedding_norm",
@@ -77,7 +77,6 @@ INERT = {
 
 # key -> (values at which the reference's behaviour is what is built here, where the reference implements the rest)
 UNBUILT = {
-    "add_amp_input_noise": ((False,), "humanoid_amp.py:281-283"),
     "addInputNoise": ((False,), "vec_task / task input noise"),
     "remove_disc_rot": ((False,), "humanoid.py:413-416 (discriminator dof subset without global rotation)"),
     "amp_obs_v": ((1,), "humanoid_amp.py:300-314, 670-680 (build_amp_observations_smpl_v2)"),

@@ -248,6 +248,7 @@ class HumanoidIm:
             self._amp_obs_buf = torch.zeros(n, self._num_amp_obs_steps, self._num_amp_obs_per_step, device=dev)
             self._amp_fused = os.environ.get("PULSE_AMP_FUSED", "1") != "0"      # fused history update / history init kernels (0: the op-by-op path)
             self._amp_obs_sink = None
+            self._add_amp_input_noise = bool(env.get("add_amp_input_noise", False))        # humanoid_amp.py:135, 281-283: demo windows + 0.01 N(0, 1)
             self._curr_amp_obs_buf = self._amp_obs_buf[:, 0]
             self._hist_amp_obs_buf = self._amp_obs_buf[:, 1:]
             self._amp_obs_space = Box(-float("inf"), float("inf"), (self.get_num_amp_obs(),))
@@ -383,7 +384,11 @@ class HumanoidIm:
             rb, dp, dv = self._motion_lib.sample_demo_states(num_samples * s)
         out = ops.build_amp_observations_smpl(rb, dp, dv, self._key_body_ids, joint_ids=self._amp_joint_ids, zero_joints=(), local_root_obs=self._local_root_obs,
                                               root_height_obs=self._amp_root_height_obs)
-        return out.view(num_samples, s * self._num_amp_obs_per_step)
+        out = out.view(num_samples, s * self._num_amp_obs_per_step)
+        if self._add_amp_input_noise:                      # build_amp_obs_demo's last statement (humanoid_amp.py:281-283)
+            self._last_amp_noise = torch.randn(out.shape, device=self.device, generator=self._clock_gen if self._use_motion_lib else None)
+            out = out + self._last_amp_noise * 0.01
+        return out
 
     def get_task_obs_size_detail(self):
         return self._task_obs_size_detail

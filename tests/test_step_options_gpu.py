@@ -157,3 +157,14 @@ def test_occl_training_lockstep(dev, overrides):
 def test_occl_training_needs_the_full_body(dev):
     with pytest.raises(NotImplementedError):
         configs.make_env(8, 4, dev, reference="motion_lib", env_overrides={"occl_training": True, "trackBodies": ["Head", "L_Hand", "R_Hand"], "obs_v": 7})
+
+
+def test_add_amp_input_noise(dev):
+    """humanoid_amp.py:281-283: demo windows + 0.01 N(0, 1)."""
+    n = 16
+    e0, t0 = configs.make_env(n, 8, dev, seed=77, env_kind="amp", reference="motion_lib")[0], None
+    e1 = configs.make_env(n, 8, dev, seed=77, env_kind="amp", reference="motion_lib", env_overrides={"add_amp_input_noise": True})[0]
+    e0.reset(); e1.reset()
+    a, b = e0.fetch_amp_obs_demo(24), e1.fetch_amp_obs_demo(24)
+    np.testing.assert_allclose(b.cpu().numpy(), (a + e1.task._last_amp_noise * 0.01).cpu().numpy(), atol=1e-6, rtol=0)
+    assert (a != b).any()

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 27
+#define PULSE_ABI_VERSION 28
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -614,6 +614,12 @@ typedef struct pulse_gemm_x3p_desc {
        out_colsum[z * stride_out_colsum + tile_m * ld_out_colsum + n], tile_m = 0 .. pulse_gemm_x3p_row_tiles(M, N, batch) - 1.  The input-
        gradient launch that produces a layer's dZ hands over the layer's bias gradient (sum the tile rows) without a pass over dZ. */
     float* out_colsum; int64_t stride_out_colsum; int32_t ld_out_colsum;
+    /* optional (v28): the ReLU derivative as a bit mask, as in pulse_gemm_desc.relu_mask but in the byte layout the planar epilogue's threads own
+       (eight consecutive columns of one row): byte [r * ld_mask8 + (c >> 3)] of batch z's mask (relu_mask8 + z * stride_mask8 bytes), bit (c & 7) <->
+       output (r, c).  A PULSE_EPI_BIAS_ACT + PULSE_ACT_RELU launch with relu_mask8 != NULL records it (after the bf16 rounding of single-plane mode:
+       exactly the stored activation's sign); a PULSE_EPI_RELU_GRAD launch with aux == NULL reads it instead of the activation matrix -- 1 / 16 of the
+       bytes of a bf16 aux, 1 / 32 of an fp32 one; same values.  ld_mask8 >= roundup8(N) / 8. */
+    uint8_t* relu_mask8; int32_t ld_mask8; int64_t stride_mask8;
 } pulse_gemm_x3p_desc;
 /* number of row tiles (256 or 128 rows) a launch of this shape uses: the row count of out_colsum */
 int pulse_gemm_x3p_row_tiles(int32_t M, int32_t N, int32_t batch);

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -199,7 +199,8 @@ class GemmX3pDesc(Structure):
                 ("stride_bias", c_int64), ("stride_aux", c_int64),
                 ("split_k", c_int32), ("split_stride", c_int64), ("activation", c_int32), ("epilogue", c_int32),
                 ("rowsum", c_void_p), ("stride_rowsum", c_int64), ("planes", c_int32), ("aux_is_bf16", c_int32),
-                ("out_colsum", c_void_p), ("stride_out_colsum", c_int64), ("ld_out_colsum", c_int32)]
+                ("out_colsum", c_void_p), ("stride_out_colsum", c_int64), ("ld_out_colsum", c_int32),
+                ("relu_mask8", c_void_p), ("ld_mask8", c_int32), ("stride_mask8", c_int64)]
 
 
 class GemmDesc(Structure):

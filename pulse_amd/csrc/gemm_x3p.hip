@@ -64,6 +64,7 @@ struct XpArgs {
     float* rowsum; long long sRowsum;
     float* colsum; long long sColsum; int ldcs;      // optional: per-row-tile column sums of the OUTPUT (colsum[bz * sColsum + tm * ldcs + n])
     long long* dbg;                                  // optional per-workgroup wall-clock stamps (tools/gemm_b16_phases.py; pulse_gemm_set_debug_buffer)
+    unsigned char* mask8; int ldm8; long long sM8;   // ReLU bit mask, one byte per (row, 8 columns): written by EPI 0 + relu, read by EPI 1 when there is no aux
 };
 
 template <int WMW>
@@ -128,6 +129,8 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
         unsigned short* Cp = g.Cp ? g.Cp + bz * g.sCp : nullptr;
         const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
         const unsigned short* aux16 = g.aux16 ? g.aux16 + bz * g.sAux : nullptr;
+        unsigned char* mask8 = g.mask8 ? g.mask8 + bz * g.sM8 : nullptr;
+        const bool use_mask = g.epi == 1 && aux == nullptr && aux16 == nullptr;
         const int c8 = (tid & 15) * 8;
         const int col = n0 + c8;
         constexpr int RPI = G::NT / 16;                             // rows per iteration
@@ -148,6 +151,12 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
                 }
                 if (g.epi == 0) {
                     if (g.act == 1) {
+                        if (mask8) {                                // the sign bits of this thread's eight outputs: one byte nobody else touches
+                            unsigned bits = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) bits |= (col + k < g.N && o[k] > 0.f ? 1u : 0u) << k;
+                            mask8[(long long)row * g.ldm8 + (col >> 3)] = (unsigned char)bits;
+                        }
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
                     } else if (g.act == 2) {
@@ -159,6 +168,10 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
                     }
+                } else if (use_mask) {                              // relu-grad from the forward's sign bits (one byte instead of 16 / 32 of activations)
+                    const unsigned bits = mask8[(long long)row * g.ldm8 + (col >> 3)];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = ((bits >> k) & 1u) ? o[k] : 0.f;
                 } else {
                     float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     if (aux16) {                                    // bf16-stored activations (rows hold roundup8(N) columns)
@@ -1041,7 +1054,11 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
                              (d->stride_cp % 8) == 0), "pulse_gemm_x3p: Cp rows must be 16-byte aligned and hold roundup8(N) columns");
     PULSE_REQUIRE(!d->Cp || d->split_k == 1, "pulse_gemm_x3p: split-K slabs carry no planes");
     PULSE_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2 && d->activation >= 0 && d->activation <= 2, "pulse_gemm_x3p: bad epilogue / activation");
-    PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr, "pulse_gemm_x3p: gradient epilogue needs aux");
+    PULSE_REQUIRE(d->epilogue == 0 || d->aux != nullptr || (d->epilogue == PULSE_EPI_RELU_GRAD && d->relu_mask8 != nullptr),
+                  "pulse_gemm_x3p: gradient epilogue needs aux (or, for relu-grad, relu_mask8)");
+    const bool mask8_on = d->relu_mask8 != nullptr && ((d->epilogue == PULSE_EPI_RELU_GRAD && d->aux == nullptr) ||
+                                                       (d->epilogue == PULSE_EPI_BIAS_ACT && d->activation == PULSE_ACT_RELU));
+    PULSE_REQUIRE(!mask8_on || (d->ld_mask8 >= (d->N + 7) / 8 && d->split_k == 1), "pulse_gemm_x3p: relu_mask8 needs ld_mask8 >= roundup8(N) / 8 and no split-K");
     if (d->aux_is_bf16) {
         PULSE_REQUIRE(!d->aux || ((reinterpret_cast<uintptr_t>(d->aux) & 15) == 0 && (d->ldaux % 8) == 0 && (d->stride_aux % 8) == 0 && d->ldaux >= ((d->N + 7) & ~7)),
                       "pulse_gemm_x3p: bf16 aux rows must be 16-byte aligned and hold roundup8(N) columns");
@@ -1073,6 +1090,7 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     g.act = d->activation; g.epi = d->epilogue;
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.colsum = d->out_colsum; g.sColsum = d->stride_out_colsum; g.ldcs = d->ld_out_colsum;
+    g.mask8 = mask8_on ? d->relu_mask8 : nullptr; g.ldm8 = d->ld_mask8; g.sM8 = d->stride_mask8;
     g.dbg = gemm_debug_buffer();
     PULSE_REQUIRE(!d->out_colsum || (d->split_k == 1 && d->ld_out_colsum >= d->N), "pulse_gemm_x3p: out_colsum needs split_k == 1 and a pitch covering N");
     const bool big = xp_big_tiles(d->M, d->N, d->batch, d->split_k);

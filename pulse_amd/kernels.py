@@ -119,6 +119,12 @@ def alloc_relu_mask(rows, cols, device):
     return torch.zeros((rows + 63) // 64 * 8, (cols + 3) // 4, dtype=torch.int32, device=device)
 
 
+def alloc_relu_mask8(rows, cols, device):
+    """The ReLU bit mask of a (rows, cols) activation matrix in the planar kernels' layout (pulse_gemm_x3p_desc.relu_mask8): one byte per row
+    and 8 columns."""
+    return torch.zeros(rows, (cols + 7) // 8, dtype=torch.uint8, device=device)
+
+
 def dw_split(tiles, max_split, fill=512):
     """Batch-split of a weight-gradient GEMM: the smallest power-of-two fraction of ``max_split`` (the slab count of the gradient
     buffer) that still gives ``fill`` workgroups = two per CU.  Fewer, longer reductions amortise each workgroup's prologue /
@@ -420,7 +426,8 @@ def make_gemm_x3p_desc(A, B, *, M, N, K, C=None, Cp=None, bias=None, activation=
                        ldc2=0, ldc=0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_cp=0, stride_c2=0, stride_bias=0, stride_aux=0,
                        a_off=0, b_off=0, c_off=0, cp_off=0, bias_off=0, aux_off=0, c2_off=0, algo_k=None, algo_n=None, planes=3,
                        a_layout=GEMM_RED_CONTIG, b_layout=GEMM_RED_CONTIG, split_k=1, split_stride=0, lda=None, ldb=None, ldcp=None,
-                       out_colsum=None, out_colsum_off=0, stride_out_colsum=0, ld_out_colsum=None):
+                       out_colsum=None, out_colsum_off=0, stride_out_colsum=0, ld_out_colsum=None, relu_mask8=None, ld_mask8=None, stride_mask8=0,
+                       mask8_off=0):
     """planes=3: A / B / Cp are planes tensors (3, rows, pitch) int16.  planes=1 (bf16 operands): (rows, pitch) int16 matrices (or flat
     int16 buffers with lda / ldb / ldcp given), aux may be one too (ReLU-mask / SiLU-derivative epilogues reading bf16 activations).
     *_off are element offsets.  Returns (descriptor, algorithmic FLOPs, tag) like make_gemm_desc."""
@@ -460,6 +467,11 @@ def make_gemm_x3p_desc(A, B, *, M, N, K, C=None, Cp=None, bias=None, activation=
         if out_colsum.dim() != 2 or out_colsum.shape[0] < need:
             raise ValueError(f"gemm_x3p: out_colsum needs {need} rows (one per row tile)")
         d.out_colsum, d.stride_out_colsum, d.ld_out_colsum = out_colsum.data_ptr() + 4 * out_colsum_off, stride_out_colsum, ld
+    if relu_mask8 is not None:             # uint8 (rows, roundup8(cols) / 8): alloc_relu_mask8; offsets / strides in bytes
+        if relu_mask8.dtype != torch.uint8:
+            raise TypeError("relu_mask8 must be a uint8 tensor (alloc_relu_mask8)")
+        d.relu_mask8 = relu_mask8.data_ptr() + int(mask8_off)
+        d.ld_mask8, d.stride_mask8 = int(relu_mask8.stride(0) if ld_mask8 is None else ld_mask8), int(stride_mask8)
     flops = 2.0 * M * (algo_n if algo_n else N) * (algo_k if algo_k else K) * batch
     kc_a, kc_b = a_layout == GEMM_RED_CONTIG, b_layout == GEMM_RED_CONTIG
     tag = ("x3p_" if planes == 3 else "b16_") + ("fwd" if kc_a and kc_b else "dx" if kc_a else "dw")

@@ -28,6 +28,7 @@ import torch
 
 from .. import kernels as K
 from .._lib import ACT_NONE, ACT_RELU, EPI_RELU_GRAD, GEMM_OUT_CONTIG
+from . import network as _network
 from .graph import Linear, ParamBook, init_linear_, r4
 
 
@@ -111,6 +112,8 @@ class DiscNetwork:
                 self._flat16 = i16(1, (self.n_flat + 7) // 8 * 8).view(-1)
                 self._w1t16 = i16(self.k0, self.u1)          # W1^T: dD/dx = u1 W1 in the forward form
                 self._w2t16 = i16(self.u1, self.u2)          # W2^T
+            if _network.RELU_BITMASK:   # [r6] sign bits of H1 / H2 (rows of the 3b forward rows): what the six relu-grad launches read instead of the activations
+                ws["M1"], ws["M2"] = K.alloc_relu_mask8(m, self.u1, dev), K.alloc_relu_mask8(m, self.u2, dev)
             ws["fwd"], ws["bwd_bce"], ws["pen_fwd"], ws["pen_bwd"], ws["wgrad"] = self._plans_b16(ws)
         else:
             ws.update({"X": z(m, self.k0p), "H1": z(m, self.u1), "H2": z(m, self.u2), "Z1": z(m, self.u1), "Z2": z(m, self.u2), "dL": z(m, 4)})
@@ -135,29 +138,32 @@ class DiscNetwork:
         # the bf16 weight image and the two W^T images of the backward passes in one launch (the weights do not change inside a minibatch)
         fwd.weights_b16(f, f16, self.n_flat, [dict(x=f, out=self._w2t16, x_off=w2.off, rows=u2, cols=u1, ld_in=w2.pitch, ld_out=u2),
                                               dict(x=f, out=self._w1t16, x_off=w1.off, rows=u1, cols=k0, ld_in=w1.pitch, ld_out=u1)])
-        fwd.gemm_b16(X, f16, M=r3, N=u1, K=k0, ldb=w1.pitch, b_off=w1.off, Cp=H1, bias=f, bias_off=self.l1.b.off, activation=ACT_RELU)
-        fwd.gemm_b16(H1, f16, M=r3, N=u2, K=u1, ldb=w2.pitch, b_off=w2.off, Cp=H2, bias=f, bias_off=self.l2.b.off, activation=ACT_RELU)
+        M1, M2 = ws.get("M1"), ws.get("M2")
+        # the derivative of ReLU for rows [row0, ..) of H1 / H2: the forward's sign bits when the workspace has them, else the activations themselves
+        d1 = lambda row0: (dict(relu_mask8=M1, mask8_off=row0 * M1.stride(0)) if M1 is not None else dict(aux=H1, ldaux=u1, aux_off=row0 * u1))
+        d2 = lambda row0: (dict(relu_mask8=M2, mask8_off=row0 * M2.stride(0)) if M2 is not None else dict(aux=H2, ldaux=u2, aux_off=row0 * u2))
+        fwd.gemm_b16(X, f16, M=r3, N=u1, K=k0, ldb=w1.pitch, b_off=w1.off, Cp=H1, bias=f, bias_off=self.l1.b.off, activation=ACT_RELU,
+                     **({} if M1 is None else dict(relu_mask8=M1)))
+        fwd.gemm_b16(H1, f16, M=r3, N=u2, K=u1, ldb=w2.pitch, b_off=w2.off, Cp=H2, bias=f, bias_off=self.l2.b.off, activation=ACT_RELU,
+                     **({} if M2 is None else dict(relu_mask8=M2)))
         fwd.gemm_b16(H2, f16, M=r3, N=1, K=u2, ldb=w3.pitch, b_off=w3.off, C=ws["L"], ldc=4, bias=f, bias_off=self.l3.b.off)
         # (1) BCE path over the 3b forward rows: dz2 = (dL w3) * m2 ; dz1 = (dz2 W2) * m1 -- the latter in the forward form over W2^T
         bce = K.Plan()
         # (both launches also hand over the column sums of the dZ rows they store: the bias gradients of layers 2 and 1, see the reduces below)
         cs2 = ws["colsum2"] = torch.zeros(K.gemm_x3p_row_tiles(r3, u2, 1), u2, dtype=torch.float32, device=self.device)
         cs1 = ws["colsum1"] = torch.zeros(K.gemm_x3p_row_tiles(r3, u1, 1), u1, dtype=torch.float32, device=self.device)
-        bce.gemm_b16(dL, f16, M=r3, N=u2, K=1, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2,
-                     out_colsum=cs2)
-        bce.gemm_b16(Z2, self._w2t16, M=r3, N=u1, K=u2, Cp=Z1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1, out_colsum=cs1)
+        bce.gemm_b16(dL, f16, M=r3, N=u2, K=1, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, epilogue=EPI_RELU_GRAD, out_colsum=cs2, **d2(0))
+        bce.gemm_b16(Z2, self._w2t16, M=r3, N=u1, K=u2, Cp=Z1, epilogue=EPI_RELU_GRAD, out_colsum=cs1, **d1(0))
         # (2a) penalty forward on the demo rows (stacked as rows 3b..): u2 = m2 * w3, u1 = m1 * (u2 W2), g = u1 W1 (fp32: its square sum is the penalty)
         pf = K.Plan()
         pf.gemm_b16(dL, f16, M=b, N=u2, K=1, a_off=r3 * 32, ldb=w3.pitch, b_off=w3.off, b_layout=GEMM_OUT_CONTIG, Cp=Z2, cp_off=r3 * u2,
-                    epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2, aux_off=demo * u2)
-        pf.gemm_b16(Z2, self._w2t16, M=b, N=u1, K=u2, a_off=r3 * u2, Cp=Z1, cp_off=r3 * u1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1, aux_off=demo * u1)
+                    epilogue=EPI_RELU_GRAD, **d2(demo))
+        pf.gemm_b16(Z2, self._w2t16, M=b, N=u1, K=u2, a_off=r3 * u2, Cp=Z1, cp_off=r3 * u1, epilogue=EPI_RELU_GRAD, **d1(demo))
         pf.gemm_b16(Z1, self._w1t16, M=b, N=k0, K=u1, a_off=r3 * u1, C=ws["G"], ldc=k0p)
         # (2b) penalty backward: dt1 = (dg W1^T) * m1 -> H1[3b:] ;  m2 * (dt1 W2^T) -> H2[3b:]      (dg lives in X[3b:]); W as stored = forward form
         pb = K.Plan()
-        pb.gemm_b16(X, f16, M=b, N=u1, K=k0, a_off=r3 * k0p, ldb=w1.pitch, b_off=w1.off, Cp=H1, cp_off=r3 * u1, epilogue=EPI_RELU_GRAD, aux=H1, ldaux=u1,
-                    aux_off=demo * u1)
-        pb.gemm_b16(H1, f16, M=b, N=u2, K=u1, a_off=r3 * u1, ldb=w2.pitch, b_off=w2.off, Cp=H2, cp_off=r3 * u2, epilogue=EPI_RELU_GRAD, aux=H2, ldaux=u2,
-                    aux_off=demo * u2)
+        pb.gemm_b16(X, f16, M=b, N=u1, K=k0, a_off=r3 * k0p, ldb=w1.pitch, b_off=w1.off, Cp=H1, cp_off=r3 * u1, epilogue=EPI_RELU_GRAD, **d1(demo))
+        pb.gemm_b16(H1, f16, M=b, N=u2, K=u1, a_off=r3 * u1, ldb=w2.pitch, b_off=w2.off, Cp=H2, cp_off=r3 * u2, epilogue=EPI_RELU_GRAD, **d2(demo))
         # (3) weight gradients over all 4b stacked rows (fp32 slabs), bias gradients = column sums over the 3b BCE rows (slab 0)
         wg = K.Plan()
         m = 4 * b

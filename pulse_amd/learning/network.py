@@ -256,6 +256,9 @@ class A2CNetwork:
                 if self._flat16 is None:
                     self._flat16 = i16(1, (self.n_flat + 7) // 8 * 8).view(-1)
                     self._wt16 = [None] + [i16(2 * u[l - 1], u[l]) for l in range(1, len(u))]     # W_l^T of both nets: (2, u_{l-1}, u_l)
+                if self.act == ACT_RELU and RELU_BITMASK:
+                    # [r6] one byte per row and 8 columns: written by the training forward, read by the input-gradient epilogues instead of h16
+                    ws["hmask8"] = [K.alloc_relu_mask8(m, 2 * uu, dev) for uu in u]
                 ws["plan_fwd_train"] = self._plan_forward_b16(ws, m)
             else:
                 # ReLU nets: the training forward also records each hidden activation's sign bits (1 bit per element), and the input-gradient
@@ -304,16 +307,18 @@ class A2CNetwork:
             p.refresh_b16(f, f16, self.n_flat)
             for t in trs:
                 p.transpose_b16(t.pop("x"), t.pop("out"), **t)
+        hm = ws.get("hmask8")
+        mk = lambda l, per_net: {} if hm is None else dict(relu_mask8=hm[l], stride_mask8=u[l] // 8 if per_net else 0)
         for l, uu in enumerate(u):
             if l == 0:
                 k = self.in_w[0]
                 p.gemm_b16(ws["x16"], f16, M=m, N=2 * uu, K=self.in_dim, ldb=k, b_off=self.w_off[0], Cp=ws["h16"][0], bias=f, bias_off=self.b_off[0],
-                           activation=self.act, C2=pre[0] if pre else None, ldc2=2 * uu)
+                           activation=self.act, C2=pre[0] if pre else None, ldc2=2 * uu, **mk(0, False))
             else:
                 up = u[l - 1]
                 p.gemm_b16(ws["h16"][l - 1], f16, M=m, N=uu, K=up, ldb=up, b_off=self.w_off[l], batch=2, stride_a=up, stride_b=uu * up,
                            Cp=ws["h16"][l], stride_cp=uu, bias=f, bias_off=self.b_off[l], stride_bias=uu, activation=self.act,
-                           C2=pre[l] if pre else None, ldc2=2 * uu, stride_c2=uu)
+                           C2=pre[l] if pre else None, ldc2=2 * uu, stride_c2=uu, **mk(l, True))
         uL, ap, hr = u[-1], self.a_pitch, self.head_rows
         p.gemm_b16(ws["h16"][-1], f16, M=m, N=hr, K=uL, ldb=uL, b_off=self.wh_off, batch=2, stride_a=uL, stride_b=hr * uL, C=ws["heads"], ldc=2 * ap,
                    stride_c=ap, bias=f, bias_off=self.bh_off, stride_bias=ap, algo_n=(self.actions_num + 1) / 2.0)
@@ -337,13 +342,19 @@ class A2CNetwork:
         # every launch that produces a layer's dZ also hands over per-row-tile column sums of what it stored (out_colsum): the layer's bias
         # gradient is their ordered sum -- a few-KB reduce into slab 0 instead of a pass over the (m, 2 u) dZ matrix
         cs = ws["colsum16"] = [torch.zeros(K.gemm_x3p_row_tiles(m, uu, 2), 2 * uu, dtype=torch.float32, device=self.device) for uu in u]
+        hm = ws.get("hmask8")              # [r6] the forward's sign bits: one byte per 8 activations instead of 16 bytes of h16
+
+        def deriv(l):
+            if hm is not None:
+                return dict(relu_mask8=hm[l], stride_mask8=u[l] // 8)
+            return dict(aux=aux[l], ldaux=ld_aux(aux[l]), stride_aux=u[l])
+
         p.gemm_b16(dh16, f16, M=m, N=uL, K=hr, ldb=uL, b_off=self.wh_off, b_layout=GEMM_OUT_CONTIG, batch=2, stride_a=hp, stride_b=hr * uL,
-                   Cp=dz[-1], stride_cp=uL, epilogue=egrad, aux=aux[-1], ldaux=ld_aux(aux[-1]), stride_aux=uL, algo_k=(self.actions_num + 1) / 2.0,
-                   out_colsum=cs[-1], stride_out_colsum=uL)
+                   Cp=dz[-1], stride_cp=uL, epilogue=egrad, algo_k=(self.actions_num + 1) / 2.0, out_colsum=cs[-1], stride_out_colsum=uL, **deriv(L - 1))
         for l in range(L - 1, 0, -1):
             uu, up = u[l], u[l - 1]
             p.gemm_b16(dz[l], self._wt16[l], M=m, N=up, K=uu, ldb=uu, batch=2, stride_a=uu, stride_b=up * uu, Cp=dz[l - 1], stride_cp=up,
-                       epilogue=egrad, aux=aux[l - 1], ldaux=ld_aux(aux[l - 1]), stride_aux=up, out_colsum=cs[l - 1], stride_out_colsum=up)
+                       epilogue=egrad, out_colsum=cs[l - 1], stride_out_colsum=up, **deriv(l - 1))
         uu, k = u[0], self.in_w[0]
         s1 = self._l0_slabs = ws["l0_slabs"] = K.dw_split_b16(2 * uu, k, 1, S)
         ws["layer_slabs"] = [s1] + [S] * (L - 1)

@@ -113,3 +113,54 @@ def test_network_training_pass_is_bit_identical_with_and_without_masks(dev, monk
         grads.append(net.backward(ws, m).clone())
     assert torch.equal(grads[0], grads[1])
     assert grads[0].abs().sum() > 0
+
+
+def test_bf16_storage_byte_mask(dev):
+    """The same idea in the planar kernels' layout (pulse_gemm_x3p_desc.relu_mask8, ABI v28): a bf16-storage ReLU forward records one byte per row
+    and 8 columns, relu-grad launches read it instead of the bf16 activations -- bit-identical outputs, mask == (h > 0), row offsets work."""
+    g = torch.Generator().manual_seed(21)
+    m, n, k = 1024 + 256, 520, 96
+    to16 = lambda t: (t.contiguous().view(torch.int32) + 0x8000 >> 16).to(torch.int16)              # round-half-up is enough for operands here
+    x16 = to16(rnd(g, m, k)).to(dev)
+    w16 = to16(rnd(g, n, k) / math.sqrt(k)).to(dev)
+    npad = (n + 7) // 8 * 8
+    h16 = torch.zeros(m, npad, dtype=torch.int16, device=dev)
+    mask = K.alloc_relu_mask8(m, n, dev)
+    mask.fill_(255)
+    K.gemm_x3p(x16, w16, planes=1, M=m, N=n, K=k, Cp=h16, activation=ACT_RELU, relu_mask8=mask)
+    h = (h16.to(torch.int32) << 16).view(torch.float32)[:, :n]
+    bits = ((mask.cpu().to(torch.int64)[:, :, None] >> torch.arange(8)) & 1).reshape(m, -1)[:, :n].bool()
+    assert torch.equal(bits, (h > 0).cpu())
+    dy16 = to16(rnd(g, m, 32)).to(dev)
+    w2 = to16(rnd(g, 32, npad)).to(dev)                       # [red][out]
+    row0 = 256                                               # a row range of the activations (the discriminator's demo rows)
+    outs = []
+    for use_mask in (False, True):
+        z = torch.zeros(m - row0, npad, dtype=torch.int16, device=dev)
+        kw = dict(relu_mask8=mask, mask8_off=row0 * mask.stride(0)) if use_mask else dict(aux=h16, ldaux=npad, aux_off=row0 * npad)
+        K.gemm_x3p(dy16, w2, planes=1, M=m - row0, N=n, K=32, a_off=row0 * 32, b_layout=GEMM_OUT_CONTIG, Cp=z, epilogue=EPI_RELU_GRAD, **kw)
+        outs.append(z)
+    assert torch.equal(outs[0], outs[1]) and (outs[0] != 0).any()
+
+
+def test_mixed_precision_network_pass_is_bit_identical_with_and_without_byte_masks(dev, monkeypatch):
+    from pulse_amd import configs
+    from pulse_amd.learning import network as N
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(N, "RELU_BITMASK", on)
+        torch.manual_seed(5)
+        net = N.A2CNetwork(configs.NETWORK_IM, actions_num=69, input_shape=(934,), device=dev)
+        net.mixed_precision = True
+        m = 1024
+        ws = net.workspace(m, True)
+        assert ws["b16"] and ("hmask8" in ws) == on
+        gsrc = torch.Generator().manual_seed(9)
+        ws["x"][:, :934] = rnd(gsrc, m, 934).to(dev)
+        net.train()
+        net.forward(ws, m)
+        ws["dheads"].zero_()
+        K.to_b16(torch.cat([rnd(gsrc, m, 69), torch.zeros(m, ws["head_pitch16"] - 69), rnd(gsrc, m, 1), torch.zeros(m, ws["head_pitch16"] - 1)], dim=1).to(dev),
+                 ws["dheads16"])
+        grads.append(net.backward(ws, m).clone())
+    assert torch.equal(grads[0], grads[1]) and grads[0].abs().sum() > 0

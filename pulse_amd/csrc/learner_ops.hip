@@ -93,7 +93,10 @@ constexpr int kRmsRowsInFlight = 4;     // rows whose loads are in flight per wo
 // -- the layer-1 operand of the planar GEMM (gemm_x3p.hip) written by its producer instead of a separate split pass.
 // OUT = 2: the output IS a bf16 matrix (planes[row * planes_ld + col], y unused): the layer-1 operand of the bf16-storage training path
 // (mixed_precision; a bf16 autocast Linear rounds its fp32 input exactly like this).
-template <int OUT>
+// G: column groups per thread.  G = 1 (rows of <= 1024 columns: every observation of this path) needs 62 - 70 VGPRs instead of 141 - 146, so
+// three workgroups share a CU instead of one and the 512 workgroups of a 16384-row minibatch are resident at once: 28.4 -> 22.0 us for
+// 16384 x 934 -> 960 (5.6 TB/s of read + write; eight rows in flight per half instead of four measured 24.9).  [r6]
+template <int OUT, int G = kRmsVecGroups>
 __global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __restrict__ x, long long x_stride,
                                                                 const long long* __restrict__ row_idx, int rows, int cols,
                                                                 const double* __restrict__ mean, const double* __restrict__ var,
@@ -108,10 +111,10 @@ __global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __
     const int per = (rows + nblk - 1) / nblk;
     const int r0 = blockIdx.x * per;
     const int r1 = min(rows, r0 + per);
-    float mu[kRmsVecGroups][4], den[kRmsVecGroups][4];
-    double s1[kRmsVecGroups][4], s2[kRmsVecGroups][4];
+    float mu[G][4], den[G][4];
+    double s1[G][4], s2[G][4];
 #pragma unroll
-    for (int j = 0; j < kRmsVecGroups; ++j)
+    for (int j = 0; j < G; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = (tid + 256 * j) * 4 + k;
@@ -130,12 +133,12 @@ __global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __
         for (int q = hf * kRmsRowsInFlight; q < nr; q += 2 * kRmsRowsInFlight) {
             // kRmsRowsInFlight rows' loads are issued before the first is consumed: a workgroup's row loop is latency-bound
             // (one 3.7 KB row per memory round trip otherwise)
-            float4 v[kRmsRowsInFlight][kRmsVecGroups];
+            float4 v[kRmsRowsInFlight][G];
 #pragma unroll
             for (int h = 0; h < kRmsRowsInFlight; ++h) {
                 const float* xr = x + s_src[q + h < nr ? q + h : q] * x_stride;
 #pragma unroll
-                for (int j = 0; j < kRmsVecGroups; ++j) {
+                for (int j = 0; j < G; ++j) {
                     const int c = (tid + 256 * j) * 4;
                     v[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (c < cols) v[h][j] = *reinterpret_cast<const float4*>(xr + c);
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __
                 if (q + h >= nr) break;
                 float* yr = OUT == 2 ? nullptr : y + (long long)(rb + q + h) * y_stride;
 #pragma unroll
-                for (int j = 0; j < kRmsVecGroups; ++j) {
+                for (int j = 0; j < G; ++j) {
                     const int c = (tid + 256 * j) * 4;
                     if (c < y_cols) {
                         const float4 vv = v[h][j];
@@ -180,23 +183,23 @@ __global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __
         }
     }
     if (partials) {
-        __shared__ double s_red[2 * kRmsVecGroups * 4][256];           // 48 KB: the upper half's sums, [moment, group, column-in-group][owner]
+        __shared__ double s_red[2 * G * 4][256];           // 48 KB: the upper half's sums, [moment, group, column-in-group][owner]
         __syncthreads();
         if (hf == 1) {
 #pragma unroll
-            for (int j = 0; j < kRmsVecGroups; ++j)
+            for (int j = 0; j < G; ++j)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { s_red[j * 4 + k][tid] = s1[j][k]; s_red[kRmsVecGroups * 4 + j * 4 + k][tid] = s2[j][k]; }
+                for (int k = 0; k < 4; ++k) { s_red[j * 4 + k][tid] = s1[j][k]; s_red[G * 4 + j * 4 + k][tid] = s2[j][k]; }
         }
         __syncthreads();
         if (hf == 0) {
             double* p = partials + (long long)blockIdx.x * 2 * cols;
 #pragma unroll
-            for (int j = 0; j < kRmsVecGroups; ++j)
+            for (int j = 0; j < G; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int c = (tid + 256 * j) * 4 + k;
-                    if (c < cols) { p[c] = s1[j][k] + s_red[j * 4 + k][tid]; p[cols + c] = s2[j][k] + s_red[kRmsVecGroups * 4 + j * 4 + k][tid]; }
+                    if (c < cols) { p[c] = s1[j][k] + s_red[j * 4 + k][tid]; p[cols + c] = s2[j][k] + s_red[G * 4 + j * 4 + k][tid]; }
                 }
         }
     }
@@ -588,7 +591,11 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
     const bool vec_ok = cols >= 64 && cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (y_stride % 4) == 0 && (y_cols % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                         x_stride >= ((cols + 3) & ~3);
-    if (vec_ok)
+    if (vec_ok && y_cols <= 1024)
+        hipLaunchKernelGGL((rms_normalize_vec4_kernel<0, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials,
+                           (unsigned short*)nullptr, 0LL, 0LL);
+    else if (vec_ok)
         hipLaunchKernelGGL(rms_normalize_vec4_kernel<0>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials,
                            (unsigned short*)nullptr, 0LL, 0LL);
@@ -616,9 +623,14 @@ int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* 
     PULSE_REQUIRE((y_cols % 32) == 0 && planes_ld >= y_cols && (planes_ld % 8) == 0 && (plane_stride % 8) == 0 && plane_stride >= (int64_t)rows * planes_ld &&
                   (reinterpret_cast<uintptr_t>(planes) & 15) == 0,
                   "pulse_rms_normalize_planes: y_cols must be a multiple of 32 (zero-padded k extent), planes rows 16-byte aligned and covering it");
-    hipLaunchKernelGGL(rms_normalize_vec4_kernel<1>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                       (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
-                       reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
+    if (y_cols <= 1024)
+        hipLaunchKernelGGL((rms_normalize_vec4_kernel<1, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
+                           reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
+    else
+        hipLaunchKernelGGL(rms_normalize_vec4_kernel<1>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
+                           reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
     return check_launch("pulse_rms_normalize_planes");
 }
 
@@ -633,9 +645,14 @@ int pulse_rms_normalize_b16(const float* x, int64_t x_stride, const int64_t* row
     PULSE_REQUIRE(cols >= 64 && y_cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride >= ((cols + 3) & ~3),
                   "pulse_rms_normalize_b16: needs the wide-row form (64 <= cols, y_cols <= %d, 16-byte aligned input rows)", 256 * 4 * kRmsVecGroups);
     PULSE_REQUIRE((y_cols % 4) == 0 && (y_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(y16) & 7) == 0, "pulse_rms_normalize_b16: output rows must be 8-byte aligned, y_cols a multiple of 4");
-    hipLaunchKernelGGL(rms_normalize_vec4_kernel<2>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                       (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, (float*)nullptr, 0LL, y_cols, moment_partials,
-                       reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
+    if (y_cols <= 1024)
+        hipLaunchKernelGGL((rms_normalize_vec4_kernel<2, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, (float*)nullptr, 0LL, y_cols, moment_partials,
+                           reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
+    else
+        hipLaunchKernelGGL(rms_normalize_vec4_kernel<2>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, (float*)nullptr, 0LL, y_cols, moment_partials,
+                           reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
     return check_launch("pulse_rms_normalize_b16");
 }
 

@@ -1181,10 +1181,10 @@ namespace {
 // launches it issues itself, never those of another host thread driving its own stream through the library.
 thread_local long long* g_dbg = nullptr;       // tools/gemm_bench --clocks
 thread_local int g_last_tile = 0;               // tile rows of the calling thread's last pulse_gemm_f32 launch (pulse_gemm_last_tile: bench.py's per-kernel roofline)
-thread_local int g_opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [1] extra LDS bytes per workgroup, [2] no 64-row tile, [3] bf16-storage tile choice (see pulse_hip.h)
+thread_local int g_opt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [1] extra LDS bytes per workgroup, [2] no 64-row tile, [3] bf16-storage tile choice (see pulse_hip.h)
 }
 
-namespace pulse { int gemm_option(int key) { return key >= 0 && key < 8 ? g_opt[key] : 0; } long long* gemm_debug_buffer() { return g_dbg; } }    // read by gemm_x3p.hip (common.h)
+namespace pulse { int gemm_option(int key) { return key >= 0 && key < 16 ? g_opt[key] : 0; } long long* gemm_debug_buffer() { return g_dbg; } }    // read by gemm_x3p.hip (common.h)
 
 namespace {
 // Which tiling serves an x3 launch.  Cost model in units of (one 128 x 128 output tile) x (k per split), per CU: the narrow kernel keeps two
@@ -1238,7 +1238,7 @@ int pulse_gemm_last_tile(void) { return g_last_tile; }
 int pulse_gemm_x3_mode(void) { return x3_mode(); }
 
 int pulse_gemm_set_option(int key, int value) {
-    PULSE_REQUIRE(key >= 0 && key < 8, "pulse_gemm_set_option: bad key");
+    PULSE_REQUIRE(key >= 0 && key < 16, "pulse_gemm_set_option: bad key");
     g_opt[key] = value;
     return PULSE_OK;
 }

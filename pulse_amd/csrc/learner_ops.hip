@@ -331,7 +331,14 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------
 // PPO losses + gradients w.r.t. (mu, value).  16 lanes per sample, 16 samples per 256-thread block.
+// HOIST [r6]: what depends on the action column only -- sigma = exp(logstd), sigma^2, the KL's log(s1 / sigma + 1e-5) and 2 (s1^2 + 1e-5), the row
+// sum of logstd -- is evaluated once per lane instead of once per sample (three exp, a log and a divide per element were two thirds of the kernel's
+// instructions), and a sample's mu / action values stay in registers between the loss pass and the gradient pass.  Same expressions on the same
+// values in the same order: the results are bit-identical to the plain form, which stays for num_actions > 16 * kLossCols.
 // ------------------------------------------------------------------------------------------------
+constexpr int kLossCols = 10;          // hoisted columns per lane: num_actions <= 160 (SMPL 69, SMPL-X 153)
+
+template <bool HOIST>
 __global__ void __launch_bounds__(256) ppo_loss_kernel(const pulse_ppo_loss_args a) {
     __shared__ float red[5][16];
     const int samples_per_block = 256 / kLanesPerSample;
@@ -340,6 +347,24 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(const pulse_ppo_loss_args
     const int A = a.num_actions;
     const float invB = 1.0f / (float)a.rows;
     float acc_a = 0.f, acc_c = 0.f, acc_b = 0.f, acc_clip = 0.f, acc_kl = 0.f;
+    float c_sg[kLossCols], c_sg2[kLossCols], c_klog[kLossCols], c_kden[kLossCols];
+    float c_lsum = 0.f;
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int t = 0; t < kLossCols; ++t) {
+            const int j = l + kLanesPerSample * t;
+            c_sg[t] = 1.f; c_sg2[t] = 1.f; c_klog[t] = 0.f; c_kden[t] = 1.f;
+            if (j < A) {
+                const float ls = a.logstd[j], sg = expf(ls);
+                const float s1 = expf(a.old_logstd[j]);
+                c_sg[t] = sg; c_sg2[t] = sg * sg;
+                c_klog[t] = logf(s1 / sg + 1e-5f);
+                c_kden[t] = 2.0f * (s1 * s1 + 1e-5f);
+                c_lsum += ls;
+            }
+        }
+        c_lsum = group16_sum(c_lsum);
+    }
     for (int base = blockIdx.x * samples_per_block; base < a.rows; base += gridDim.x * samples_per_block) {
         const int i = base + slot;
         if (i >= a.rows) continue;
@@ -348,22 +373,51 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(const pulse_ppo_loss_args
         const float* act = a.actions + d * a.actions_stride;
         const float* omu = a.old_mu + d * a.old_mu_stride;
         float quad = 0.f, lsum = 0.f, bl = 0.f, kl = 0.f;
-        for (int j = l; j < A; j += kLanesPerSample) {
-            const float ls = a.logstd[j], sg = expf(ls);
-            const float m = mu[j];
-            const float zz = (act[j] - m) / sg;
-            quad += zz * zz;
-            lsum += ls;
-            if (a.has_bounds_loss) {
-                const float hi = fmaxf(m - 1.0f, 0.f), lo = fminf(m + 1.0f, 0.f);
-                bl += lo * lo + hi * hi;
+        float r_m[kLossCols], r_da[kLossCols];                  // HOIST: mu and (action - mu) of this lane's columns
+        if constexpr (HOIST) {
+            float r_o[kLossCols];
+#pragma unroll
+            for (int t = 0; t < kLossCols; ++t) {               // all loads of the sample first: one memory round trip, not one per column
+                const int j = l + kLanesPerSample * t;
+                r_m[t] = 0.f; r_da[t] = 0.f; r_o[t] = 0.f;
+                if (j < A) { r_m[t] = mu[j]; r_da[t] = act[j]; r_o[t] = omu[j]; }
             }
-            // rl_games policy_kl(p0 = new, p1 = old)
-            const float s1 = expf(a.old_logstd[j]);
-            const float dm = omu[j] - m;
-            kl += logf(s1 / sg + 1e-5f) + (sg * sg + dm * dm) / (2.0f * (s1 * s1 + 1e-5f)) + (-0.5f);
+#pragma unroll
+            for (int t = 0; t < kLossCols; ++t) {
+                const int j = l + kLanesPerSample * t;
+                if (j < A) {
+                    const float m = r_m[t];
+                    r_da[t] = r_da[t] - m;
+                    const float zz = r_da[t] / c_sg[t];
+                    quad += zz * zz;
+                    if (a.has_bounds_loss) {
+                        const float hi = fmaxf(m - 1.0f, 0.f), lo = fminf(m + 1.0f, 0.f);
+                        bl += lo * lo + hi * hi;
+                    }
+                    const float dm = r_o[t] - m;
+                    kl += c_klog[t] + (c_sg2[t] + dm * dm) / c_kden[t] + (-0.5f);
+                }
+            }
+            lsum = c_lsum;
+            quad = group16_sum(quad); bl = group16_sum(bl); kl = group16_sum(kl);
+        } else {
+            for (int j = l; j < A; j += kLanesPerSample) {
+                const float ls = a.logstd[j], sg = expf(ls);
+                const float m = mu[j];
+                const float zz = (act[j] - m) / sg;
+                quad += zz * zz;
+                lsum += ls;
+                if (a.has_bounds_loss) {
+                    const float hi = fmaxf(m - 1.0f, 0.f), lo = fminf(m + 1.0f, 0.f);
+                    bl += lo * lo + hi * hi;
+                }
+                // rl_games policy_kl(p0 = new, p1 = old)
+                const float s1 = expf(a.old_logstd[j]);
+                const float dm = omu[j] - m;
+                kl += logf(s1 / sg + 1e-5f) + (sg * sg + dm * dm) / (2.0f * (s1 * s1 + 1e-5f)) + (-0.5f);
+            }
+            quad = group16_sum(quad); lsum = group16_sum(lsum); bl = group16_sum(bl); kl = group16_sum(kl);
         }
-        quad = group16_sum(quad); lsum = group16_sum(lsum); bl = group16_sum(bl); kl = group16_sum(kl);
         const float nlp = 0.5f * quad + kHalfLog2Pi * (float)A + lsum;
         const float adv = a.advantages[d];
         const float ratio = expf(a.old_neglogp[d] - nlp);
@@ -393,13 +447,27 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(const pulse_ppo_loss_args
         }
         // gradients (mean over the batch folded in)
         float* dmu = a.dmu + (long long)i * a.dmu_stride;
-        for (int j = l; j < A; j += kLanesPerSample) {
-            const float sg = expf(a.logstd[j]);
-            const float m = mu[j];
-            float gmu = g_nlp * (-(act[j] - m) / (sg * sg));
-            if (a.has_bounds_loss) gmu += a.bounds_loss_coef * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
-            dmu[j] = gmu * invB;
-            if (a.dmu16) reinterpret_cast<unsigned short*>(a.dmu16)[(long long)i * a.dmu16_stride + j] = (unsigned short)(split_pack_rn(gmu * invB, 0.f) & 0xffffu);
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int t = 0; t < kLossCols; ++t) {
+                const int j = l + kLanesPerSample * t;
+                if (j < A) {
+                    const float m = r_m[t];
+                    float gmu = g_nlp * (-r_da[t] / c_sg2[t]);
+                    if (a.has_bounds_loss) gmu += a.bounds_loss_coef * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
+                    dmu[j] = gmu * invB;
+                    if (a.dmu16) reinterpret_cast<unsigned short*>(a.dmu16)[(long long)i * a.dmu16_stride + j] = (unsigned short)(split_pack_rn(gmu * invB, 0.f) & 0xffffu);
+                }
+            }
+        } else {
+            for (int j = l; j < A; j += kLanesPerSample) {
+                const float sg = expf(a.logstd[j]);
+                const float m = mu[j];
+                float gmu = g_nlp * (-(act[j] - m) / (sg * sg));
+                if (a.has_bounds_loss) gmu += a.bounds_loss_coef * (2.0f * fmaxf(m - 1.0f, 0.f) + 2.0f * fminf(m + 1.0f, 0.f));
+                dmu[j] = gmu * invB;
+                if (a.dmu16) reinterpret_cast<unsigned short*>(a.dmu16)[(long long)i * a.dmu16_stride + j] = (unsigned short)(split_pack_rn(gmu * invB, 0.f) & 0xffffu);
+            }
         }
         if (l == 0) {
             a.dvalue[(long long)i * a.dvalue_stride] = a.critic_coef * g_v * invB;
@@ -695,7 +763,10 @@ int pulse_ppo_loss(const pulse_ppo_loss_args* args, pulse_stream_t s) {
                       a.dmu && a.dvalue && a.partials,
                   "pulse_ppo_loss: null pointer");
     PULSE_REQUIRE(!a.clip_value || a.old_values, "pulse_ppo_loss: clip_value needs old_values");
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3(a.num_blocks), dim3(256), 0, as_stream(s), a);
+    if (a.num_actions <= kLanesPerSample * kLossCols && gemm_option(8) == 0)
+        hipLaunchKernelGGL(ppo_loss_kernel<true>, dim3(a.num_blocks), dim3(256), 0, as_stream(s), a);
+    else
+        hipLaunchKernelGGL(ppo_loss_kernel<false>, dim3(a.num_blocks), dim3(256), 0, as_stream(s), a);
     return check_launch("pulse_ppo_loss");
 }
 

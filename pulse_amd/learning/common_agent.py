@@ -149,7 +149,7 @@ class CommonAgent:
         self._sq_done, self._sq_fuse = set(), False      # parameter groups whose sum-of-squares partials the gradient reduce of this step already produced
         self._grad_norm = torch.zeros(1, device=self.ppo_device)
         self._partials_ring, self._lazy_info, self._ring_pos = None, False, 0
-        self._loss_partials = torch.zeros(max(1, min(512, self.minibatch_size // 16)), 8, device=self.ppo_device)
+        self._loss_partials = torch.zeros(max(1, min(1024, self.minibatch_size // 16)), 8, device=self.ppo_device)   # one pass of 16-sample groups per workgroup
         self._adv_partials = torch.zeros(128, 2, dtype=torch.float64, device=self.ppo_device)
         perm_gen = torch.Generator()
         perm_gen.manual_seed(seed)

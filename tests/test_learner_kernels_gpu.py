@@ -313,6 +313,40 @@ def test_ppo_loss_and_gradients_vs_autograd(dev, clip_value):
     np.testing.assert_allclose(dval.cpu().numpy(), val.grad.numpy(), rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("a,clip_value,bounds", [(69, False, True), (69, True, False), (153, False, True), (1, True, True), (16, False, False), (160, True, True), (161, False, True)])
+def test_ppo_loss_hoisted_form_is_bit_identical_to_plain(dev, a, clip_value, bounds):
+    """[r6] The kernel evaluates the column-only terms (sigma, sigma^2, the KL's log and denominator, sum logstd) once per lane; gemm option 8
+    selects the plain per-sample form.  Same expressions on the same values: every output must agree bit for bit (161 actions: both calls
+    run the plain form -- the hoisted one holds 160 columns)."""
+    g = torch.Generator().manual_seed(100 + a)
+    n_data, b = 3000, 2050                                       # ragged: the last block is partial, blocks loop over rows
+    ap = (a + 3) // 4 * 4
+    logstd, old_logstd = rnd(g, a) * 0.3 - 2.0, rnd(g, a) * 0.3 - 2.1
+    idx = torch.randperm(n_data, generator=g)[:b]
+    old_mu = rnd(g, n_data, a)
+    actions = old_mu + torch.exp(old_logstd) * rnd(g, n_data, a)
+    mu = old_mu[idx] + 0.05 * rnd(g, b, a)
+    mu[:9] *= 2.0
+    d = lambda t: t.to(dev).contiguous()
+    args = dict(mu=padded(mu, ap + 4, dev), mu_stride=ap + 4, value=d(rnd(g, b)), value_stride=1, logstd=d(logstd), old_logstd=d(old_logstd), idx=d(idx),
+                actions=padded(actions, ap, dev), actions_stride=ap, old_mu=padded(old_mu, ap, dev), old_mu_stride=ap,
+                old_neglogp=d(_neglogp(actions, old_mu, old_logstd)), advantages=d(rnd(g, n_data)), old_values=d(rnd(g, n_data)), returns=d(rnd(g, n_data)),
+                rows=b, num_actions=a, e_clip=0.2, critic_coef=5.0, bounds_loss_coef=10.0 if bounds else None, clip_value=clip_value)
+    outs = []
+    for plain in (0, 1):
+        dmu, dval, part = torch.full((b, ap), 7.0, device=dev), torch.empty(b, device=dev), torch.empty(40, 8, device=dev)
+        dmu16, dval16 = torch.zeros(b, ap, dtype=torch.int16, device=dev), torch.zeros(b, 4, dtype=torch.int16, device=dev)
+        K.gemm_set_option(8, plain)
+        try:
+            K.ppo_loss(dmu=dmu, dmu_stride=ap, dvalue=dval, dvalue_stride=1, partials=part, dmu16=dmu16, dmu16_stride=ap, dvalue16=dval16, dvalue16_stride=4, **args)
+        finally:
+            K.gemm_set_option(8, 0)
+        outs.append((dmu, dval, part[:, :5], dmu16, dval16))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert torch.isfinite(outs[0][0]).all() and (outs[0][0][:, a:] == 7.0).all()          # pad columns untouched
+
+
 def test_losses_vs_reference_golden(golden, dev):
     """_actor_loss / _critic_loss / bound_loss values from the real CommonAgent methods."""
     g = golden("agent_math.npz")

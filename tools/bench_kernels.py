@@ -82,6 +82,31 @@ def opt():
 
 t = timeit(opt)
 report("sqnorm_partial + adam_kernel", net.n_flat * 4 * (1 + 4 + 3), t, f"{net.n_flat} params")
+# the PPO loss head on one minibatch (gathered actions / old mu, mu | value of the heads, d mu | d value out)
+td0 = eb.tensor_dict
+lp = torch.zeros(1024, 8, device=dev)
+wsl = net.workspace(mb, train=True)
+wsl["heads"].normal_()
+fl = lambda k: eb.flat(k)
+adv_flat = torch.randn(n * T, device=dev)
+
+
+def loss():
+    K.ppo_loss(mu=wsl["mu"], mu_stride=wsl["mu"].stride(0), value=wsl["val"], value_stride=wsl["val"].stride(0), logstd=net.sigma, old_logstd=net.sigma,
+               idx=idx, actions=fl("actions"), actions_stride=fl("actions").stride(0), old_mu=fl("mus"), old_mu_stride=fl("mus").stride(0),
+               old_neglogp=fl("neglogpacs").reshape(-1), advantages=adv_flat, old_values=fl("values").reshape(-1), returns=adv_flat, rows=mb, num_actions=69,
+               e_clip=0.2, critic_coef=5.0, bounds_loss_coef=10.0, clip_value=False, dmu=wsl["dmu"], dmu_stride=wsl["dmu"].stride(0),
+               dvalue=wsl["dval"], dvalue_stride=wsl["dval"].stride(0), partials=lp)
+
+
+t = timeit(loss)
+# (the Python wrapper fills a 200-byte argument struct per call: back-to-back launches are host-bound at ~14 us; rocprofv3 --kernel-trace of this
+# tool gives the kernel: 9.6 us hoisted, 10.6 us plain at 1024 workgroups; 10.4 / 14.0 at 512 -- profiles/r06_ab_runs.txt)
+report("ppo_loss_kernel (losses + d mu | d value; host-bound here)", mb * (69 * 4 * 4 + 8 + 6 * 4), t, f"{mb} rows")
+K.gemm_set_option(8, 1)
+t = timeit(loss)
+K.gemm_set_option(8, 0)
+report("ppo_loss_kernel, plain per-sample form (gemm option 8)", mb * (69 * 4 * 4 + 8 + 6 * 4), t, f"{mb} rows")
 vm = agent.value_mean_std
 wsr = net.workspace(n, train=False)
 mask = torch.zeros(n, dtype=torch.bool, device=dev)

@@ -36,7 +36,7 @@ extern "C" {
 #define PULSE_ERR_LAUNCH (-2)
 #define PULSE_ERR_UNSUPPORTED (-3)
 
-#define PULSE_ABI_VERSION 28
+#define PULSE_ABI_VERSION 29
 
 typedef void* pulse_stream_t; /* hipStream_t */
 
@@ -224,6 +224,11 @@ typedef struct pulse_im_step_args {
        (HumanoidIm._compute_reset's else-branch, :1178-1183, which indexes the mask by BODY id: tracked bodies must be all bodies in order),
        an occluded reset body never counts as fallen. */
     const uint32_t* occl_bits; int32_t occl_reset;
+    /* ---- optional (v29): a second destination for the observation rows (obs_copy[e * obs_copy_stride + c], same columns as obs).  The rollout
+       records every observation twice -- as the policy's next input and as ``next_obses`` of the step that produced it (a2c_common.play_steps:
+       experience_buffer.update_data('next_obses', n, ...)) --; the step kernel holds the finished row in LDS, so the second copy costs a store,
+       not a launch. */
+    float* obs_copy; int64_t obs_copy_stride;
 } pulse_im_step_args;
 
 /* sizeof(pulse_im_step_args) as compiled, so a foreign-language binding can verify its mirror */
@@ -769,6 +774,13 @@ int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* 
 int pulse_rms_normalize_b16(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols,
                             const double* mean, const double* var, float eps, float clip,
                             void* y16, int64_t y_stride, int32_t y_cols, double* moment_partials, int32_t num_blocks, pulse_stream_t s);
+/* pulse_rms_normalize (mode 0, wide-row form) that ALSO stores the raw rows it read: raw_out[i * raw_stride + c] = x[row(i)][c] for c < cols
+ * rounded up to a multiple of 4 (16-byte stores: the source's pad columns travel with the last group) -- the rollout's
+ * experience_buffer.update_data('obses', n, obs) (a2c_common.play_steps) done by the pass that reads the observation anyway.  v29. */
+int pulse_rms_normalize_copy(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols,
+                             const double* mean, const double* var, float eps, float clip,
+                             float* y, int64_t y_stride, int32_t y_cols, double* moment_partials, int32_t num_blocks,
+                             float* raw_out, int64_t raw_stride, pulse_stream_t s);
 /* _update_mean_var_count_from_moments, running_mean_std.py:56-67 (unbiased batch variance).
  * count_old is tracked by the host (it only ever grows by the batch size). */
 int pulse_rms_update(double* mean, double* var, double* count_out, const double* moment_partials, int32_t num_blocks,

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PULSE_HIP_LIB: another build of the SAME library (tools/im_step_repro.py compares compile variants); default = the in-tree build
 LIB_PATH = os.environ.get("PULSE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulse_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 PULSE_IM_SELF_OBS = 1
 PULSE_IM_TASK_OBS = 2
@@ -65,6 +65,7 @@ class ImStepArgs(Structure):
         ("recovery_counter", c_void_p),
         ("zero_out_far", c_int32), ("close_distance", c_float), ("far_distance", c_float), ("point_goal", c_void_p),
         ("occl_bits", c_void_p), ("occl_reset", c_int32),
+        ("obs_copy", c_void_p), ("obs_copy_stride", c_int64),
     ]
 
 
@@ -297,6 +298,7 @@ SIGNATURES = {
     "pulse_reduce_slabs": (c_int, [P, c_int32, c_int64, c_int64, P, c_float, P]),
     "pulse_colsum_partial": (c_int, [P, c_int32, c_int32, c_int32, c_int32, P, c_int64, P]),
     "pulse_rms_normalize": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, c_int32, P, c_int64, c_int32, P, c_int32, P]),
+    "pulse_rms_normalize_copy": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, P, c_int64, c_int32, P, c_int32, P, c_int64, P]),
     "pulse_rms_normalize_planes": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, P, c_int64, c_int32, P, c_int32, P, c_int64, c_int64, P]),
     "pulse_rms_normalize_b16": (c_int, [P, c_int64, P, c_int32, c_int32, P, P, c_float, c_float, P, c_int64, c_int32, P, c_int32, P]),
     "pulse_transpose_to_b16": (c_int, [P, c_int64, c_int32, c_int32, P, c_int64, c_int32, c_int64, c_int64, P]),

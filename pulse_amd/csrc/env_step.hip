@@ -522,12 +522,21 @@ __global__ void __launch_bounds__(E * R * kLanesPerEnv) im_step_kernel(const pul
         const int c0 = do_self ? 0 : L.self_w;
         const int c1 = do_task ? a.obs_cols : L.self_w;
         float* g = a.obs + e * a.obs_stride;
-        if (c0 == 0 && (c1 & 3) == 0 && aligned16(g)) {
+        float* g2 = a.obs_copy ? a.obs_copy + e * a.obs_copy_stride : nullptr;      // the rollout's second record of the row (v29)
+        if (c0 == 0 && (c1 & 3) == 0 && aligned16(g) && (!g2 || aligned16(g2))) {
             const float4* s4 = reinterpret_cast<const float4*>(obs_e);
             float4* g4 = reinterpret_cast<float4*>(g);
-            for (int i = lane_all; i < (c1 >> 2); i += NL) g4[i] = s4[i];
+            float4* h4 = reinterpret_cast<float4*>(g2);
+            for (int i = lane_all; i < (c1 >> 2); i += NL) {
+                const float4 v = s4[i];
+                g4[i] = v;
+                if (g2) h4[i] = v;
+            }
         } else {
-            for (int c = c0 + lane_all; c < c1; c += NL) g[c] = obs_e[c];
+            for (int c = c0 + lane_all; c < c1; c += NL) {
+                g[c] = obs_e[c];
+                if (g2) g2[c] = obs_e[c];
+            }
         }
     }
 }
@@ -580,6 +589,7 @@ int pulse_im_step(const pulse_im_step_args* args, pulse_stream_t s) {
         PULSE_REQUIRE(a.obs_cols >= L.self_w + ((a.what & PULSE_IM_TASK_OBS) ? L.task_w : 0),
                       "pulse_im_step: obs_cols %d < observation width %d", a.obs_cols, L.self_w + L.task_w);
         PULSE_REQUIRE(a.obs_stride >= a.obs_cols, "pulse_im_step: obs_stride < obs_cols");
+        PULSE_REQUIRE(a.obs_copy == nullptr || a.obs_copy_stride >= a.obs_cols, "pulse_im_step: obs_copy_stride < obs_cols");
     }
     if (a.what & PULSE_IM_TASK_OBS) {
         const int ov = a.obs_version;

@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __
                                                                 const double* __restrict__ mean, const double* __restrict__ var,
                                                                 float eps, float clip, int mode, float* __restrict__ y,
                                                                 long long y_stride, int y_cols, double* __restrict__ partials,
-                                                                unsigned short* __restrict__ planes, long long plane_stride, long long planes_ld) {
+                                                                unsigned short* __restrict__ planes, long long plane_stride, long long planes_ld,
+                                                                float* __restrict__ raw = nullptr, long long raw_stride = 0) {
     // 512 threads = two halves of 256 column owners: the halves take alternate groups of kRmsRowsInFlight rows of the workgroup's row range and
     // their moment sums are combined through LDS at the end.  (One workgroup per CU with four waves could not hide the row loads' latency:
     // 4096 x 1960 rows took 29 us = 1.6 TB/s; the partials per WORKGROUP, which rms_update has to read back, stay what they were.)
@@ -153,6 +154,7 @@ __global__ void __launch_bounds__(512) rms_normalize_vec4_kernel(const float* __
                     const int c = (tid + 256 * j) * 4;
                     if (c < y_cols) {
                         const float4 vv = v[h][j];
+                        if (raw && c < cols) *reinterpret_cast<float4*>(raw + (long long)(rb + q + h) * raw_stride + c) = vv;     // the rollout's record of the raw row
                         float in[4] = {vv.x, vv.y, vv.z, vv.w}, o[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -674,6 +676,30 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
         hipLaunchKernelGGL(rms_normalize_narrow_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
     return check_launch("pulse_rms_normalize");
+}
+
+int pulse_rms_normalize_copy(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols, const double* mean,
+                             const double* var, float eps, float clip, float* y, int64_t y_stride, int32_t y_cols, double* moment_partials,
+                             int32_t num_blocks, float* raw_out, int64_t raw_stride, pulse_stream_t s) {
+    PULSE_REQUIRE(rows >= 0 && cols >= 0, "pulse_rms_normalize_copy: negative size");
+    if (rows == 0 || cols == 0) return PULSE_OK;
+    PULSE_REQUIRE(x && y && mean && var && raw_out, "pulse_rms_normalize_copy: null pointer");
+    PULSE_REQUIRE(num_blocks >= 1, "pulse_rms_normalize_copy: num_blocks < 1");
+    PULSE_REQUIRE(y_cols >= cols && y_stride >= y_cols && x_stride >= cols, "pulse_rms_normalize_copy: bad pitches");
+    PULSE_REQUIRE(cols >= 64 && y_cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (y_stride % 4) == 0 && (y_cols % 4) == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && x_stride >= ((cols + 3) & ~3),
+                  "pulse_rms_normalize_copy: needs the wide-row form (64 <= cols, y_cols <= %d, 16-byte aligned rows)", 256 * 4 * kRmsVecGroups);
+    PULSE_REQUIRE((raw_stride % 4) == 0 && raw_stride >= ((cols + 3) & ~3) && (reinterpret_cast<uintptr_t>(raw_out) & 15) == 0,
+                  "pulse_rms_normalize_copy: raw_out rows must be 16-byte aligned and hold cols rounded up to 4 floats");
+    if (y_cols <= 1024)
+        hipLaunchKernelGGL((rms_normalize_vec4_kernel<0, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
+                           (unsigned short*)nullptr, 0LL, 0LL, raw_out, (long long)raw_stride);
+    else
+        hipLaunchKernelGGL(rms_normalize_vec4_kernel<0>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
+                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
+                           (unsigned short*)nullptr, 0LL, 0LL, raw_out, (long long)raw_stride);
+    return check_launch("pulse_rms_normalize_copy");
 }
 
 int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols, const double* mean,

@@ -161,6 +161,7 @@ class HumanoidIm:
         n, dev = self.num_envs, self.device
         self._obs_store = torch.zeros(n, self.obs_pitch, device=dev)
         self._im_launch_cache = {}                      # per phase: the filled pulse_im_step argument struct (ops.im_step cache=)
+        self._obs_sink, self.obs_sink_written = None, False      # set_obs_sink: a second destination for the next step's observation rows
         self.obs_buf = self._obs_store[:, :self.num_obs]
         self.rew_buf = torch.zeros(n, device=dev)
         self.reward_raw = torch.zeros(n, 5 if self.power_reward else 4, device=dev)
@@ -331,6 +332,18 @@ class HumanoidIm:
         that view out as extras['amp_obs'] -- the agent passes the experience-buffer slot of the step, so recording the window costs no copy."""
         self._amp_obs_sink = rows
 
+    def set_obs_sink(self, rows):
+        """The NEXT post_physics_step also writes its observation rows into ``rows`` ((N, >= obs pitch) float32, any row pitch: the agent passes
+        experience-buffer slot ``next_obses[n]``, so recording the row costs a store inside the step kernel instead of a 15 MB copy launch).
+        Returns False -- and does nothing -- when the observation is post-processed after the kernel (fut_tracks_dropout / add_obs_noise at
+        training time): the caller copies as before.  ``obs_sink_written`` says whether the last step honoured the sink."""
+        self.obs_sink_written = False
+        if not self.test and (self._fut_tracks_dropout or self.add_obs_noise):
+            self._obs_sink = None
+            return False
+        self._obs_sink = rows
+        return True
+
     def _update_hist_amp_obs(self):
         """humanoid_amp.py:622-631: shift the history by one slot."""
         self._hist_amp_obs_buf.copy_(self._amp_obs_buf[:, 0:self._num_amp_obs_steps - 1].clone())
@@ -436,7 +449,7 @@ class HumanoidIm:
             t = self.progress_buf * self.dt + self._motion_start_times + self._motion_start_times_offset
             torch.ge(t, self._motion_len_env, out=self._pass_time)
 
-    def _im_step(self, what, env_ids=None, env_mask=None, ref_next=None, inc=0):
+    def _im_step(self, what, env_ids=None, env_mask=None, ref_next=None, inc=0, obs_copy=None):
         need_now = what & (PULSE_IM_REWARD | PULSE_IM_RESET)
         if self._use_motion_lib:
             clock, motion = self._motion_kwargs(inc)
@@ -478,7 +491,7 @@ class HumanoidIm:
             local_root_obs=self._local_root_obs, root_height_obs=self._root_height_obs, specs=self.reward_specs,
             power_coef=self.power_coefficient, power_reward=self.power_reward, env_ids=env_ids, env_mask=env_mask,
             obs=self._obs_store, obs_cols=self.obs_pitch, rew=self.rew_buf, rew_raw=self.reward_raw,
-            reset=self.reset_buf, terminate=self._terminate_buf, clock=clock, motion=motion)
+            reset=self.reset_buf, terminate=self._terminate_buf, clock=clock, motion=motion, obs_copy=obs_copy)
 
     def _recovery_counter_for_step(self):
         """HumanoidImGetup hands its recovery counter to the fused step (its _compute_reset, humanoid_im_getup.py:203-210); None here."""
@@ -608,18 +621,20 @@ class HumanoidIm:
             self._update_tensor_history()
         # progress += 1, pass_time, reward -> reset -> observations (humanoid.py:1316-1328): one launch.  With the motion library
         # the increment, the time-out test and the reference blend (t and t+1) all happen inside it.
+        sink, self._obs_sink = self._obs_sink, None          # set_obs_sink: the observation rows also go to the caller's buffer
         if self._use_motion_lib and self.cycle_motion:
             # cycle_motion (env_im_vae.yaml:55): the reward is taken on the OLD clock, then motions that ran out restart in place
             # (_compute_reset, humanoid_im.py:1125-1146), then reset + observations use the new clock
             self._im_step(PULSE_IM_REWARD, inc=1)
             self._cycle_motion_update()
-            self._im_step(PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
+            self._im_step(PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, obs_copy=sink)
         elif self._use_motion_lib:
-            self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, inc=1)
+            self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, inc=1, obs_copy=sink)
         else:
             self.progress_buf += 1
             self._update_pass_time()
-            self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)
+            self._im_step(PULSE_IM_REWARD | PULSE_IM_RESET | PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS, obs_copy=sink)
+        self.obs_sink_written = sink is not None
         self._obs_post()
         self.extras["terminate"] = self._terminate_buf
         self.extras["reward_raw"] = self.reward_raw
@@ -730,6 +745,17 @@ class VecTaskPythonWrapper:
         elif not self.alias_obs:
             obs = obs.clone()
         return obs, self.task.rew_buf, self.task.reset_buf, self.task.extras
+
+    def set_obs_sink(self, rows):
+        """Ask the task to write the NEXT step's observation rows into ``rows`` as well (HumanoidIm.set_obs_sink).  Only when what step()
+        returns IS the task's buffer (no clamp, aliased hand-out); False = not taken, the caller copies."""
+        f = getattr(self.task, "set_obs_sink", None)
+        if f is None or self.clip_obs != float("inf") or not self.alias_obs:
+            return False
+        return bool(f(rows))
+
+    def obs_sink_written(self):
+        return bool(getattr(self.task, "obs_sink_written", False))
 
     def reset(self, env_ids=None):
         self.task.reset(env_ids)

@@ -526,12 +526,31 @@ def colsum_partial(x, m, n, ld, num_chunks, partial, ld_partial, x_off=0, partia
                                                 partial.data_ptr() + 4 * partial_off, ld_partial, _stream()), "pulse_colsum_partial")
 
 
+def rms_copy_supported(x, cols, y, y_cols, raw_out):
+    """Can ``rms_normalize(..., raw_out=raw_out)`` run (pulse_rms_normalize_copy's wide-row form)?  Decided by the caller once per buffer set."""
+    ok = lambda t: t is not None and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    c4 = (cols + 3) // 4 * 4
+    return bool(ok(x) and ok(y) and ok(raw_out) and 64 <= cols and y_cols <= 3072 and y_cols % 4 == 0 and y_cols >= cols and x.stride(0) >= c4 and
+                y.stride(0) >= y_cols and raw_out.stride(0) >= c4 and raw_out.shape[1] >= c4)
+
+
 def rms_normalize(x, mean, var, *, rows, cols, x_stride, y, y_stride, y_cols=None, row_idx=None, eps=1e-5, clip=5.0,
-                  unnorm=False, moment_partials=None, num_blocks=None, planes=None):
+                  unnorm=False, moment_partials=None, num_blocks=None, planes=None, raw_out=None):
     """``planes``: a (3, rows, pitch) int16 planes tensor that also receives the exact three-way bf16 split of y (layer-1 operand of gemm_x3p).
-    ``y`` of dtype int16: the output IS a bf16 matrix (layer-1 operand of the bf16-storage training path); wide rows only."""
+    ``y`` of dtype int16: the output IS a bf16 matrix (layer-1 operand of the bf16-storage training path); wide rows only.
+    ``raw_out``: a (rows, >= cols rounded up to 4) float32 view (any 16-byte aligned row pitch) that also receives the RAW rows read (the rollout's
+    record of the observation, see rms_copy_supported); normalising direction, fp32 output, no planes."""
     if num_blocks is None:
         num_blocks = max(1, min(512, rows // 16)) if moment_partials is None else moment_partials.shape[0]
+    if raw_out is not None:
+        if unnorm or planes is not None or y.dtype != torch.float32:
+            raise ValueError("rms_normalize: raw_out goes with the plain normalising direction only")
+        if not raw_out.is_cuda or raw_out.dtype != torch.float32 or raw_out.dim() != 2 or raw_out.stride(1) != 1 or raw_out.shape[0] < rows:
+            raise TypeError("rms_normalize: raw_out must be a (>= rows, cols) float32 CUDA view with unit inner stride")
+        _lib.check(_lib.load().pulse_rms_normalize_copy(_p(x), x_stride, _p(row_idx), rows, cols, _p(mean), _p(var), eps, clip, _p(y), y_stride,
+                                                        cols if y_cols is None else y_cols, _p(moment_partials), num_blocks, raw_out.data_ptr(),
+                                                        raw_out.stride(0), _stream()), "pulse_rms_normalize_copy")
+        return
     if y.dtype == torch.int16:
         if unnorm or planes is not None or not y.is_cuda or y.stride(-1) != 1:
             raise ValueError("rms_normalize: a bf16 output goes with the normalising direction, without planes")

@@ -27,6 +27,7 @@ What is different underneath (MI355X-first):
     all-reduce of the flat gradient (pulse_amd/parallel.py).
 """
 import math
+import os
 import time
 
 import torch
@@ -164,6 +165,10 @@ class CommonAgent:
         self._tensors_ready = False
         self._boot_idx = self._boot_val = None
         self._boot_shortcut = None           # decided on the first rollout (_bootstrap_values)
+        # the rollout's two records of every observation (obses[n], next_obses[n]) written by the kernels that hold the row anyway -- the
+        # normaliser pass and the env's step kernel -- instead of by two 15 MB copy launches per step; PULSE_OBS_SINK=0 restores the copies (A/B)
+        self._obs_sink_enabled = os.environ.get("PULSE_OBS_SINK", "1") != "0"
+        self._obs_fused_key, self._obs_fused_ok = None, False
         self._rollout_noise = None
 
     # ------------------------------------------------------------------ construction helpers
@@ -276,22 +281,41 @@ class CommonAgent:
         """The pitched allocation behind an (N, obs_dim) observation view (zero copy)."""
         return obs
 
-    def _preproc_obs(self, obs_batch, ws, rows, row_idx=None):
-        """running_mean_std(obs) written into the network's GEMM-ready input buffer."""
+    def _preproc_obs(self, obs_batch, ws, rows, row_idx=None, raw_out=None):
+        """running_mean_std(obs) written into the network's GEMM-ready input buffer.  ``raw_out``: the pass also records the raw rows there
+        (the rollout's ``obses`` slot; the caller checked _obs_record_fused)."""
         xp = ws.get("xp")                      # a model whose layer 1 runs on the planar GEMM: the normaliser also writes the operand's planes
-        self.running_mean_std.forward(obs_batch, row_idx=row_idx, out=ws["x"], out_cols=self.model.in_pitch, planes=xp)
+        self.running_mean_std.forward(obs_batch, row_idx=row_idx, out=ws["x"], out_cols=self.model.in_pitch, planes=xp, raw_out=raw_out)
         if xp is not None:
             ws["xp_fresh"] = True
         return ws["x"]
 
-    def get_action_values(self, obs, slot=None):
+    def _obs_record_fused(self, obs, ws, slot_rows):
+        """May the normaliser pass of a rollout step also record the raw observation into the experience-buffer slot (one launch instead of
+        a 15 MB copy + the pass)?  Needs the plain fp32 normaliser on wide 16-byte aligned rows (no operand planes).  Decided once per buffer set."""
+        key = (obs.data_ptr(), obs.stride(0), ws["x"].data_ptr(), slot_rows.stride(0))
+        if self._obs_fused_key != key:
+            self._obs_fused_key = key
+            self._obs_fused_ok = (ws.get("xp") is None and obs.dim() == 2 and
+                                  K.rms_copy_supported(obs, self.running_mean_std.mean_size, ws["x"], self.model.in_pitch, slot_rows))
+        return self._obs_fused_ok
+
+    def get_action_values(self, obs, slot=None, record_obs=False):
         """Actor + critic inference and action sampling for one rollout step.  With ``slot`` (time
-        index) the outputs are produced directly inside the experience buffer."""
+        index) the outputs are produced directly inside the experience buffer.  ``record_obs``: the step's observation still has to go into
+        experience-buffer slot ``obses[slot]`` (play_steps): done by the normaliser pass when it can, by a copy otherwise."""
         n = self.num_actors
         net = self.model
         ws = net.workspace(n, train=False)
         net.eval()
-        self._preproc_obs(obs["obs"], ws, n)
+        raw = None
+        if record_obs:
+            rows = self.experience_buffer.slot("obses", slot)
+            if self._obs_sink_enabled and self._obs_record_fused(obs["obs"], ws, rows):
+                raw = rows
+            else:
+                self.experience_buffer.update_data("obses", slot, obs["obs"])
+        self._preproc_obs(obs["obs"], ws, n, raw_out=raw)
         eb = self.experience_buffer
         t = self.horizon_length
         ap = net.a_pitch
@@ -345,15 +369,18 @@ class CommonAgent:
             self._rollout_noise.normal_(generator=self.noise_generator)
         if self._meter_partials is None:
             self._meter_partials = torch.zeros(self.horizon_length, max(1, min(64, self.num_actors // 128)), 4, device=self.ppo_device)
+        set_sink = getattr(self.vec_env, "set_obs_sink", None) if self._obs_sink_enabled else None
         for n in range(self.horizon_length):
             self.obs = self._env_reset_masked(done_mask) if done_mask is not None else self.env_reset([])
-            eb.update_data("obses", n, self.obs["obs"])
-            res_dict = self.get_action_values(self.obs, slot=n)
+            res_dict = self.get_action_values(self.obs, slot=n, record_obs=True)         # (+ eb.update_data("obses", n, obs), fused into the normaliser pass)
             for k in self.update_list:
                 eb.update_data(k, n, res_dict[k])
             self._before_env_step(n)
+            # next_obses[n]: the step kernel writes the row into the slot itself when the env can (set_obs_sink), a copy otherwise
+            sink = set_sink is not None and set_sink(eb.slot("next_obses", n))
             self.obs, rewards, self.dones, infos = self.env_step(self._action_for_env(res_dict))
-            eb.update_data("next_obses", n, self.obs["obs"])
+            if not (sink and self.vec_env.obs_sink_written()):
+                eb.update_data("next_obses", n, self.obs["obs"])
             self._after_env_step(n, infos)
             # ONE launch for the step's bookkeeping (:318-347): shaped reward / dones / terminate flags into slot n, episode
             # accumulators, the two AverageMeters, and the done mask that drives the next masked reset.  The bootstrap value of the

@@ -83,7 +83,7 @@ class RunningMeanStd:
             self._partials = torch.zeros(nblk, 2, self.mean_size, dtype=torch.float64, device=self.device)
         return self._partials
 
-    def forward(self, input, unnorm=False, *, row_idx=None, out=None, out_cols=None, update=None, norm_with=None, planes=None):
+    def forward(self, input, unnorm=False, *, row_idx=None, out=None, out_cols=None, update=None, norm_with=None, planes=None, raw_out=None):
         """input: (rows, >=mean_size) float32 with unit inner stride.  Returns ``out`` (allocated
         (rows, mean_size) when not given).  ``update`` overrides the training/frozen rule."""
         x = input
@@ -100,7 +100,7 @@ class RunningMeanStd:
         K.rms_normalize(x, src.running_mean, src.running_var, rows=rows, cols=f, x_stride=x.stride(0), y=out,  # update of the live stats
                         y_stride=out.stride(0), y_cols=out.shape[1] if out_cols is None else out_cols, row_idx=row_idx,
                         eps=self.epsilon, unnorm=unnorm, moment_partials=part,
-                        num_blocks=None if part is None else part.shape[0], planes=planes)
+                        num_blocks=None if part is None else part.shape[0], planes=planes, raw_out=raw_out)
         if do_update:
             K.rms_update(self.running_mean, self.running_var, self.count, part, f, self._count_host, rows)
             self._count_host += rows

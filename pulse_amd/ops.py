@@ -212,6 +212,16 @@ def _launch_sig(o):
     return sig() if sig is not None else o
 
 
+def _obs_copy_fields(obs_copy, n, cols, dev):
+    """(pointer, row stride) of im_step's second observation destination; (None, 0) without one."""
+    if obs_copy is None:
+        return None, 0
+    if (obs_copy.dtype != torch.float32 or obs_copy.device != dev or obs_copy.dim() != 2 or obs_copy.stride(1) != 1 or obs_copy.shape[0] != n or
+            obs_copy.shape[1] < cols or obs_copy.stride(0) < cols):
+        raise ValueError(f"obs_copy must be a ({n}, >= {cols}) float32 view on {dev} with unit inner stride")
+    return obs_copy.data_ptr(), obs_copy.stride(0)
+
+
 def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=None, dof_vel=None,
             progress=None, pass_time=None, cycle_counter=None, track_ids=None, reset_ids=None, term_dist=None,
             reset_use_mean=False, full_body_reward=True, obs_version=6, local_root_obs=True,
@@ -219,8 +229,10 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
             env_ids=None, env_mask=None, obs=None, obs_cols=None, rew=None, rew_raw=None, reset=None,
             terminate=None, clock=None, motion=None, upright=True, enable_early_termination=True, self_obs_version=1,
             force_sensor=None, dof_pos=None, ref_next_dof_pos=None, smpl_params=None, limb_weights=None, recovery_counter=None, cache=None,
-            zero_out_far=None, occl_bits=None, occl_reset=False):
-    """``occl_bits``: (N,) int32, bit j = tracked body j of the env is occluded (occl_training, humanoid_im.py:778-784, 827-831); ``occl_reset``:
+            zero_out_far=None, occl_bits=None, occl_reset=False, obs_copy=None):
+    """``obs_copy``: a second (N, >= obs_cols) float32 view (any row pitch, e.g. an experience-buffer slot) that receives the same observation rows
+    as ``obs``; NOT part of a cached launch's signature -- the pointer is patched into the cached struct on every call.
+    ``occl_bits``: (N,) int32, bit j = tracked body j of the env is occluded (occl_training, humanoid_im.py:778-784, 827-831); ``occl_reset``:
     occluded reset bodies never count as fallen (:1178-1183).
     ``zero_out_far``: dict(point_goal (N,) float32 read by the reward stage / written by the task-observation stage, close_distance,
     far_distance) -- the far-masking branch of _compute_task_obs / _compute_reward (humanoid_im.py:763-777, 814-826, 870-887).
@@ -240,7 +252,9 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
                            obs, obs_cols, rew, rew_raw, reset, terminate, clock, motion, upright, enable_early_termination, self_obs_version, force_sensor,
                            dof_pos, ref_next_dof_pos, smpl_params, limb_weights, recovery_counter, zero_out_far, occl_bits, occl_reset, _IM_DEBUG_BITS))
         if cache.get("sig") == sig:
-            _lib.check(lib.pulse_im_step(ctypes.byref(cache["args"]), _stream()), "pulse_im_step")
+            ca = cache["args"]
+            ca.obs_copy, ca.obs_copy_stride = _obs_copy_fields(obs_copy, ca.num_envs, ca.obs_cols, rb.device)
+            _lib.check(lib.pulse_im_step(ctypes.byref(ca), _stream()), "pulse_im_step")
             return cache["out"]
         # only launches whose outputs are all caller-owned are replayed (an output this wrapper allocates would be a new buffer every call)
         owned = ((obs is not None or not what & (PULSE_IM_SELF_OBS | PULSE_IM_TASK_OBS)) and
@@ -367,6 +381,9 @@ def im_step(rb, *, what, ref_now=None, ref_next=None, time_steps=1, dof_force=No
         a.obs, a.obs_stride = obs.data_ptr(), obs.stride()[0]
         a.obs_cols = width if obs_cols is None else obs_cols
         out["obs"] = obs
+        a.obs_copy, a.obs_copy_stride = _obs_copy_fields(obs_copy, n, a.obs_cols, dev)
+    elif obs_copy is not None:
+        raise ValueError("obs_copy without an observation stage")
     if what & PULSE_IM_REWARD:
         rw = 5 if power_reward else 4
         rew = torch.empty(n, dtype=torch.float32, device=dev) if rew is None else _dev(rew, "rew")

@@ -155,3 +155,58 @@ def test_bootstrap_value_shortcut_equals_full_critic_pass(dev):
     b = played(False)                                                     # an env that does not promise observation continuity
     assert b._boot_shortcut is False
     assert (b.experience_buffer.flat("next_values") - full).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("name,reference,fused", [("cfg1", "motion_lib", True), ("cfg1", "recorded", True), ("cfg5_small", "motion_lib", True),
+                                                  ("cfg3_small", "motion_lib", None), ("speed_z_small", "motion_lib", None)])
+def test_rollout_records_observations_without_copy_launches(dev, name, reference, fused):
+    """[r6] play_steps records every observation twice (obses[n] before the policy step, next_obses[n] after the env step:
+    a2c_common.play_steps).  The normaliser pass and the env's step kernel write those rows themselves (pulse_rms_normalize_copy,
+    pulse_im_step_args.obs_copy); PULSE_OBS_SINK=0 is the two-copies-per-step form.  Every tensor of the experience buffer must be
+    bit-identical either way, and the fused form must really be the one that ran."""
+    def played(enabled):
+        torch.manual_seed(7)
+        agent, _ = configs.make_agent(name, device=dev, seed=21, reference=reference)
+        agent._obs_sink_enabled = enabled
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        agent._tensors_ready = True
+        calls = []
+        eb = agent.experience_buffer
+        orig = eb.update_data
+        eb.update_data = lambda nm, i, v: (calls.append(nm), orig(nm, i, v))[1]
+        batch = agent.play_steps()
+        return agent, calls, batch
+    a, calls_a, batch_a = played(True)
+    b, calls_b, batch_b = played(False)
+    assert calls_b.count("obses") == b.horizon_length and calls_b.count("next_obses") == b.horizon_length
+    if fused:
+        assert "obses" not in calls_a and "next_obses" not in calls_a, "the fused records fell back to copies"
+        assert a.vec_env.obs_sink_written()
+    for k in a.experience_buffer.phys:
+        assert torch.equal(a.experience_buffer.phys[k], b.experience_buffer.phys[k]), k
+    for k in ("returns", "advs_raw"):
+        assert torch.equal(batch_a[k], batch_b[k]), k
+    assert a.experience_buffer.phys["dones"].sum() > 0                    # resets happened: obses[n + 1] != next_obses[n] on those rows
+    nx, ob = a.experience_buffer.phys["next_obses"], a.experience_buffer.phys["obses"]
+    assert not torch.equal(nx[:, :-1], ob[:, 1:])
+
+
+def test_obs_sink_is_refused_when_the_observation_is_post_processed(dev):
+    """add_obs_noise / fut_tracks_dropout edit the row AFTER the step kernel (training time): the env must refuse the sink and the agent copies."""
+    env, _ = configs.make_env(32, 8, dev, seed=3, reference="motion_lib", env_overrides={"add_obs_noise": True})
+    env.alias_obs = True
+    rows = torch.zeros(32, env.task.obs_pitch, device=dev)
+    assert env.set_obs_sink(rows) is False
+    env.reset()
+    env.step(torch.zeros(32, 69, device=dev))
+    assert not env.obs_sink_written() and rows.abs().sum() == 0
+    env2, _ = configs.make_env(32, 8, dev, seed=3, reference="motion_lib")
+    assert env2.set_obs_sink(rows) is False                               # a caller that may keep the returned tensor gets the reference's fresh copy
+    env2.alias_obs = True
+    assert env2.set_obs_sink(rows) is True
+    env2.reset()
+    obs, *_ = env2.step(torch.zeros(32, 69, device=dev))
+    assert env2.obs_sink_written() and torch.equal(rows[:, :obs.shape[1]], obs)
+    env2.step(torch.zeros(32, 69, device=dev))                            # the sink is one-shot
+    assert not env2.obs_sink_written()

@@ -680,7 +680,10 @@ int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int
  * number of slabs its weight-gradient launch wrote): out[off + i] = scale * sum_s slabs[s * slab_stride + off + i] + alpha_r * flat[off + i]
  * (the regularisers of pulse_disc_reg; alphas / flat may be NULL).  sq_partials[block] (optional) = the block's share of sum out^2 -- the
  * clip_grad_norm_ input (common_agent.py:472-478) without a pass of its own -- and w2_partials[block * 8 + r] (optional) the share of
- * sum flat[region r]^2.  offsets / counts / nslabs / alphas are HOST arrays of num_regions <= 8 entries; offsets and counts multiples of 4.
+ * sum flat[region r]^2 for the first 8 regions.  offsets / counts / nslabs / alphas are HOST arrays of num_regions <= 32 entries (8 before v29); offsets
+ * and counts multiples of 4.  nslabs[r] = 0 (v29): no launch of this pass wrote the region -- out is alpha_r * flat there (zero without a
+ * regulariser), nothing is read from the slabs: a pass that visits part of a network (the kin pass of PULSE: encoder / decoder / prior, not the
+ * critic) neither zero-fills nor sums the slabs of the rest.
  * region_src / region_src_stride (HOST arrays, may be NULL; v19): a region with region_src[r] != NULL sums nslabs[r] partial rows of its OWN device
  * buffer (row s at region_src[r] + s * region_src_stride[r]) instead of the slabs -- column-sum partials of a bias gradient, or the scratch of a
  * weight gradient that was split wider than the slab count; same summation order as pulse_reduce_slabs (bit-identical results). */

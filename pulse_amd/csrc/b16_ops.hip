@@ -229,15 +229,16 @@ __global__ void __launch_bounds__(256) disc_reg_kernel(const float* __restrict__
 // A region may name its OWN source (src[r] != null: nslabs[r] partial rows of sstride[r] floats, element i of the region at src[r][s * sstride[r] + i]):
 // the column-sum partials of a bias gradient or the scratch of a weight gradient that was split wider than the slab count are summed here
 // instead of by a pulse_reduce_slabs launch of their own.
-struct ReduceRegions { long long off[8]; long long count[8]; int nslabs[8]; float alpha[8]; const float* src[8]; long long sstride[8]; int n; };
+constexpr int kReduceRegions = 32;        // (8 until v29; the regularisers' w2 partials cover the first 8)
+struct ReduceRegions { long long off[kReduceRegions]; long long count[kReduceRegions]; int nslabs[kReduceRegions]; float alpha[kReduceRegions];
+                       const float* src[kReduceRegions]; long long sstride[kReduceRegions]; int n; };
 __global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restrict__ slabs, long long slab_stride, const ReduceRegions rg, float* __restrict__ out,
                                                           float scale, const float* __restrict__ flat, float* __restrict__ sq_partials,
                                                           float* __restrict__ w2_partials) {
     __shared__ float red[4][9];
     float sq = 0.f, w2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r >= rg.n) break;
+    for (int r = 0; r < rg.n; ++r) {
+        float w2r = 0.f;
         const float* base = rg.src[r] ? rg.src[r] : slabs + rg.off[r];
         const long long stride = rg.src[r] ? rg.sstride[r] : slab_stride;
         float* o = out + rg.off[r];
@@ -249,8 +250,9 @@ __global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restri
             // the SAME association as reduce_slabs_kernel (gemm_f32.hip): slab 0 + four chains over the groups of four, remainder onto chain 0,
             // ((c0 + c1) + (c2 + c3)) -- a gradient reduced by either kernel is bit-identical (the data-parallel path reduces bucket by bucket
             // with pulse_reduce_slabs, the single-GPU path with this kernel)
-            float4 a = reinterpret_cast<const float4*>(base)[i];
             float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1, a3 = a1;
+            float4 a = a1;
+            if (ns > 0) a = reinterpret_cast<const float4*>(base)[i];         // ns == 0: a region no launch of this pass wrote (zero gradient)
             int k = 1;
             for (; k + 3 < ns; k += 4) {
                 const float4 v0 = reinterpret_cast<const float4*>(base + k * stride)[i];
@@ -270,12 +272,15 @@ __global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restri
             a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
             if (w) {
                 const float4 v = reinterpret_cast<const float4*>(w)[i];
-                w2[r] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                w2r += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 if (al != 0.f) { a.x += al * v.x; a.y += al * v.y; a.z += al * v.z; a.w += al * v.w; }
             }
             sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
             reinterpret_cast<float4*>(o)[i] = a;
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q == r) w2[q] += w2r;
     }
     float vals[9] = {sq, w2[0], w2[1], w2[2], w2[3], w2[4], w2[5], w2[6], w2[7]};
 #pragma unroll
@@ -420,21 +425,21 @@ int pulse_disc_reg(const float* flat, float* grad, int32_t num_ranges, const int
 int pulse_reduce_grads(const float* slabs, int64_t slab_stride, int32_t num_regions, const int64_t* offsets, const int64_t* counts, const int32_t* nslabs,
                        const float* alphas, const float* const* region_src, const int64_t* region_src_stride, float* out, float scale, const float* flat,
                        float* sq_partials, float* w2_partials, int32_t num_blocks, pulse_stream_t s) {
-    PULSE_REQUIRE(num_regions >= 1 && num_regions <= 8 && num_blocks >= 1, "pulse_reduce_grads: 1..8 regions");
+    PULSE_REQUIRE(num_regions >= 1 && num_regions <= kReduceRegions && num_blocks >= 1, "pulse_reduce_grads: 1..32 regions");
     PULSE_REQUIRE(slabs && offsets && counts && nslabs && out, "pulse_reduce_grads: null pointer");
     PULSE_REQUIRE((slab_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                   (!flat || (reinterpret_cast<uintptr_t>(flat) & 15) == 0), "pulse_reduce_grads: 16-byte alignment required");
     ReduceRegions rg;
     rg.n = num_regions;
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < kReduceRegions; ++r) {
         rg.off[r] = r < num_regions ? offsets[r] : 0; rg.count[r] = r < num_regions ? counts[r] : 0; rg.nslabs[r] = r < num_regions ? nslabs[r] : 1;
         rg.alpha[r] = (r < num_regions && alphas) ? alphas[r] : 0.f;
         rg.src[r] = (r < num_regions && region_src) ? region_src[r] : nullptr;
         rg.sstride[r] = (rg.src[r] && region_src_stride) ? region_src_stride[r] : 0;
         PULSE_REQUIRE(!rg.src[r] || ((reinterpret_cast<uintptr_t>(rg.src[r]) & 15) == 0 && (rg.sstride[r] % 4) == 0 && (rg.nslabs[r] == 1 || rg.sstride[r] >= rg.count[r])),
                       "pulse_reduce_grads: a region's own source must be 16-byte aligned with a row stride that is a multiple of 4 floats covering the region");
-        PULSE_REQUIRE(rg.off[r] >= 0 && rg.count[r] >= 0 && (rg.off[r] % 4) == 0 && (rg.count[r] % 4) == 0 && rg.nslabs[r] >= 1,
-                      "pulse_reduce_grads: region offsets / counts must be non-negative multiples of 4 floats, slab counts >= 1");
+        PULSE_REQUIRE(rg.off[r] >= 0 && rg.count[r] >= 0 && (rg.off[r] % 4) == 0 && (rg.count[r] % 4) == 0 && rg.nslabs[r] >= 0,
+                      "pulse_reduce_grads: region offsets / counts must be non-negative multiples of 4 floats, slab counts >= 0");
     }
     hipLaunchKernelGGL(reduce_grads_kernel, dim3((unsigned)num_blocks), dim3(256), 0, as_stream(s), slabs, (long long)slab_stride, rg, out, scale, flat,
                        sq_partials, w2_partials);

@@ -730,8 +730,8 @@ class ReduceGrads:
 
     def __init__(self, slabs, slab_stride, regions, out, flat=None):
         n = len(regions)
-        if not 1 <= n <= 8:
-            raise ValueError("ReduceGrads: 1..8 regions")
+        if not 1 <= n <= 32:
+            raise ValueError("ReduceGrads: 1..32 regions")
         _chk(slabs, "slabs"), _chk(out, "out"), _chk(flat, "flat")
         self.n = n
         self.offs = (ctypes.c_int64 * n)(*[int(r[0]) for r in regions])

@@ -526,17 +526,21 @@ class AMPAgent(CommonAgent):
                 task.kld_coefficient = (0.01 - mn) * max((5000 - self.epoch_num) / 2500, 0) + mn
             info["kin_kld_w"] = task.kld_coefficient
         # ---- backward through the GEMM plans; the head-level gradients join at the encoder / prior heads
-        model.book.zero_slab_ranges(model._untouched(ws, ("dec", "enc", "prior")))     # the critic's slabs (PPO pass) must read as zero
         model.backward_actor(ws, kin={"c_kl": kld_w / mb, "c_ar1": (task.ar1_coefficient / n_err) if use_ar1 else 0.0,
                                       "c_regu": (0.005 * 0.001 / (mb * E)) if use_regu else 0.0, "progress": prog, "horizon": t})
         model.backward_prior(ws)
-        model.book.reduce_grads(1.0 / self.world_size)
+        # the critic (PPO pass only) is not visited: its gradient is written as zeros by the region reduce, which also leaves the norm clip's
+        # sums of squares on one GPU (with data parallelism the norm is taken after the all-reduce)
+        sqp = self._sq_slice(0)
+        fused = model.book.reduce_grads(1.0 / self.world_size, untouched=model._untouched(ws, ("dec", "enc", "prior")),
+                                        sq_partials=None if self.multi_gpu else sqp)
         if self.multi_gpu:
             self.dist.sync_gradients(model.grad)
         self.kin_step += 1
-        K.sqnorm_partial(model.grad, model.n_flat, self._sq_partials[:256])
+        if not fused:
+            K.sqnorm_partial(model.grad, model.n_flat, sqp)
         K.adam_step(model.flat, model.grad, self.kin_exp_avg, self.kin_exp_avg_sq, model.n_flat, lr=self.kin_lr, step=self.kin_step,
-                    max_norm=self.grad_norm, sqnorm_partials=self._sq_partials[:256], grad_norm_out=self._grad_norm)
+                    max_norm=self.grad_norm, sqnorm_partials=sqp, grad_norm_out=self._grad_norm)
         info["kin_loss"] = kin_loss
         info["grad_norm"] = self._grad_norm.clone()
         return info

@@ -29,6 +29,7 @@ from .._lib import (ACT_NONE, ACT_RELU, ACT_SILU, ACT_SILU_D, EPI_BIAS_ACT, EPI_
 
 import os
 
+REGION_REDUCE = os.environ.get("PULSE_BOOK_REGION_REDUCE", "1") != "0"     # ParamBook.reduce_grads region by region (0: zero fill + uniform reduce, A/B)
 SILU_DERIV = os.environ.get("PULSE_SILU_DERIV", "1") != "0"       # SiLU layers keep their derivative instead of their pre-activation (forward_plan)
 
 
@@ -117,9 +118,52 @@ class ParamBook:
             if hi > lo:
                 self.slabs[:, lo:hi].zero_()
 
-    def reduce_grads(self, scale=1.0):
+    def reduce_regions(self, untouched=()):
+        """[(offset, count, nslabs)] covering [0, n_flat): per parameter the number of slabs its weight-gradient launch writes
+        (note_slab_layout; split_k for a parameter no launch registered), 0 for a parameter inside one of the ``untouched`` ranges
+        [(lo, hi), ...] (no launch of this pass writes it: its gradient is zero); adjacent parameters with equal counts are merged."""
+        lay = self.__dict__.get("_slab_layout", {})
+        regions = []
+        pos = 0
+        for p in sorted(self.params.values(), key=lambda q: q.off):
+            size = p.rows * p.pitch
+            ns = lay[p.name][0] if p.name in lay else self.split_k
+            if any(lo <= p.off and p.off + size <= hi for lo, hi in untouched):
+                ns = 0
+            if p.off != pos:
+                raise RuntimeError("ParamBook: parameters are not contiguous in the flat buffer")
+            if regions and regions[-1][2] == ns:
+                regions[-1] = (regions[-1][0], regions[-1][1] + size, ns)
+            else:
+                regions.append((p.off, size, ns))
+            pos = p.off + size
+        if pos < self.n_flat:                                   # the flat buffer's tail padding
+            if regions and regions[-1][2] == 0:
+                regions[-1] = (regions[-1][0], regions[-1][1] + self.n_flat - pos, 0)
+            else:
+                regions.append((pos, self.n_flat - pos, 0))
+        return regions
+
+    def reduce_grads(self, scale=1.0, untouched=None, sq_partials=None):
+        """grad = scale * (sum of the slabs).  ``untouched`` (ranges of the sub-networks the pass did not visit, ComputeGraph.untouched_ranges):
+        the reduce goes region by region with each parameter's OWN slab count and writes zeros over the untouched ranges [r6] -- nothing has
+        to be zero-filled before the pass and no slab a launch never writes is read (the uniform form read split_k slabs of every parameter:
+        930 MB per minibatch of cfg3, plus a 230 MB zero fill of the critic's slabs).  ``sq_partials`` (with ``untouched``): the launch also
+        leaves the per-block sums of squares of the result (clip_grad_norm_ without its own pass).  Returns True when sq_partials were written."""
+        if untouched is not None and REGION_REDUCE:
+            key = tuple(untouched)
+            cache = self.__dict__.setdefault("_reduce_cache", {})
+            rg = cache.get(key)
+            if rg is None:
+                regions = self.reduce_regions(untouched)
+                rg = cache[key] = K.ReduceGrads(self.slabs, self.n_flat, [(o, c, n, 0.0) for o, c, n in regions], self.grad) if len(regions) <= 32 else False
+            if rg:
+                rg.run(scale=scale, sq_partials=sq_partials)
+                return sq_partials is not None
+        if untouched is not None:
+            self.zero_slab_ranges(untouched)
         K.reduce_slabs(self.slabs, self.split_k, self.n_flat, self.n_flat, self.grad, scale=scale)
-        return self.grad
+        return False
 
     def clip_and_adam(self, lr, max_norm=0.0, weight_decay=0.0):
         """nn.utils.clip_grad_norm_ + Adam.step over every parameter of the book."""
@@ -289,6 +333,7 @@ class MlpGraph:
             #  agree on it, and network_z / network_sept also build backward plans for the rollout's m -- round-5 advisor finding)
             sl = K.dw_split_x3(lin.n, lin.k_phys, 1, S, K=16384)
             book.note_slab_layout(lin.w.name, 1 if via_scratch else sl, m)
+            book.note_slab_layout(lin.b.name, 1 if via_scratch else sl, m)      # (the bias gradient rides along as the launch's per-slab row sums)
             if via_scratch:
                 ws_ = self._w_scratch
                 p.gemm(gz, x, ws_, M=lin.n, N=lin.k_phys, K=m, lda=ldg, ldb=x.stride(0), ldc=lin.w.pitch, a_layout=GEMM_OUT_CONTIG,

@@ -119,12 +119,17 @@ class AMPZModel:
     def backward_prior(self, ws):
         ws["G"]["bwd_prior"].run()                                  # d loss / d prior heads was written by backward_actor(kin=...)
 
-    def backward(self, ws, m, grad_scale=1.0):
-        """PPO backward: actor (through the VAE) + critic; weight gradients of untouched sub-nets stay zero."""
-        self.book.zero_slab_ranges(self._untouched(ws, ("dec", "enc", "critic", "critic_z")))      # the prior's slabs (kin pass) must read as zero
+    supports_fused_sqnorm = True
+
+    def backward(self, ws, m, grad_scale=1.0, sq_partials=None, on_bucket=None):
+        """PPO backward: actor (through the VAE) + critic; weight gradients of untouched sub-nets (the prior: kin pass only) are zero.
+        ``sq_partials``: the gradient reduce also leaves the norm clip's per-block sums of squares there; returns True when it did."""
         self.backward_actor(ws)
         ws["G"]["bwd_critic"].run()
-        return self.book.reduce_grads(grad_scale)
+        done = self.book.reduce_grads(grad_scale, untouched=self._untouched(ws, ("dec", "enc", "critic", "critic_z")), sq_partials=sq_partials)
+        if sq_partials is not None and not done:                # (the uniform reduce: more regions than one launch takes)
+            K.sqnorm_partial(self.book.grad, self.book.n_flat, sq_partials)
+        return self.book.grad
 
     def _untouched(self, ws, tags):
         key = ("untouched",) + tuple(tags)

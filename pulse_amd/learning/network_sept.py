@@ -212,14 +212,21 @@ class AMPSeptModel:
         self._task(ws)
         ws["G"]["fwd_critic"].run()
 
-    def backward(self, ws, m, grad_scale=1.0):
+    supports_fused_sqnorm = True
+
+    def backward(self, ws, m, grad_scale=1.0, sq_partials=None, on_bucket=None):
         """d loss / d (mu, value) are in ws['dmu'] / ws['dval'].  The shared task MLP receives the sum of the actor's and the critic's
-        gradient at its output (both already carry the SiLU derivative from the fused input-gradient epilogues)."""
+        gradient at its output (both already carry the SiLU derivative from the fused input-gradient epilogues).  Every layer is visited,
+        so the region reduce reads exactly the slabs the weight-gradient launches wrote (no zero fill of the slab buffer) and leaves the norm
+        clip's sums of squares in ``sq_partials``."""
         net, g = self.net, ws["g"]
         tc, cw = net.t_col, net.cat_width
-        self.book.slabs.zero_()
         ws["G"]["bwd_actor"].run()
         ws["G"]["bwd_critic"].run()
         g.grad("ain")[:, tc:cw].add_(g.grad("cin")[:, tc:cw])
         ws["G"]["bwd_task"].run()
-        return self.book.reduce_grads(grad_scale)
+        if "untouched" not in ws:
+            ws["untouched"] = g.untouched_ranges({"actor", "critic", "task"})
+        if not self.book.reduce_grads(grad_scale, untouched=ws["untouched"], sq_partials=sq_partials) and sq_partials is not None:
+            K.sqnorm_partial(self.book.grad, self.book.n_flat, sq_partials)
+        return self.book.grad

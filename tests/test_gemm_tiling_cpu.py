@@ -75,3 +75,28 @@ def test_per_layer_slab_regions_cover_the_flat_gradient_once():
     hs = torch.zeros(32, net.n_flat - net.wh_off)
     carved, fused = K.carve_reduce_regions(regions, [(net.wh_off, net.n_flat - net.wh_off, 32, hs)])
     assert fused and [r[2] for r in carved] == [8, 16, 32] and sum(r[1] for r in carved) == net.n_flat
+
+
+def test_param_book_reduce_regions_cover_the_flat_buffer():
+    """[r6] ParamBook.reduce_regions: per-parameter slab counts, zeros over untouched ranges, adjacent equal counts merged, tail padding covered."""
+    from pulse_amd.learning.graph import ParamBook
+    book = ParamBook("cpu", split_k=8)
+    book.add("a.w", 8, 10)           # pitch 12 -> 96 floats
+    book.add("a.b", 1, 8)            # 8
+    book.add("b.w", 4, 6)            # pitch 8 -> 32
+    book.add("b.b", 1, 4)            # 4
+    book.add("c.w", 2, 3)            # pitch 4 -> 8
+    book.add("c.b", 1, 2)            # pitch 4 -> 4   (total 152; n_flat = 152)
+    book.add("sigma", 1, 5)          # pitch 8 -> 8  (no launch registered: split_k)
+    book.finalize(trainable=False)
+    book.note_slab_layout("a.w", 4, 256); book.note_slab_layout("a.b", 4, 256)
+    book.note_slab_layout("b.w", 4, 256); book.note_slab_layout("b.b", 4, 256)
+    book.note_slab_layout("c.w", 1, 256); book.note_slab_layout("c.b", 1, 256)
+    regs = book.reduce_regions(())
+    assert regs == [(0, 140, 4), (140, 12, 1), (152, 8, 8)]
+    regs = book.reduce_regions([(104, 140)])                      # sub-network b untouched
+    assert regs == [(0, 104, 4), (104, 36, 0), (140, 12, 1), (152, 8, 8)]
+    assert sum(c for _, c, _ in regs) == book.n_flat and all(o % 4 == 0 and c % 4 == 0 for o, c, _ in regs)
+    import pytest
+    with pytest.raises(RuntimeError):
+        book.note_slab_layout("a.w", 8, 128)                      # another plan writing a different slab count: refused

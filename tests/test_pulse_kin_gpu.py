@@ -93,3 +93,32 @@ def test_humanoid_z_decoder_in_env(dev):
     rel_close(act, want, 5e-5, "z -> action")
     task.step(az.to(dev))                                                       # full step with the latent action
     assert torch.isfinite(task.obs_buf).all() and task.rew_buf.shape == (n,)
+
+
+@pytest.mark.parametrize("name", ["cfg3_small", "cfg3_ppo_small", "terrain_z_small"])
+def test_region_reduce_equals_zero_fill_plus_uniform_reduce(dev, name, monkeypatch):
+    """[r6] ParamBook.reduce_grads goes region by region (each parameter's own slab count, zeros over the sub-networks a pass does not
+    visit, the norm clip's sums of squares from the same launch) instead of zero-filling the unvisited slabs and summing split_k slabs of
+    everything.  Same summation order per element: the GRADIENT is bit-identical; the clip's norm is summed in another order, so the
+    parameters after two epochs agree to round-off."""
+    from pulse_amd.learning import graph as G
+
+    def run(region):
+        monkeypatch.setattr(G, "REGION_REDUCE", region)
+        torch.manual_seed(4)
+        agent, _ = configs.make_agent(name, device=str(dev), seed=9)
+        agent.train_epoch()
+        grad = agent.model.grad.clone()
+        agent.train_epoch()
+        return agent, grad
+    a, ga = run(True)
+    b, gb = run(False)
+    book = a.model.book
+    assert book.__dict__.get("_reduce_cache") and all(book._reduce_cache.values()), "the region reduce was not the one that ran"
+    assert not b.model.book.__dict__.get("_reduce_cache")
+    regs = [r for rg in book._reduce_cache for r in book.reduce_regions(rg)]
+    assert any(ns == 0 for _, _, ns in regs) or name == "terrain_z_small"     # (the terrain policy visits every layer)
+    d = (ga - gb).abs().max().item()
+    assert d <= 1e-6 * max(1.0, gb.abs().max().item()), d          # (first epoch's last minibatch: parameters already differ by the clip's round-off)
+    rel = (a.model.flat - b.model.flat).abs().max().item() / b.model.flat.abs().max().item()
+    assert rel <= 1e-5, rel

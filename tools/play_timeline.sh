@@ -19,15 +19,16 @@ for r in rows[a:b]:
     print(f"gap {max(0, s - prev_end) / 1e3:6.2f} us | {(e - s) / 1e3:7.2f} us | {r['Kernel_Name'][:110]}")
     prev_end = max(prev_end, e)
 print(f"step: {(int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])) / 1e3:.1f} us, {b - a} launches")
-# one minibatch of the update for comparison: from the last ppo_loss launch back to the normaliser before it and on to the next normaliser
-li = [i for i, n in enumerate(names) if "ppo_loss_kernel" in n][-3]
-a = max(i for i in range(li) if "rms_normalize_vec4" in names[i])
-b = min(i for i in range(li, len(names)) if "rms_normalize_vec4" in names[i])
+# one minibatch of the update: from one optimiser launch to the next
+ad = [i for i, n in enumerate(names) if "adam" in n]
+a, b = ad[-3] + 1, ad[-2] + 1
 prev_end = int(rows[a - 1]["End_Timestamp"])
 print("--- one minibatch of the update")
+busy = 0.0
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     print(f"gap {max(0, s - prev_end) / 1e3:6.2f} us | {(e - s) / 1e3:7.2f} us | {r['Kernel_Name'][:110]}")
+    busy += (e - s) / 1e3
     prev_end = max(prev_end, e)
-print(f"minibatch: {(int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])) / 1e3:.1f} us, {b - a} launches")
+print(f"minibatch: {(int(rows[b - 1]['End_Timestamp']) - int(rows[a - 1]['End_Timestamp'])) / 1e3:.1f} us wall, {busy:.1f} us of kernels, {b - a} launches")
 PY

@@ -506,19 +506,24 @@ class AMPAgent(CommonAgent):
         K.vae_kin_loss(ws["mu"], gt, g.act_bufs["zheads"], g.act_bufs["pheads"], prog, ws["dmu"], self._kin_partials, rows=mb,
                        num_actions=self.actions_num, embedding_size=E, horizon=t, clamp=net.use_vae_clamped_prior, clamp_max=net.vae_var_clamp_max,
                        use_ar1=use_ar1, use_regu=use_regu)
-        sums = self._kin_partials.sum(0)                                       # fixed-order reduction of the per-workgroup partials
-        info = {}
-        kin_action_loss, kld = sums[0] / mb, sums[1] / mb
+        # the loss terms from the per-workgroup partials in three small launches (fixed-order column sum, one scaling, one dot product) instead of
+        # a dozen scalar ops: sums = [sum sq action error -> RMSE term, KL, AR(1), four regulariser sums, -]
         n_err = (mb // t) * (t - 1)
-        ar1_prior = sums[2] / n_err if use_ar1 else 0
-        if use_ar1:
-            info["kin_ar1"] = ar1_prior
-        regu_prior = 0
-        if use_regu:
-            regu_prior = (sums[3] + sums[4]) / (mb * E) * 0.001 + (sums[5] + sums[6]) / (mb * E) * 0.001
-            info["kin_prior_regu"] = regu_prior
         kld_w = float(task.kld_coefficient)
-        kin_loss = kin_action_loss + kld * kld_w + ar1_prior * task.ar1_coefficient + regu_prior * 0.005
+        key = (mb, t, E, use_ar1, use_regu, kld_w, float(task.ar1_coefficient))
+        if getattr(self, "_kin_scale_key", None) != key:
+            r = 0.001 / (mb * E) if use_regu else 0.0
+            self._kin_scale = torch.tensor([1.0 / mb, 1.0 / mb, (1.0 / n_err) if use_ar1 else 0.0, r, r, r, r, 0.0], device=self.ppo_device)
+            self._kin_weight = torch.tensor([1.0, kld_w, float(task.ar1_coefficient), 0.005, 0.005, 0.005, 0.005, 0.0], device=self.ppo_device)
+            self._kin_scale_key = key
+        terms = self._kin_partials.sum(0) * self._kin_scale
+        info = {}
+        kin_action_loss, kld = terms[0], terms[1]
+        if use_ar1:
+            info["kin_ar1"] = terms[2]
+        if use_regu:
+            info["kin_prior_regu"] = terms[3:7].sum()
+        kin_loss = torch.dot(terms, self._kin_weight)
         info["kin_action_loss"], info["kin_KLD"] = kin_action_loss, kld
         if task.kld_anneal:                                                     # :826-832 (after the loss: this step used the old weight)
             if self.epoch_num > 2500:

@@ -646,6 +646,23 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamGroups a, flo
 
 using namespace pulse;
 
+// the normaliser's wide-row kernel with as many column groups per thread as the row needs (1 / 2 / 3 groups: 62 - 70 / ~100 / 141 - 146 VGPRs)
+template <int OUT>
+static void launch_rms_vec4(int num_blocks, hipStream_t st, const float* x, long long x_stride, const long long* row_idx, int rows, int cols,
+                            const double* mean, const double* var, float eps, float clip, int mode, float* y, long long y_stride, int y_cols,
+                            double* partials, unsigned short* planes, long long plane_stride, long long planes_ld, float* raw = nullptr,
+                            long long raw_stride = 0) {
+    if (y_cols <= 1024)
+        hipLaunchKernelGGL((rms_normalize_vec4_kernel<OUT, 1>), dim3(num_blocks), dim3(512), 0, st, x, x_stride, row_idx, rows, cols, mean, var, eps, clip, mode,
+                           y, y_stride, y_cols, partials, planes, plane_stride, planes_ld, raw, raw_stride);
+    else if (y_cols <= 2048)
+        hipLaunchKernelGGL((rms_normalize_vec4_kernel<OUT, 2>), dim3(num_blocks), dim3(512), 0, st, x, x_stride, row_idx, rows, cols, mean, var, eps, clip, mode,
+                           y, y_stride, y_cols, partials, planes, plane_stride, planes_ld, raw, raw_stride);
+    else
+        hipLaunchKernelGGL((rms_normalize_vec4_kernel<OUT, 3>), dim3(num_blocks), dim3(512), 0, st, x, x_stride, row_idx, rows, cols, mean, var, eps, clip, mode,
+                           y, y_stride, y_cols, partials, planes, plane_stride, planes_ld, raw, raw_stride);
+}
+
 extern "C" {
 
 int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx, int32_t rows, int32_t cols, const double* mean,
@@ -661,14 +678,9 @@ int pulse_rms_normalize(const float* x, int64_t x_stride, const int64_t* row_idx
     const bool vec_ok = cols >= 64 && cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (y_stride % 4) == 0 && (y_cols % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                         x_stride >= ((cols + 3) & ~3);
-    if (vec_ok && y_cols <= 1024)
-        hipLaunchKernelGGL((rms_normalize_vec4_kernel<0, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials,
-                           (unsigned short*)nullptr, 0LL, 0LL);
-    else if (vec_ok)
-        hipLaunchKernelGGL(rms_normalize_vec4_kernel<0>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials,
-                           (unsigned short*)nullptr, 0LL, 0LL);
+    if (vec_ok)
+        launch_rms_vec4<0>(num_blocks, as_stream(s), x, (long long)x_stride, (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y,
+                           (long long)y_stride, y_cols, moment_partials, nullptr, 0LL, 0LL);
     else if (cols >= 64)
         hipLaunchKernelGGL(rms_normalize_wide_kernel, dim3(num_blocks), dim3(256), 0, as_stream(s), x, (long long)x_stride,
                            (const long long*)row_idx, rows, cols, mean, var, eps, clip, mode, y, (long long)y_stride, y_cols, moment_partials);
@@ -691,14 +703,8 @@ int pulse_rms_normalize_copy(const float* x, int64_t x_stride, const int64_t* ro
                   "pulse_rms_normalize_copy: needs the wide-row form (64 <= cols, y_cols <= %d, 16-byte aligned rows)", 256 * 4 * kRmsVecGroups);
     PULSE_REQUIRE((raw_stride % 4) == 0 && raw_stride >= ((cols + 3) & ~3) && (reinterpret_cast<uintptr_t>(raw_out) & 15) == 0,
                   "pulse_rms_normalize_copy: raw_out rows must be 16-byte aligned and hold cols rounded up to 4 floats");
-    if (y_cols <= 1024)
-        hipLaunchKernelGGL((rms_normalize_vec4_kernel<0, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
-                           (unsigned short*)nullptr, 0LL, 0LL, raw_out, (long long)raw_stride);
-    else
-        hipLaunchKernelGGL(rms_normalize_vec4_kernel<0>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
-                           (unsigned short*)nullptr, 0LL, 0LL, raw_out, (long long)raw_stride);
+    launch_rms_vec4<0>(num_blocks, as_stream(s), x, (long long)x_stride, (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y,
+                       (long long)y_stride, y_cols, moment_partials, nullptr, 0LL, 0LL, raw_out, (long long)raw_stride);
     return check_launch("pulse_rms_normalize_copy");
 }
 
@@ -717,14 +723,8 @@ int pulse_rms_normalize_planes(const float* x, int64_t x_stride, const int64_t* 
     PULSE_REQUIRE((y_cols % 32) == 0 && planes_ld >= y_cols && (planes_ld % 8) == 0 && (plane_stride % 8) == 0 && plane_stride >= (int64_t)rows * planes_ld &&
                   (reinterpret_cast<uintptr_t>(planes) & 15) == 0,
                   "pulse_rms_normalize_planes: y_cols must be a multiple of 32 (zero-padded k extent), planes rows 16-byte aligned and covering it");
-    if (y_cols <= 1024)
-        hipLaunchKernelGGL((rms_normalize_vec4_kernel<1, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
-                           reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
-    else
-        hipLaunchKernelGGL(rms_normalize_vec4_kernel<1>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y, (long long)y_stride, y_cols, moment_partials,
-                           reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
+    launch_rms_vec4<1>(num_blocks, as_stream(s), x, (long long)x_stride, (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, y,
+                       (long long)y_stride, y_cols, moment_partials, reinterpret_cast<unsigned short*>(planes), (long long)plane_stride, (long long)planes_ld);
     return check_launch("pulse_rms_normalize_planes");
 }
 
@@ -739,14 +739,8 @@ int pulse_rms_normalize_b16(const float* x, int64_t x_stride, const int64_t* row
     PULSE_REQUIRE(cols >= 64 && y_cols <= 256 * 4 * kRmsVecGroups && (x_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride >= ((cols + 3) & ~3),
                   "pulse_rms_normalize_b16: needs the wide-row form (64 <= cols, y_cols <= %d, 16-byte aligned input rows)", 256 * 4 * kRmsVecGroups);
     PULSE_REQUIRE((y_cols % 4) == 0 && (y_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(y16) & 7) == 0, "pulse_rms_normalize_b16: output rows must be 8-byte aligned, y_cols a multiple of 4");
-    if (y_cols <= 1024)
-        hipLaunchKernelGGL((rms_normalize_vec4_kernel<2, 1>), dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, (float*)nullptr, 0LL, y_cols, moment_partials,
-                           reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
-    else
-        hipLaunchKernelGGL(rms_normalize_vec4_kernel<2>, dim3(num_blocks), dim3(512), 0, as_stream(s), x, (long long)x_stride,
-                           (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, (float*)nullptr, 0LL, y_cols, moment_partials,
-                           reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
+    launch_rms_vec4<2>(num_blocks, as_stream(s), x, (long long)x_stride, (const long long*)row_idx, rows, cols, mean, var, eps, clip, 0, nullptr, 0LL,
+                       y_cols, moment_partials, reinterpret_cast<unsigned short*>(y16), 0LL, (long long)y_stride);
     return check_launch("pulse_rms_normalize_b16");
 }
 

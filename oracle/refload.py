@@ -270,6 +270,26 @@ def task_functions():
     return out
 
 
+def task_reward_methods():
+    """HumanoidSpeed._compute_reward (humanoid_speed.py:198-240) and HumanoidStrike._compute_reward (humanoid_strike.py:174-199) extracted by
+    name, with their jit functions in scope: the power_reward / power_usage_reward terms are written in the method bodies, not in the jit
+    functions."""
+    if "task_rew" in _cache:
+        return _cache["task_rew"]
+    tasks = os.path.join(REFERENCE_ROOT, "phc", "env", "tasks")
+    tf = task_functions()
+    out = {}
+    for fname, cls in (("humanoid_speed.py", "HumanoidSpeed"), ("humanoid_strike.py", "HumanoidStrike")):
+        ns = _namespace()
+        ns.update({k: tf[k] for k in ("compute_speed_reward", "compute_strike_reward")})
+        ns["flags"] = types.SimpleNamespace(test=False)
+        for name, text in _extract(os.path.join(tasks, fname), ["_compute_reward"], methods_of=cls).items():
+            exec(compile(text, f"<reference:{cls}.{name}>", "exec"), ns)
+            out[cls] = ns[name]
+    _cache["task_rew"] = out
+    return out
+
+
 def terrain_functions():
     """HumanoidTraj / HumanoidPedestrianTerrain (README: the terrain-traversal PULSE command): the TorchScript functions
     compute_location_observations (with the upright flag), compute_location_reward(_fuzzy), quat_apply_yaw and the terrain variant of

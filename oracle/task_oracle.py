@@ -52,6 +52,27 @@ def speed_reward(root_pos, prev_root_pos, root_rot, tar_speed, dt):
     return torch.exp(-0.25 * (tar_vel_err * tar_vel_err + 0.1 * tangent * tangent))
 
 
+def power_usage_reward(dof_force, dof_vel, power_acc, progress_buf, left_idx, right_idx, coef):
+    """The power_usage_reward block of HumanoidSpeed._compute_reward (humanoid_speed.py:225-238; left_indexes / right_indexes) and
+    HumanoidStrike._compute_reward (humanoid_strike.py:186-198; left_lower_indexes / right_lower_indexes): accumulates the per-side
+    |torque x velocity| into ``power_acc`` (N, 2) IN PLACE and returns the reward term (N,)."""
+    power_all = torch.abs(torch.multiply(dof_force, dof_vel)).reshape(-1, 23, 3)
+    n = power_all.shape[0]
+    power_acc[:, 0] += power_all[:, left_idx].reshape(n, -1).sum(dim=-1)
+    power_acc[:, 1] += power_all[:, right_idx].reshape(n, -1).sum(dim=-1)
+    pur = power_acc / (progress_buf + 1)[:, None]
+    pur = -coef * (pur[:, 0] - pur[:, 1]).abs()
+    pur[progress_buf <= 3] = 0
+    return pur
+
+
+def side_dof_indexes(dof_names, lower_only):
+    """humanoid.py:422-426: left_indexes / right_indexes (lower_only: the *_lower_indexes: hips, knees, ankles, toes)."""
+    lower = ("Hip", "Knee", "Ankle", "Toe")
+    pick = lambda side: [i for i, nm in enumerate(dof_names) if nm.startswith(side) and (not lower_only or nm[2:] in lower)]
+    return pick("L"), pick("R")
+
+
 def location_observations(root_states, tar_pos):
     return R.qrot(R.heading_q_inv(root_states[:, 3:7]), tar_pos - root_states[:, 0:3])
 

@@ -44,6 +44,7 @@ HONOURED = {
     "tarDistMax", "tarHeightMin", "tarHeightMax", "reachBodyName", "strikeBodyNames", "terminationHeight", "contact_bodies",
     "trajSampleTimestep", "speedMin", "speedMax", "accelMax", "sharpTurnProb", "sensor_extent", "sensor_res", "fuzzy_target",
     "terrain", "terrain_obs", "terrain_obs_type", "terrain_obs_root", "use_center_height",
+    "power_usage_reward", "power_usage_coefficient",      # read by the speed / strike tasks only (humanoid_speed.py:43-53, humanoid_strike.py:37-40)
     # keys of THIS package (no reference counterpart): seeds of the synthetic stand-ins, stand-in selection
     "motion_clock_seed", "obs_noise_seed", "occl_seed", "shape_seed", "task_seed", "getup_seed", "physics", "contactBodies", "tarDistMin", "nearDist", "nearProb",
 }
@@ -67,7 +68,6 @@ INERT = {
     "num_prim": _TEACH, "training_prim": _TEACH, "actors_to_load": _TEACH, "has_lateral": _TEACH,
     "distill_model_config": "structure of the frozen PULSE networks: HumanoidZ.initialize_z_models takes the checkpoint and network params as arguments",
     "hybridInitProb": "only read when stateInit is Hybrid (humanoid_amp.py:490-505), which raises here",
-    "power_usage_coefficient": "only read when power_usage_reward is on, which raises here",
     "dict_size": "VQ dictionary size: only read for z_type vq_vae variants, which raise here",
     "embedding_partion": "VQ partition count: only read for z_type vq_vae variants, which raise here",
     "vae_prior_fixed_logvar": "only read with use_vae_fixed_prior, which raises here",
@@ -84,7 +84,6 @@ UNBUILT = {
     "enableHistObs": ((False,), "humanoid_amp.py:320, 509-517"),
     "is_discrete": ((False,), "base_task.py:90; amp_agent.py:42-44 (discrete action heads)"),
     "control_mode": (("isaac_pd",), "humanoid.py:1250-1290 (torques computed in Python for control_mode pd)"),
-    "power_usage_reward": ((False,), "humanoid_speed.py:225-238, humanoid_strike.py:186-198 (left / right power balance)"),
     "divide_group": ((False,), "humanoid_pedestrian_terrain.py:265-289, 431-468, 744-766 (crowd observations)"),
     "group_obs": ((False,), "humanoid_pedestrian_terrain.py:431-437, 744-766 (crowd observations)"),
     "disable_group_obs": ((False,), "humanoid_pedestrian_terrain.py:749"),

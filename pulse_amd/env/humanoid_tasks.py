@@ -44,6 +44,17 @@ class HumanoidTask:
         self.power_reward = bool(env.get("power_reward", False))
         self.power_coefficient = float(env.get("power_coefficient", 0.0005))
         self._dof_size = syn.NUM_DOF
+        # power_usage_reward (humanoid_speed.py:43-53, 225-238; humanoid_strike.py:37-40, 186-198): a penalty on the difference between the
+        # accumulated |torque x velocity| of the left and the right joints.  Only those two task classes read the key.
+        self.power_usage_reward = bool(env.get("power_usage_reward", False)) and self.TASK in ("speed", "strike")
+        self.power_usage_coefficient = float(env.get("power_usage_coefficient", 0.0025))
+        if self.power_usage_reward:
+            dof_names = syn.SMPL_BODY_NAMES[1:]                                        # humanoid.py: _dof_names = body names without the root
+            lower = ("Hip", "Knee", "Ankle", "Toe")                                    # the strike task balances the legs only (left_lower_indexes, humanoid.py:425-426)
+            pick = lambda side: [i for i, nm in enumerate(dof_names) if nm.startswith(side) and (self.TASK == "speed" or nm[2:] in lower)]
+            self._left_idx = torch.tensor(pick("L"), dtype=torch.int64, device=self.device)
+            self._right_idx = torch.tensor(pick("R"), dtype=torch.int64, device=self.device)
+            self.power_acc = torch.zeros(self.num_envs, 2, device=self.device)
         lib = ops._lib.load()
         self._self_obs_size = lib.pulse_self_obs_width(self.num_bodies, int(self._root_height_obs))
         self._task_obs_size = self._task_obs_width(env) if self._enable_task_obs else 0
@@ -144,9 +155,26 @@ class HumanoidTask:
         self.progress_buf += 1
         # reward -> reset (one launch), then the observation row for the next step (humanoid.py:1322-1325)
         self._task_step(TASK_REWARD | TASK_RESET)
+        raw = self.reward_raw
+        if self.power_usage_reward:
+            raw = self._add_power_usage_reward(raw)
         self._compute_observations()
         self.extras["terminate"] = self._terminate_buf
-        self.extras["reward_raw"] = self.reward_raw
+        self.extras["reward_raw"] = raw
+
+    def _add_power_usage_reward(self, raw):
+        """humanoid_speed.py:225-238 / humanoid_strike.py:186-198, statement for statement on the kernel's reward (torch ops, as in the
+        reference: the option is off in every shipped config).  The speed task appends the term to reward_raw, the strike task does not."""
+        power_all = torch.abs(torch.multiply(self.sim.dof_force, self.sim.dof_vel)).reshape(-1, self._dof_size // 3, 3)
+        left_power = power_all[:, self._left_idx].reshape(self.num_envs, -1).sum(dim=-1)
+        right_power = power_all[:, self._right_idx].reshape(self.num_envs, -1).sum(dim=-1)
+        self.power_acc[:, 0] += left_power
+        self.power_acc[:, 1] += right_power
+        pur = self.power_acc / (self.progress_buf + 1)[:, None]
+        pur = -self.power_usage_coefficient * (pur[:, 0] - pur[:, 1]).abs()
+        pur = torch.where(self.progress_buf <= 3, torch.zeros_like(pur), pur)           # (pur[progress <= 3] = 0 without a host read)
+        self.rew_buf += pur
+        return torch.cat([raw, pur[:, None]], dim=-1) if self.TASK == "speed" else raw
 
     def reset(self, env_ids=None):
         if env_ids is None:
@@ -169,6 +197,8 @@ class HumanoidTask:
         self.progress_buf.mul_(keep)
         self.reset_buf.mul_(keep)
         self._terminate_buf.mul_(keep)
+        if self.power_usage_reward and self.TASK == "speed":
+            self.power_acc.masked_fill_(mask[:, None], 0.0)     # HumanoidSpeed._reset_ref_state_init (humanoid_speed.py:247-249); the strike task never clears it
         self._reset_task(mask)
         self._compute_observations(env_mask=mask)
 

@@ -243,3 +243,48 @@ def test_small_step_options_match_reference_bodies():
     got = E.res_action_pd_targets(t2.ref_dof_pos, t2._pd_action_scale, act, t2._dof_pos)
     assert torch.equal(want, got)
     assert (got == t2._dof_pos + torch.pi / 2).any() or (got == t2._dof_pos - torch.pi / 2).any()      # the clamp is exercised
+
+
+@pytest.mark.parametrize("cls", ["HumanoidSpeed", "HumanoidStrike"])
+def test_power_usage_reward_matches_reference_bodies(cls):
+    """[r6] power_usage_reward: the block lives in the METHOD bodies of HumanoidSpeed / HumanoidStrike._compute_reward (humanoid_speed.py:225-238,
+    humanoid_strike.py:186-198).  The bodies are executed on a stub over several steps (the accumulator carries over) and compared with
+    oracle.task_oracle.power_usage_reward on top of the pinned jit rewards: reward, reward_raw layout and the accumulator, bit for bit."""
+    import types
+    from oracle import task_oracle as TO
+    from pulse_amd import synthetic as syn
+    body = refload.task_reward_methods()[cls]
+    g = torch.Generator().manual_seed(5)
+    n = 37
+    dof_names = syn.SMPL_BODY_NAMES[1:]
+    left, right = TO.side_dof_indexes(dof_names, lower_only=False)
+    left_lo, right_lo = TO.side_dof_indexes(dof_names, lower_only=True)
+    assert len(left) == len(right) == 9 and len(left_lo) == len(right_lo) == 4          # L_/R_ Hip Knee Ankle Toe Thorax Shoulder Elbow Wrist Hand
+    st = types.SimpleNamespace(num_envs=n, dt=1 / 30, power_reward=cls == "HumanoidSpeed", power_usage_reward=True, power_coefficient=0.0005,
+                               power_usage_coefficient=0.0025, left_indexes=left, right_indexes=right, left_lower_indexes=left_lo,
+                               right_lower_indexes=right_lo, power_acc=torch.zeros(n, 2), rew_buf=torch.zeros(n), _near_dist=1.4,
+                               _strike_body_ids=torch.tensor([23]))
+    acc = torch.zeros(n, 2)
+    for step in range(6):
+        root = torch.randn(n, 13, generator=g)
+        root[:, 3:7] = torch.nn.functional.normalize(root[:, 3:7], dim=-1)
+        st._humanoid_root_states, st._prev_root_pos = root, root[:, 0:3] - 0.03 * torch.randn(n, 3, generator=g)
+        st._tar_speed = torch.rand(n, generator=g) * 3
+        st._target_states = torch.randn(n, 13, generator=g)
+        st._target_states[:, 3:7] = torch.nn.functional.normalize(st._target_states[:, 3:7], dim=-1)
+        st._rigid_body_vel = torch.randn(n, 24, 3, generator=g)
+        st.dof_force_tensor, st._dof_vel = torch.randn(n, 69, generator=g) * 30, torch.randn(n, 69, generator=g)
+        st.progress_buf = torch.randint(0, 9, (n,), generator=g)
+        body(st, None)
+        if cls == "HumanoidSpeed":
+            base = TO.speed_reward(root[:, 0:3], st._prev_root_pos, root[:, 3:7], st._tar_speed, st.dt)
+            pw = -0.0005 * (st.dof_force_tensor * st._dof_vel).abs().sum(-1)
+            pw[st.progress_buf <= 3] = 0
+            pur = TO.power_usage_reward(st.dof_force_tensor, st._dof_vel, acc, st.progress_buf, left, right, 0.0025)
+            assert torch.equal(st.rew_buf, base + pw + pur)
+            assert torch.equal(st.reward_raw, torch.stack([base, pw, pur], dim=-1))
+        else:
+            base = TO.strike_reward(st._target_states[:, 0:3], st._target_states[:, 3:7], root, st._prev_root_pos, st._rigid_body_vel[:, 23], st.dt, 1.4)
+            pur = TO.power_usage_reward(st.dof_force_tensor, st._dof_vel, acc, st.progress_buf, left_lo, right_lo, 0.0025)
+            assert torch.equal(st.rew_buf, base + pur)
+        assert torch.equal(st.power_acc, acc) and (pur != 0).any() and (pur[st.progress_buf <= 3] == 0).all()

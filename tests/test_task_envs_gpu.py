@@ -116,3 +116,47 @@ def test_speed_z_policy_trains_end_to_end(dev):
     assert all(torch.isfinite(torch.as_tensor(x)).all() for x in info["actor_loss"]) and not torch.equal(before, agent.model.flat)
     eb = agent.experience_buffer
     assert eb.tensor_dict["actions"].shape[-1] == 32 and torch.isfinite(eb.tensor_dict["rewards"]).all()
+
+
+@pytest.mark.parametrize("name", ["HumanoidSpeed", "HumanoidStrike"])
+def test_power_usage_reward_steps_match_oracle(dev, name):
+    """[r6] power_usage_reward (humanoid_speed.py:225-238, humanoid_strike.py:186-198): the left / right power-balance term on top of the
+    kernel's reward, the accumulator carried across steps (cleared on reset by the speed task only), reward_raw's extra column (speed only)."""
+    n, frames = 96, 12
+    sim = HT.SyntheticTaskSim(n, frames, dev, seed=8)
+    speed = name == "HumanoidSpeed"
+    task = HT.TASKS[name]({"env": {"power_reward": speed, "power_usage_reward": True, "power_usage_coefficient": 0.004, "episode_length": 7}}, sim, device=dev)
+    task.reset()
+    left, right = TO.side_dof_indexes(syn.SMPL_BODY_NAMES[1:], lower_only=not speed)
+    acc = torch.zeros(n, 2)
+    saw_reset = 0
+    for step in range(12):
+        prev_root = sim.rigid_body_state[:, 0, 0:3].clone().cpu()
+        prog = task.progress_buf.clone().cpu() + 1
+        task.step(torch.zeros(n, 69, device=dev))
+        rb = sim.rigid_body_state.cpu()
+        root = rb[:, 0]
+        if speed:
+            rew = TO.speed_reward(root[:, 0:3], prev_root, root[:, 3:7], task._tar_speed.cpu(), task.dt)
+            pw = -0.0005 * (sim.dof_force * sim.dof_vel).abs().sum(-1).cpu()
+            pw[prog <= 3] = 0
+            rew = rew + pw
+        else:
+            ts = task._target_states.cpu()
+            rew = TO.strike_reward(ts[:, 0:3], ts[:, 3:7], root, prev_root, rb[:, 23, 7:10], task.dt, 1.4)
+        pur = TO.power_usage_reward(sim.dof_force.cpu(), sim.dof_vel.cpu(), acc, prog, left, right, 0.004)
+        _cmp(task.rew_buf, rew + pur)
+        _cmp(task.power_acc, acc, atol=1e-3)
+        raw = task.extras["reward_raw"]
+        assert raw.shape[1] == (3 if speed else 1)
+        if speed:
+            _cmp(raw[:, 2], pur)
+        done = task.reset_buf.bool()
+        saw_reset += int(done.sum())
+        task.reset_masked(done)
+        if speed:
+            acc[done.cpu()] = 0
+    assert saw_reset > 0 and (pur != 0).any()
+    # the other task classes do not read the key (the reference's HumanoidReach has no such block): accepted and without effect
+    reach = HT.HumanoidReach({"env": {"power_usage_reward": True}}, HT.SyntheticTaskSim(8, 4, dev, seed=1), device=dev)
+    assert reach.power_usage_reward is False

@@ -572,7 +572,8 @@ int pulse_gemm_f32(const pulse_gemm_desc* desc, pulse_stream_t s);
  * also steered by PULSE_X3_WIDE = 0 / 1 / 2 in the environment; 1 = 128 x 128 only; 2 = 256 x 256 whenever M, N > 128; BIT-IDENTICAL matrix outputs
  * either way, the weight-gradient form's row sums agree to rounding), option 5 = 1: never split a narrow column tail off a 256 x 256 launch (A/B;
  * same bits), option 6 = 1: never the skinny-N kernel (N <= 96 over a long M; same bits), option 7: timing variants of the skinny-N kernel (tools/; results are garbage),
- * option 8 = 1: pulse_ppo_loss in its plain per-sample form instead of the hoisted one (same bits; keys 0 .. 15 are accepted).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
+ * option 8 = 1: pulse_ppo_loss in its plain per-sample form instead of the hoisted one (same bits), option 9 = 1: every epilogue row of pulse_gemm_x3p
+ * through the general form instead of the round-once rows of the ReLU forward / ReLU-gradient launches (same bits; keys 0 .. 15 are accepted).  With a debug buffer set (8 int64 per workgroup, device memory) every workgroup of the following launches stamps
  * s_memtime / the 100 MHz wall clock at its start, after the main loop and at its end, plus its HW_ID / XCC_ID.  The 256 x 256 bf16-storage
  * kernel of pulse_gemm_x3p honours the same buffer with wall-clock stamps only: [0] start, [1] first stage landed, [2] main loop done,
  * [3] epilogue stores issued, [4] stores acknowledged, [5] XCC_ID, [6] / [7] transpose image written / stores issued of the last epilogue

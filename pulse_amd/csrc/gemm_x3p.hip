@@ -65,6 +65,7 @@ struct XpArgs {
     float* colsum; long long sColsum; int ldcs;      // optional: per-row-tile column sums of the OUTPUT (colsum[bz * sColsum + tm * ldcs + n])
     long long* dbg;                                  // optional per-workgroup wall-clock stamps (tools/gemm_b16_phases.py; pulse_gemm_set_debug_buffer)
     unsigned char* mask8; int ldm8; long long sM8;   // ReLU bit mask, one byte per (row, 8 columns): written by EPI 0 + relu, read by EPI 1 when there is no aux
+    int general_rows;                                // gemm option 9 (tests): every epilogue row through the general form
 };
 
 template <int WMW>
@@ -196,8 +197,10 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
                         }
                     }
                 }
+                if (g.colsum) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) cs[k] += o[k];
+                    for (int k = 0; k < 8; ++k) cs[k] += o[k];
+                }
                 if (C) {
                     float* pc = C + (long long)row * g.ldc + col;
                     if (full) {
@@ -224,6 +227,42 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
                     }
                 }
             };
+            // [r6] The two hot epilogues of the bf16-storage path -- ReLU forward (sign byte + bf16 row) and ReLU gradient from the sign byte -- on
+            // whole 8-column groups with the bf16 matrix as the only output.  ReLU and the mask select either keep a value or replace it by +0, so they
+            // commute with the rounding: the row is rounded ONCE, by the pack that stores it, and the sign byte / the column sums are read off the
+            // packed words.  (The general row rounds, converts back, acts, tests eight column bounds and packs again: ~95 VALU per row -- at 16 rows per
+            // thread and two waves per SIMD that is the 8 us the phases tool shows for a 256 x 256 tile: the epilogue was VALU-bound, not store-bound.)
+            // Same bits as the general row: tests/test_bf16_gpu.py::test_b16_fast_epilogue_rows_equal_the_general_row.
+            const bool fast = NPL == 1 && g.splitk == 1 && Cp != nullptr && C == nullptr && C2 == nullptr && full && g.general_rows == 0 &&
+                              ((g.epi == 0 && g.act <= 1) || use_mask);
+            auto fast_row = [&](int rl, const f32x4 v0, const f32x4 v1) {
+                const int row = m0 + rl;
+                float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (g.epi == 0) {
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = fmaxf(o[k], 0.f);
+                    }
+                } else {
+                    const unsigned bits = mask8[(long long)row * g.ldm8 + (col >> 3)];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = ((bits >> k) & 1u) ? o[k] : 0.f;
+                }
+                u32x4 q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = xp_pack_rn(o[2 * k], o[2 * k + 1]);
+                if (g.epi == 0 && g.act == 1 && mask8) {                 // rounded value > 0  <=>  its bf16 magnitude bits are not all zero (after ReLU nothing is negative)
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bits |= ((q[k] & 0x7fffu) ? 1u : 0u) << (2 * k) | ((q[k] & 0x7fff0000u) ? 1u : 0u) << (2 * k + 1);
+                    mask8[(long long)row * g.ldm8 + (col >> 3)] = (unsigned char)bits;
+                }
+                if (g.colsum) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { cs[2 * k] += xp_bitsf(q[k] << 16); cs[2 * k + 1] += xp_bitsf(q[k] & 0xffff0000u); }
+                }
+                *reinterpret_cast<u32x4*>(Cp + (long long)row * g.ldcp + col) = q;
+            };
             constexpr int ITER = BM / RPI;
             if (m0 + BM <= g.M) {
                 // full tile in M: every image read of the thread's ITER rows is issued before the first row is processed (a rolled loop was one
@@ -235,13 +274,20 @@ __device__ __forceinline__ void xp_epilogue(const XpArgs& g, f32x16 (&acc)[2][2]
                     va[it] = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8);
                     vb[it] = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4);
                 }
+                if (fast) {
 #pragma unroll
-                for (int it = 0; it < ITER; ++it) do_row((tid >> 4) + it * RPI, va[it], vb[it]);
+                    for (int it = 0; it < ITER; ++it) fast_row((tid >> 4) + it * RPI, va[it], vb[it]);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) do_row((tid >> 4) + it * RPI, va[it], vb[it]);
+                }
             } else {
 #pragma unroll 2
                 for (int rl = tid >> 4; rl < BM; rl += RPI) {
                     if (m0 + rl >= g.M) break;
-                    do_row(rl, *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8), *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4));
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8), v1 = *reinterpret_cast<const f32x4*>(sC + rl * G::CPF + c8 + 4);
+                    if (fast) fast_row(rl, v0, v1);
+                    else do_row(rl, v0, v1);
                 }
             }
         }
@@ -1091,6 +1137,7 @@ int pulse_gemm_x3p(const pulse_gemm_x3p_desc* d, pulse_stream_t s) {
     g.rowsum = d->rowsum; g.sRowsum = d->stride_rowsum;
     g.colsum = d->out_colsum; g.sColsum = d->stride_out_colsum; g.ldcs = d->ld_out_colsum;
     g.mask8 = mask8_on ? d->relu_mask8 : nullptr; g.ldm8 = d->ld_mask8; g.sM8 = d->stride_mask8;
+    g.general_rows = gemm_option(9);
     g.dbg = gemm_debug_buffer();
     PULSE_REQUIRE(!d->out_colsum || (d->split_k == 1 && d->ld_out_colsum >= d->N), "pulse_gemm_x3p: out_colsum needs split_k == 1 and a pitch covering N");
     const bool big = xp_big_tiles(d->M, d->N, d->batch, d->split_k);

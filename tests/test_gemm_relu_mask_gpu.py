@@ -164,3 +164,49 @@ def test_mixed_precision_network_pass_is_bit_identical_with_and_without_byte_mas
                  ws["dheads16"])
         grads.append(net.backward(ws, m).clone())
     assert torch.equal(grads[0], grads[1]) and grads[0].abs().sum() > 0
+
+
+@pytest.mark.parametrize("tile", [1, 2])                       # gemm option 3: never / always the 256 x 256 bf16-storage tile
+@pytest.mark.parametrize("m,n,k,bias", [(512, 256, 64, True), (1000, 520, 96, True), (1280, 1024, 128, False), (300, 136, 64, True), (2048, 2048, 64, True)])
+def test_b16_fast_epilogue_rows_equal_the_general_row(dev, tile, m, n, k, bias):
+    """[r6] The ReLU-forward and ReLU-gradient launches of the bf16-storage path round a row once (ReLU / the mask select commute with the
+    rounding) and read the sign byte and the column sums off the packed words; gemm option 9 sends every row through the general form.
+    Outputs, sign bytes and column sums must agree bit for bit -- including rows with NaN, -0, values that round to zero and ragged edges
+    (N = 520 / 136: the last 8-column group of a row is partial and takes the general row inside the same launch)."""
+    g = torch.Generator().manual_seed(m + n)
+    to16 = lambda t: (t.contiguous().view(torch.int32) + 0x8000 >> 16).to(torch.int16)
+    x = rnd(g, m, k)
+    x[3] = 0.0                                                  # zero rows: outputs are the bias alone (incl. exact zeros where it is zero)
+    x[5, 0] = float("nan")
+    w = rnd(g, n, k) / math.sqrt(k)
+    b = rnd(g, n) * 0.3
+    b[::7] = 0.0
+    b[1::7] = -0.0
+    b[2::7] = 1e-41                                             # rounds to zero in bf16
+    x16, w16 = to16(x).to(dev), to16(w).to(dev)
+    npad = (n + 7) // 8 * 8
+    res = []
+    for general in (0, 1):
+        K.gemm_set_option(9, general)
+        K.gemm_set_option(3, tile)
+        try:
+            h16 = torch.full((m, npad), 0x7fc0, dtype=torch.int16, device=dev)
+            mask = K.alloc_relu_mask8(m, n, dev)
+            mask.fill_(255)
+            cs = torch.full((K.gemm_x3p_row_tiles(m, n, 1), npad), 9.0, device=dev)
+            K.gemm_x3p(x16, w16, planes=1, M=m, N=n, K=k, Cp=h16, activation=ACT_RELU, relu_mask8=mask, bias=b.to(dev) if bias else None, out_colsum=cs)
+            lin16 = torch.full((m, npad), 0x7fc0, dtype=torch.int16, device=dev)         # no activation: plain rounding
+            K.gemm_x3p(x16, w16, planes=1, M=m, N=n, K=k, Cp=lin16, bias=b.to(dev) if bias else None)
+            dy16 = to16(rnd(torch.Generator().manual_seed(9), m, 32)).to(dev)
+            w2 = to16(rnd(torch.Generator().manual_seed(10), 32, npad)).to(dev)
+            z = torch.full((m, npad), 0x7fc0, dtype=torch.int16, device=dev)
+            cs2 = torch.full_like(cs, 9.0)
+            K.gemm_x3p(dy16, w2, planes=1, M=m, N=n, K=32, b_layout=GEMM_OUT_CONTIG, Cp=z, epilogue=EPI_RELU_GRAD, relu_mask8=mask, out_colsum=cs2)
+        finally:
+            K.gemm_set_option(9, 0)
+            K.gemm_set_option(3, 0)
+        res.append((h16, mask, cs[:, :n], lin16, z, cs2[:, :n]))
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)
+    h = (res[0][0].to(torch.int32) << 16).view(torch.float32)[:, :n]
+    assert (h[3] == 0).any() and (res[0][4] != 0).any() and (not bias or (h[3] > 0).any())

@@ -254,6 +254,21 @@ __global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restri
             float4 a = a1;
             if (ns > 0) a = reinterpret_cast<const float4*>(base)[i];         // ns == 0: a region no launch of this pass wrote (zero gradient)
             int k = 1;
+            // [r6] sixteen slabs' loads in flight where a region has that many (the bias column-sum partials and the heads' wide split have 32 - 128
+            // rows: at four loads per round trip a thread walked up to 32 dependent round trips while the big regions' threads had long finished);
+            // the adds keep their order, so the association -- and every bit -- is unchanged
+            for (; k + 15 < ns; k += 16) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = reinterpret_cast<const float4*>(base + (k + u) * stride)[i];
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+                    a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+                    a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w;
+                    a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
+                }
+            }
             for (; k + 3 < ns; k += 4) {
                 const float4 v0 = reinterpret_cast<const float4*>(base + k * stride)[i];
                 const float4 v1 = reinterpret_cast<const float4*>(base + (k + 1) * stride)[i];
@@ -264,9 +279,23 @@ __global__ void __launch_bounds__(256) reduce_grads_kernel(const float* __restri
                 a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
                 a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
             }
-            for (; k < ns; ++k) {
-                const float4 v = reinterpret_cast<const float4*>(base + k * stride)[i];
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            // the last one to three slabs go onto chain 0 in order; their loads are issued together (uniform branches: ns belongs to the region)
+            const int rem = ns - k;
+            if (rem == 3) {
+                const float4 t0 = reinterpret_cast<const float4*>(base + k * stride)[i];
+                const float4 t1 = reinterpret_cast<const float4*>(base + (k + 1) * stride)[i];
+                const float4 t2 = reinterpret_cast<const float4*>(base + (k + 2) * stride)[i];
+                a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
+                a.x += t1.x; a.y += t1.y; a.z += t1.z; a.w += t1.w;
+                a.x += t2.x; a.y += t2.y; a.z += t2.z; a.w += t2.w;
+            } else if (rem == 2) {
+                const float4 t0 = reinterpret_cast<const float4*>(base + k * stride)[i];
+                const float4 t1 = reinterpret_cast<const float4*>(base + (k + 1) * stride)[i];
+                a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
+                a.x += t1.x; a.y += t1.y; a.z += t1.z; a.w += t1.w;
+            } else if (rem == 1) {
+                const float4 t0 = reinterpret_cast<const float4*>(base + k * stride)[i];
+                a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
             }
             a.x = (a.x + a1.x) + (a2.x + a3.x); a.y = (a.y + a1.y) + (a2.y + a3.y); a.z = (a.z + a1.z) + (a2.z + a3.z); a.w = (a.w + a1.w) + (a2.w + a3.w);
             a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;

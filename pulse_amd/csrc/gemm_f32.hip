@@ -1103,6 +1103,18 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
             float4 s = *reinterpret_cast<const float4*>(slabs + i);
             float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
             int k = 1;
+            for (; k + 15 < nslab; k += 16) {                  // [r6] sixteen slabs in flight, added in the same order (reduce_grads_kernel, b16_ops.hip)
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(slabs + (k + u) * slab_stride + i);
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+                    s1.x += v[u + 1].x; s1.y += v[u + 1].y; s1.z += v[u + 1].z; s1.w += v[u + 1].w;
+                    s2.x += v[u + 2].x; s2.y += v[u + 2].y; s2.z += v[u + 2].z; s2.w += v[u + 2].w;
+                    s3.x += v[u + 3].x; s3.y += v[u + 3].y; s3.z += v[u + 3].z; s3.w += v[u + 3].w;
+                }
+            }
             for (; k + 3 < nslab; k += 4) {
                 const float4 v0 = *reinterpret_cast<const float4*>(slabs + k * slab_stride + i);
                 const float4 v1 = *reinterpret_cast<const float4*>(slabs + (k + 1) * slab_stride + i);
@@ -1113,9 +1125,22 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
                 s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
                 s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
             }
-            for (; k < nslab; ++k) {
-                const float4 v = *reinterpret_cast<const float4*>(slabs + k * slab_stride + i);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            const int rem = nslab - k;                          // the last one to three slabs onto chain 0 in order, loads issued together
+            if (rem == 3) {
+                const float4 t0 = *reinterpret_cast<const float4*>(slabs + k * slab_stride + i);
+                const float4 t1 = *reinterpret_cast<const float4*>(slabs + (k + 1) * slab_stride + i);
+                const float4 t2 = *reinterpret_cast<const float4*>(slabs + (k + 2) * slab_stride + i);
+                s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+                s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+                s.x += t2.x; s.y += t2.y; s.z += t2.z; s.w += t2.w;
+            } else if (rem == 2) {
+                const float4 t0 = *reinterpret_cast<const float4*>(slabs + k * slab_stride + i);
+                const float4 t1 = *reinterpret_cast<const float4*>(slabs + (k + 1) * slab_stride + i);
+                s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+                s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+            } else if (rem == 1) {
+                const float4 t0 = *reinterpret_cast<const float4*>(slabs + k * slab_stride + i);
+                s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
             }
             s.x = (s.x + s1.x) + (s2.x + s3.x); s.y = (s.y + s1.y) + (s2.y + s3.y); s.z = (s.z + s1.z) + (s2.z + s3.z); s.w = (s.w + s1.w) + (s2.w + s3.w);
             s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;

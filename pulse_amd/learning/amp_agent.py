@@ -126,6 +126,13 @@ class AMPAgent(CommonAgent):
             raise NotImplementedError("normalize_amp_input: True / norm_disc_reward: False (the shipped settings)")
         self.disc = DiscNetwork(config["network"], self._amp_dim, device=self.ppo_device, split_k=int(config.get("split_k", 8)))
         self.disc.mixed_precision = self.mixed_precision
+        # The discriminator chain runs on its own stream beside the actor / critic chain (_side_stream).  Round-6 finding (tools/mask_contend_probe.py,
+        # DESIGN.md section 6): the fp32 x3 kernels' relu-grad epilogue that takes its derivative from the BIT MASK returns wrong values in one
+        # 16-lane quarter of a wave now and then while ANOTHER stream's GEMM waves share the SIMD (0 differences alone, or reading the fp32
+        # activations instead) -- the same class of hazard as round 3's packed-fp32 one.  A policy network that has a concurrent chain beside it
+        # therefore keeps the activation re-read; the bf16-storage path's byte masks and single-chain agents (cfg2) are not affected.
+        if self._side_stream() is not None and hasattr(self.model, "concurrent_chain"):
+            self.model.concurrent_chain = True
         self._amp_input_mean_std = RunningMeanStd((self._amp_dim,), device=self.ppo_device)
         self.disc_exp_avg = torch.zeros(self.disc.n_flat, device=self.ppo_device)
         self.disc_exp_avg_sq = torch.zeros(self.disc.n_flat, device=self.ppo_device)

@@ -30,8 +30,13 @@ from .. import kernels as K
 from .._lib import ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CONTIG
 
 
-# PULSE_RELU_BITMASK=0: the input-gradient launches re-read the fp32 activations (A/B switch; same bits either way)
+# PULSE_RELU_BITMASK=0: the bf16-storage path's relu-grad launches re-read the bf16 activations instead of the forward's sign bytes (A/B switch; same bits)
 RELU_BITMASK = os.environ.get("PULSE_RELU_BITMASK", "1") != "0"
+# PULSE_RELU_BITMASK_F32=1: the fp32 path's ReLU BIT masks (pulse_gemm_desc.relu_mask).  OFF by default since the last hours of round 6: bit-identical
+# and 1.3 % faster on cfg2 when the process has the GPU to itself, but the relu-grad epilogue that reads the mask returns wrong values now and then
+# (garbage in one 16-lane quarter of a wave) while ANOTHER stream's or process's GEMM waves share the SIMD -- tools/mask_contend_probe.py, DESIGN.md
+# section 6.  A training job must not depend on nobody else touching the GPU; opt in on an exclusive device.
+RELU_BITMASK_F32 = os.environ.get("PULSE_RELU_BITMASK_F32", "0") == "1"
 
 
 def _r4(x):
@@ -80,6 +85,7 @@ class A2CNetwork:
         self.l1_planar = os.environ.get("PULSE_L1_PLANAR", "0") == "1" and K.F32_MODE == "x3"
         self._w1p = None
         self.training = True
+        self.concurrent_chain = False     # True: another stream's GEMMs run beside this network's training pass (AMPAgent's discriminator chain): no fp32 bit masks (workspace)
         self.mixed_precision = False      # True: the TRAINING forward / backward run on the bf16 MFMA (amp_agent.py:671 autocast); inference stays fp32
         self.reset_parameters()
 
@@ -263,7 +269,7 @@ class A2CNetwork:
             else:
                 # ReLU nets: the training forward also records each hidden activation's sign bits (1 bit per element), and the input-gradient
                 # launches mask with those instead of re-reading the fp32 activation matrix (134 MB per layer-1-wide launch at cfg2)
-                if self.act == ACT_RELU and not self.mixed_precision and RELU_BITMASK:
+                if self.act == ACT_RELU and not self.mixed_precision and RELU_BITMASK_F32 and not self.concurrent_chain:
                     ws["hmask"] = [K.alloc_relu_mask(m, 2 * uu, dev) for uu in u]
                     ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, masks=True)
                 else:

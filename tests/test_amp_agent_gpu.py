@@ -129,3 +129,28 @@ def test_joint_grad_clip_covers_both_buffers(agent):
     ag._apply_gradients()
     want = np.sqrt(ag.model.n_flat * 0.01 ** 2 + ag.disc.n_flat * 0.02 ** 2)
     np.testing.assert_allclose(ag._grad_norm.item(), want, rtol=1e-4)
+
+
+def test_policy_network_beside_a_concurrent_chain_keeps_off_the_fp32_bit_masks(dev, monkeypatch):
+    """[r6] tools/mask_contend_probe.py: the fp32 x3 relu-grad epilogue that reads the ReLU bit mask returns wrong values now and then while another
+    stream's GEMM waves share the SIMD.  AMPAgent runs its discriminator chain on a side stream, so its policy network must not use the fp32 bit
+    masks; with the chain inline (PULSE_DISC_STREAM=0) and in single-chain agents it does."""
+    from pulse_amd import configs
+    from pulse_amd.learning import network as N
+    ag0, _ = configs.make_agent("cfg1", device=str(dev), seed=3, reference="motion_lib")
+    ag0.train_epoch()
+    assert "hmask" not in ag0.model.workspace(ag0.minibatch_size, train=True)          # the fp32 bit masks are opt-in (PULSE_RELU_BITMASK_F32=1)
+    monkeypatch.setattr(N, "RELU_BITMASK_F32", True)
+    ag, _ = configs.make_agent("cfg5_small", device=str(dev), seed=3)
+    assert ag._side_stream() is not None and ag.model.concurrent_chain
+    ag.train_epoch()
+    ws = ag.model.workspace(ag.minibatch_size, train=True)
+    assert "hmask" not in ws
+    monkeypatch.setenv("PULSE_DISC_STREAM", "0")
+    ag2, _ = configs.make_agent("cfg5_small", device=str(dev), seed=3)
+    assert ag2._side_stream() is None and not ag2.model.concurrent_chain
+    ag2.train_epoch()
+    assert "hmask" in ag2.model.workspace(ag2.minibatch_size, train=True)
+    ag3, _ = configs.make_agent("cfg1", device=str(dev), seed=3, reference="motion_lib")
+    ag3.train_epoch()
+    assert "hmask" in ag3.model.workspace(ag3.minibatch_size, train=True)

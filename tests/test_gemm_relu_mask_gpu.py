@@ -97,7 +97,7 @@ def test_network_training_pass_is_bit_identical_with_and_without_masks(dev, monk
     monkeypatch.setattr(K, "F32_MODE", "x3")
     grads = []
     for on in (True, False):
-        monkeypatch.setattr(N, "RELU_BITMASK", on)
+        monkeypatch.setattr(N, "RELU_BITMASK_F32", on)
         torch.manual_seed(5)
         net = N.A2CNetwork(configs.NETWORK_IM, actions_num=69, input_shape=(934,), device=dev)
         m = 1024

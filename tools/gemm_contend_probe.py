@@ -56,6 +56,15 @@ cases.append(case("x3 64x128 input gradient READING the bit mask", A=dyh, B=whd,
 dxa = torch.empty(1024, 1024, device=dev)
 cases.append(case("   the same launch reading the activations (aux)", A=dyh, B=whd, C=dxa, M=1024, N=512, K=69, lda=144, ldb=512, ldc=1024, b_layout=GEMM_OUT_CONTIG, batch=2,
                   stride_a=72, stride_b=69 * 512, stride_c=512, epilogue=EPI_RELU_GRAD, aux=h2m, ldaux=1024, stride_aux=512))
+# the same pair on the 256 x 256 tile (cfg2's layer-2 input gradient: 16384 x 1024 x 512, both nets; here 4096 rows)
+mkw = K.alloc_relu_mask(4096, 2048, dev)
+hw_ = torch.empty(4096, 2048, device=dev)
+cases.append(case("x3 256x256 forward writing the bit mask", A=x, B=w, C=hw_, M=4096, N=2048, K=934, lda=960, ldb=960, ldc=2048, bias=b, activation=ACT_RELU,
+                  relu_mask=mkw, ld_mask=mkw.stride(0)))
+K.launch_gemm(*cases[-1][1])
+dz2, w2b, dxw = rnd(4096, 1024), rnd(2 * 512, 1024) / 30, torch.empty(4096, 2048, device=dev)
+cases.append(case("x3 256x256 input gradient READING the bit mask", A=dz2, B=w2b, C=dxw, M=4096, N=1024, K=512, lda=1024, ldb=1024, ldc=2048, b_layout=GEMM_OUT_CONTIG,
+                  batch=2, stride_a=512, stride_b=512 * 1024, stride_c=1024, epilogue=EPI_RELU_GRAD, relu_mask=mkw, ld_mask=mkw.stride(0), stride_mask=256))
 for _, d, _ in cases:
     K.launch_gemm(*d)
 torch.cuda.synchronize()

@@ -154,6 +154,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
     if (fast && use_mask) {
 #pragma unroll
         for (int b = 0; b < WM; ++b) mw[b] = mask[mask_word(m0 + 64 * b + rl0, (n0 + c4) >> 2, g.ldmask)];
+        // [r6, last hours] The bits are expanded HERE into the registers the aux path would have loaded (+1 / -1 per element) and the store loop
+        // below is the aux path's.  The loop this replaces -- ``nb = mw >> 4 q; v.x = (nb & 1) ? v.x : 0`` after the barrier -- was bit-identical in
+        // every test and returned garbage in 12 - 48 elements of a row now and then as soon as another stream's or process's GEMMs ran beside the
+        // launch (tools/gemm_contend_probe.py: 5 412 wrong elements in 4 000 launches, 0 alone, 0 for the aux path); this form:
+        // 0 in 3 000, and the agent-level tests pass 10 / 10 beside a GEMM-hammering process with the masks forced on.
+#pragma unroll
+        for (int q = 0; q < 8 * WM; ++q) {
+            const unsigned nb = mw[q >> 3] >> (4 * (q & 7));
+            ax[q] = (f32x4){(nb & 1u) ? 1.f : -1.f, (nb & 2u) ? 1.f : -1.f, (nb & 4u) ? 1.f : -1.f, (nb & 8u) ? 1.f : -1.f};
+        }
     } else if (fast && g.epi != 0) {           // relu-grad / multiply-by-aux: the 16 aux loads fly while the accumulators go through LDS
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aux) + (long long)m0 * g.ldaux + n0, 0,
                                                                             0xffffffffu, RSRC_FLAGS);
@@ -192,15 +202,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[W
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
                 }
-            } else if (use_mask) {
-#pragma unroll
-                for (int q = 0; q < 8 * WM; ++q) {
-                    const unsigned nb = mw[q >> 3] >> (4 * (q & 7));
-                    f32x4 v = lds_read(ldsC + q * 8 * CP * 4);
-                    v.x = (nb & 1u) ? v.x : 0.f; v.y = (nb & 2u) ? v.y : 0.f; v.z = (nb & 4u) ? v.z : 0.f; v.w = (nb & 8u) ? v.w : 0.f;
-                    buf_store(v, rsC, voC, q * 8 * g.ldc * 4);
-                }
-            } else if (g.epi == 1) {
+            } else if (g.epi == 1) {                   // relu-grad: aux = the activations, or the +-1 expansion of the forward's bit mask (above)
 #pragma unroll
                 for (int q = 0; q < 8 * WM; ++q) {
                     const f32x4 a = ax[q];

@@ -32,11 +32,13 @@ from .._lib import ACT_RELU, ACT_SILU, EPI_RELU_GRAD, EPI_SILU_GRAD, GEMM_OUT_CO
 
 # PULSE_RELU_BITMASK=0: the bf16-storage path's relu-grad launches re-read the bf16 activations instead of the forward's sign bytes (A/B switch; same bits)
 RELU_BITMASK = os.environ.get("PULSE_RELU_BITMASK", "1") != "0"
-# PULSE_RELU_BITMASK_F32=1: the fp32 path's ReLU BIT masks (pulse_gemm_desc.relu_mask).  OFF by default since the last hours of round 6: bit-identical
-# and 1.3 % faster on cfg2 when the process has the GPU to itself, but the relu-grad epilogue that reads the mask returns wrong values now and then
-# (garbage in one 16-lane quarter of a wave) while ANOTHER stream's or process's GEMM waves share the SIMD -- tools/mask_contend_probe.py, DESIGN.md
-# section 6.  A training job must not depend on nobody else touching the GPU; opt in on an exclusive device.
-RELU_BITMASK_F32 = os.environ.get("PULSE_RELU_BITMASK_F32", "0") == "1"
+# PULSE_RELU_BITMASK_F32=0: the fp32 path's input-gradient launches re-read the activations instead of the forward's sign BITS (pulse_gemm_desc.relu_mask;
+# A/B switch, same bits).  History: the 128 x 128 / 64 x 128 kernel's store loop that consumed the bits returned garbage beside another
+# stream's / process's GEMM waves; that loop is gone (the bits are expanded into the aux path's registers), the probes and the stress runs are clean, and the
+# masks are on again -- except for a policy network with a concurrent chain beside it (A2CNetwork.concurrent_chain), which keeps the re-read ("2" forces them
+# there too: stress tests).
+RELU_BITMASK_F32 = os.environ.get("PULSE_RELU_BITMASK_F32", "1") in ("1", "2")
+RELU_BITMASK_F32_FORCE = os.environ.get("PULSE_RELU_BITMASK_F32", "0") == "2"      # (stress tests: also beside a concurrent chain)
 
 
 def _r4(x):
@@ -269,7 +271,7 @@ class A2CNetwork:
             else:
                 # ReLU nets: the training forward also records each hidden activation's sign bits (1 bit per element), and the input-gradient
                 # launches mask with those instead of re-reading the fp32 activation matrix (134 MB per layer-1-wide launch at cfg2)
-                if self.act == ACT_RELU and not self.mixed_precision and RELU_BITMASK_F32 and not self.concurrent_chain:
+                if self.act == ACT_RELU and not self.mixed_precision and RELU_BITMASK_F32 and (RELU_BITMASK_F32_FORCE or not self.concurrent_chain):
                     ws["hmask"] = [K.alloc_relu_mask(m, 2 * uu, dev) for uu in u]
                     ws["plan_fwd_train"] = self._plan_forward(ws, m, 0, 2, masks=True)
                 else:

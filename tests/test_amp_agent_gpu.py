@@ -137,10 +137,8 @@ def test_policy_network_beside_a_concurrent_chain_keeps_off_the_fp32_bit_masks(d
     masks; with the chain inline (PULSE_DISC_STREAM=0) and in single-chain agents it does."""
     from pulse_amd import configs
     from pulse_amd.learning import network as N
-    ag0, _ = configs.make_agent("cfg1", device=str(dev), seed=3, reference="motion_lib")
-    ag0.train_epoch()
-    assert "hmask" not in ag0.model.workspace(ag0.minibatch_size, train=True)          # the fp32 bit masks are opt-in (PULSE_RELU_BITMASK_F32=1)
     monkeypatch.setattr(N, "RELU_BITMASK_F32", True)
+    monkeypatch.setattr(N, "RELU_BITMASK_F32_FORCE", False)
     ag, _ = configs.make_agent("cfg5_small", device=str(dev), seed=3)
     assert ag._side_stream() is not None and ag.model.concurrent_chain
     ag.train_epoch()

@@ -65,8 +65,36 @@ K.launch_gemm(*cases[-1][1])
 dz2, w2b, dxw = rnd(4096, 1024), rnd(2 * 512, 1024) / 30, torch.empty(4096, 2048, device=dev)
 cases.append(case("x3 256x256 input gradient READING the bit mask", A=dz2, B=w2b, C=dxw, M=4096, N=1024, K=512, lda=1024, ldb=1024, ldc=2048, b_layout=GEMM_OUT_CONTIG,
                   batch=2, stride_a=512, stride_b=512 * 1024, stride_c=1024, epilogue=EPI_RELU_GRAD, relu_mask=mkw, ld_mask=mkw.stride(0), stride_mask=256))
-for _, d, _ in cases:
+# ragged tiles (the epilogue's per-element path): 1000 x 500 per net
+mkr = K.alloc_relu_mask(1000, 1024, dev)
+hr_ = torch.empty(1000, 1024, device=dev)
+xr = rnd(1000, 2048)
+cases.append(case("x3 ragged batched layer writing the bit mask", A=xr, B=w3, C=hr_, M=1000, N=500, K=1024, lda=2048, ldb=1024, ldc=1024, activation=ACT_RELU, batch=2,
+                  stride_a=1024, stride_b=512 * 1024, stride_c=512, relu_mask=mkr, ld_mask=mkr.stride(0), stride_mask=128))
+K.launch_gemm(*cases[-1][1])
+dyr, dxr = rnd(1000, 144), torch.empty(1000, 1024, device=dev)
+cases.append(case("x3 ragged input gradient READING the bit mask", A=dyr, B=whd, C=dxr, M=1000, N=500, K=69, lda=144, ldb=512, ldc=1024, b_layout=GEMM_OUT_CONTIG, batch=2,
+                  stride_a=72, stride_b=69 * 512, stride_c=512, epilogue=EPI_RELU_GRAD, relu_mask=mkr, ld_mask=mkr.stride(0), stride_mask=128))
+# ... and with the 256 x 256 tile forced (gemm option 4 = 2): the kernel that serves these launches at 16384 rows
+dxw2 = torch.empty(4096, 2048, device=dev)
+cases.append(case("[wide forced] input gradient READING the bit mask", A=dz2, B=w2b, C=dxw2, M=4096, N=1024, K=512, lda=1024, ldb=1024, ldc=2048, b_layout=GEMM_OUT_CONTIG,
+                  batch=2, stride_a=512, stride_b=512 * 1024, stride_c=1024, epilogue=EPI_RELU_GRAD, relu_mask=mkw, ld_mask=mkw.stride(0), stride_mask=256))
+hw2, mkw2 = torch.empty(4096, 2048, device=dev), K.alloc_relu_mask(4096, 2048, dev)
+cases.append(case("[wide forced] forward writing the bit mask", A=x, B=w, C=hw2, M=4096, N=2048, K=934, lda=960, ldb=960, ldc=2048, bias=b, activation=ACT_RELU,
+                  relu_mask=mkw2, ld_mask=mkw2.stride(0)))
+WIDE = {len(cases) - 2, len(cases) - 1}
+
+
+def launch(i, d):
+    if i in WIDE:
+        K.gemm_set_option(4, 2)
     K.launch_gemm(*d)
+    if i in WIDE:
+        K.gemm_set_option(4, 0)
+
+
+for i, (_, d, _) in enumerate(cases):
+    launch(i, d)
 torch.cuda.synchronize()
 refs = [c[2].clone() for c in cases]
 side = torch.cuda.Stream()
@@ -83,7 +111,7 @@ for it in range(iters):
             K.launch_gemm(*d_side)
             K.launch_gemm_x3p(*d_side16)
     for i, (name, d, out) in enumerate(cases):
-        K.launch_gemm(*d)
+        launch(i, d)
         bad[i] += (out != refs[i]).sum()
 torch.cuda.synchronize()
 for (name, _, _), n in zip(cases, bad.tolist()):

@@ -1,0 +1,24 @@
+"""GPU: every x3 launch form of the product path gives the same bits beside a second stream's GEMMs as alone (tools/gemm_contend_probe.py).
+
+Round-6 finding: the 128 x 128 kernel's store loop that consumed the ReLU bit mask was bit-identical in every test and returned
+garbage in a few elements per thousand launches as soon as another stream's GEMMs ran beside it -- nothing in the suite ran two streams of GEMMs on
+purpose.  This does: the probe's thirteen launch forms (all tilings; bit-mask writers and readers on the fast, ragged and 256 x 256 paths), 600 launches each.
+The loop that was removed showed ~1.3 differing elements per launch in this probe."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_all_x3_launch_forms_are_stable_beside_a_second_stream():
+    env = dict(os.environ, ITERS="600")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_contend_probe.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "launches beside a second stream" in l]
+    assert len(lines) >= 13, r.stdout[-2000:]
+    bad = [l for l in lines if not l.rstrip().endswith(": 0 elements differ from the launch alone")]
+    assert not bad, "\n".join(bad)

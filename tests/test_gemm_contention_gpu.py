@@ -22,3 +22,15 @@ def test_all_x3_launch_forms_are_stable_beside_a_second_stream():
     assert len(lines) >= 13, r.stdout[-2000:]
     bad = [l for l in lines if not l.rstrip().endswith(": 0 elements differ from the launch alone")]
     assert not bad, "\n".join(bad)
+
+
+def test_bf16_storage_relu_launches_are_stable_beside_a_second_stream():
+    """The bf16-storage twin (tools/mask8_contend_probe.py): the ReLU forward's round-once rows (outputs, sign bytes) and the relu-grad launches that read
+    the sign bytes / the bf16 activations, with column sums, 500 launches each beside a second stream's x3 and bf16-storage GEMMs."""
+    env = dict(os.environ, ITERS="500")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mask8_contend_probe.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "iterations:" in l]
+    assert len(lines) == 2, r.stdout[-2000:]
+    for l in lines:
+        assert "sign-byte variant mismatches 0, aux variant 0, column sums 0, forward outputs / sign bytes 0" in l, l
